@@ -1,0 +1,228 @@
+/*
+ * vpcc_recon.h — C ABI of the MI355X-native V-PCC point-cloud reconstruction path.
+ *
+ * This is the drop-in boundary for the per-frame reconstruction hot path of the
+ * Rust crate benclmnt/tmc2-rs (reference).  The reference has no FFI layer; the
+ * entry points below are what a `extern "C"` binding placed inside the
+ * reference's worker thread (src/decoder.rs:188-314) would call instead of
+ *
+ *   codec::generate_block_to_patch_from_occupancy_map_video   src/codec.rs:205-250
+ *   codec::generate_point_cloud (+ generate_points,           src/codec.rs:256-514, 517-565
+ *          color_point_cloud)                                  src/codec.rs:569-658
+ *   PointSet3::convert_yuv16_to_rgb8 / convert_yuv10_to_rgb8   src/codec.rs:88-94, 661-687
+ *
+ * The Rust side of the binding is shown in INTEGRATION.md.
+ *
+ * Conventions
+ *   - plain C, no C++/torch/HIP types in signatures; HIP streams travel as void*.
+ *   - every function returns a vpcc_status (0 = OK).  The reference has no error
+ *     channel on this path: it panics (assert!/unwrap/unimplemented!) and the
+ *     consumer sees end-of-stream (src/lib.rs:113-145).  Each non-zero status
+ *     names the reference panic it stands for; the Rust shim turns it back into
+ *     a panic to keep that behaviour.
+ *   - all arithmetic that the reference does in `usize` and truncates with
+ *     `as u16` is reproduced modulo 2^16, so 32-bit descriptor fields give
+ *     identical results.
+ */
+#ifndef VPCC_RECON_H
+#define VPCC_RECON_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define VPCC_ABI_VERSION 1
+
+/* ------------------------------------------------------------------ status */
+typedef enum vpcc_status {
+  VPCC_OK = 0,
+  VPCC_ERR_INVALID_ARG = 1,      /* null pointer / zero size / inconsistent descriptor          */
+  VPCC_ERR_UNSUPPORTED = 2,      /* reference: unimplemented!() (src/codec.rs:285-287,429-440…) */
+  VPCC_ERR_PATCH_OUT_OF_CANVAS = 3, /* reference: assert!(x < canvas_stride && y < canvas_height)
+                                      src/decoder.rs:835,848, or Image::get bounds assert :974    */
+  VPCC_ERR_SHORT_VIDEO = 4,      /* reference: generate_point_cloud -> None -> unwrap panic
+                                      (src/codec.rs:318-320, src/decoder.rs:271) or
+                                      video.get(1).unwrap() (src/codec.rs:589-590)               */
+  VPCC_ERR_CAPACITY = 5,         /* caller-provided output capacity too small (no reference analogue) */
+  VPCC_ERR_DEVICE = 6,           /* HIP runtime error; see vpcc_last_error()                      */
+  VPCC_ERR_NO_DEVICE = 7,        /* no gfx950 device / HIP extension unusable: the product path
+                                      has NO CPU fallback and fails loudly                        */
+  VPCC_ERR_STATE = 8             /* call order violated (e.g. results read before reconstruct)    */
+} vpcc_status;
+
+/* ------------------------------------------------------------- output types */
+/* Layout-compatible with cgmath::Vector3<u16> / Vector3<u8> (#[repr(C)]),
+ * i.e. with Vec<Point3D> / Vec<Color3B> storage (src/codec.rs:13-14, 23-24). */
+typedef struct vpcc_point3 { uint16_t x, y, z; } vpcc_point3;
+typedef struct vpcc_color3 { uint8_t r, g, b; } vpcc_color3;
+
+/* ------------------------------------------------------------ patch record */
+/* Exactly the `Patch` fields the hot path reads (src/decoder.rs:719-755), as
+ * produced by create_patch_frame (src/decoder.rs:415-486). */
+typedef enum vpcc_orientation {   /* PatchOrientation, src/decoder.rs:694-707 */
+  VPCC_ORIENT_DEFAULT = 0, VPCC_ORIENT_SWAP = 1, VPCC_ORIENT_ROT90 = 2,
+  VPCC_ORIENT_ROT180 = 3, VPCC_ORIENT_ROT270 = 4, VPCC_ORIENT_MIRROR = 5,
+  VPCC_ORIENT_MROT90 = 6, VPCC_ORIENT_MROT180 = 7, VPCC_ORIENT_MROT270 = 8
+} vpcc_orientation;
+
+typedef struct vpcc_patch {
+  uint32_t u0, v0;            /* uv0: location in the atlas, in blocks                */
+  uint32_t size_u0, size_v0;  /* size_uv0: size in blocks                             */
+  uint32_t u1, v1;            /* uv1: tangential / bitangential 3-D shift             */
+  uint32_t d1;                /* depth shift (already mode-adjusted, decoder.rs:468-473) */
+  uint32_t lod_x, lod_y;      /* level_of_detail, (1,1) in the supported envelope     */
+  uint8_t  normal_axis, tangent_axis, bitangent_axis;   /* axes, each in 0..2         */
+  uint8_t  projection_mode;   /* 0: min-depth related, 1: max-depth related           */
+  uint8_t  orientation;       /* vpcc_orientation                                      */
+  uint8_t  axis_of_additional_plane; /* must be 0 (src/codec.rs:429-440)              */
+  uint8_t  reserved[2];
+} vpcc_patch;
+
+/* ------------------------------------------------------------ video planes */
+/* Decoded video frames as the reference holds them in Image<T>
+ * (src/decoder.rs:961-1021): YUV420, luma index v*stride+u, chroma index
+ * (v/2)*cstride+(u/2) — nearest-neighbour chroma.  Strides are in ELEMENTS.
+ * The reference ignores libav's linesize and uses stride == width (luma) and
+ * width/2 (chroma); pass those to be bit-identical with it. */
+typedef struct vpcc_image_u8 {      /* occupancy video frame; only luma is read */
+  const uint8_t* y;
+  uint32_t width, height, stride;
+} vpcc_image_u8;
+
+typedef struct vpcc_image_u16 {     /* geometry / attribute frame, 10-bit in u16 (YUV420P10LE) */
+  const uint16_t* y;
+  const uint16_t* u;                /* may be NULL for geometry (never read)     */
+  const uint16_t* v;
+  uint32_t width, height;           /* luma size                                  */
+  uint32_t stride, cstride;         /* luma / chroma stride in elements           */
+} vpcc_image_u16;
+
+/* One atlas frame = one tile (the reference supports exactly one tile per
+ * frame, src/decoder.rs:200-206) with the video frames it consumes:
+ * occ_frames[f], geo_frames[0][f*map_count + m], attr_frames[0][f*map_count + m]
+ * (src/codec.rs:294, 317, 330, 545, 620-637). */
+typedef struct vpcc_frame_desc {
+  uint32_t width, height;            /* tile.width/height == ASPS frame size          */
+  uint32_t occupancy_resolution;     /* R = 1 << log2_patch_packing_block_size        */
+  uint32_t occupancy_precision;      /* vps.frame_width / occ video width (decoder.rs:194) */
+  uint32_t map_count;                /* map_count_minus1 + 1; parity is defined for 2  */
+  uint32_t absolute_d1;              /* GeneratePointCloudParams::absolute_d1          */
+  uint32_t attribute_count;          /* 0 or 1 (src/decoder.rs:133)                    */
+  uint32_t flags;                    /* VPCC_FRAME_* below                             */
+  vpcc_image_u8  occupancy;
+  vpcc_image_u16 geometry[2];        /* D0, D1                                          */
+  vpcc_image_u16 attribute[2];       /* attribute frame of layer 0 / 1                  */
+  const vpcc_patch* patches;         /* tile.patches, ascending patch index             */
+  uint32_t patch_count;
+  uint32_t reserved;
+} vpcc_frame_desc;
+
+#define VPCC_FRAME_RGB444 0x1u  /* ColorFormat::_Rgb444: copy_rgb16_to_rgb8 instead of
+                                   convert_yuv16_to_rgb8 (src/decoder.rs:301-305); unreachable in
+                                   the reference (format is always Yuv420) — rejected as UNSUPPORTED */
+
+/* Where the plane pointers of a vpcc_frame_desc live. */
+typedef enum vpcc_memory_kind {
+  VPCC_MEM_HOST = 0,    /* host pointers: the library stages them into HBM (H2D)   */
+  VPCC_MEM_DEVICE = 1   /* device pointers on the context's GPU: borrowed, zero-copy */
+} vpcc_memory_kind;
+
+/* ---------------------------------------------------------------- context */
+typedef struct vpcc_ctx vpcc_ctx;   /* one per GPU / per worker thread */
+typedef struct vpcc_gof vpcc_gof;   /* a batch of independent frames resident in HBM */
+
+int  vpcc_abi_version(void);
+const char* vpcc_status_string(int status);
+
+/* Creates a context on HIP device `device_id`.  Fails with VPCC_ERR_NO_DEVICE
+ * when no usable GPU exists — there is no CPU fallback. */
+int  vpcc_ctx_create(int device_id, vpcc_ctx** out);
+void vpcc_ctx_destroy(vpcc_ctx* ctx);
+const char* vpcc_last_error(const vpcc_ctx* ctx);
+
+/* Validates a frame descriptor on the host exactly as far as the reference's
+ * asserts would fire while walking it (patch extents, plane sizes, supported
+ * envelope).  Pure host function, no GPU needed. */
+int  vpcc_frame_validate(const vpcc_frame_desc* frame);
+
+/* Upper bound on the number of points one frame can produce
+ * (map_count × width × height). */
+uint64_t vpcc_frame_capacity_bound(const vpcc_frame_desc* frame);
+
+/* ------------------------------------------ one-shot seam replacements (sync) */
+/* Replaces codec::generate_block_to_patch_from_occupancy_map_video
+ * (src/codec.rs:205-250).  block_to_patch_out has (width/R)*(height/R) entries;
+ * 0 = unowned, else patch_index+1 (the reference stores usize; widen in the shim). */
+int vpcc_generate_block_to_patch(vpcc_ctx* ctx, const vpcc_frame_desc* frame,
+                                 vpcc_memory_kind planes, uint32_t* block_to_patch_out);
+
+/* Replaces the nearest-neighbour occupancy upsample (src/codec.rs:288-301);
+ * occupancy_map_out has width*height bytes (tile.occupancy_map). */
+int vpcc_upsample_occupancy(vpcc_ctx* ctx, const vpcc_frame_desc* frame,
+                            vpcc_memory_kind planes, uint8_t* occupancy_map_out);
+
+/* Replaces, for one frame, the body of the per-frame loop src/decoder.rs:249-305:
+ * block->patch, generate_point_cloud (incl. color_point_cloud) and
+ * convert_yuv16_to_rgb8.  xyz_out/rgb_out are host arrays of `capacity` entries
+ * (rgb_out may be NULL when attribute_count == 0); patch_index_out (optional,
+ * may be NULL) receives the `partition` vector (src/codec.rs:452) as u16.
+ * *n_points receives the point count even on VPCC_ERR_CAPACITY. */
+int vpcc_reconstruct_frame(vpcc_ctx* ctx, const vpcc_frame_desc* frame, vpcc_memory_kind planes,
+                           vpcc_point3* xyz_out, vpcc_color3* rgb_out, uint16_t* patch_index_out,
+                           size_t capacity, size_t* n_points);
+
+/* ------------------------------------------------- batched GOF path (async) */
+/* Frames of a group-of-frames are independent (src/decoder.rs:186, 403-407).
+ * A vpcc_gof keeps n_frames frames resident in HBM and reconstructs them in
+ * one batched launch sequence.  With VPCC_MEM_HOST the planes are copied to
+ * HBM at creation; with VPCC_MEM_DEVICE they are borrowed and must outlive the
+ * gof.  capacity_points is the per-frame output capacity (0 = the safe bound
+ * vpcc_frame_capacity_bound()). */
+int  vpcc_gof_create(vpcc_ctx* ctx, const vpcc_frame_desc* frames, uint32_t n_frames,
+                     vpcc_memory_kind planes, uint64_t capacity_points, uint32_t gof_flags,
+                     vpcc_gof** out);
+void vpcc_gof_destroy(vpcc_gof* gof);
+
+#define VPCC_GOF_WANT_PATCH_INDEX 0x1u  /* also emit per-point patch index (partition)          */
+#define VPCC_GOF_FORCE_GENERAL    0x2u  /* force the general (all-orientation) kernel sequence  */
+#define VPCC_GOF_PROFILE          0x4u  /* record per-kernel HIP-event timings                  */
+
+/* Enqueues the reconstruction of frames [first, first+count) on `hip_stream`
+ * (a hipStream_t passed as void*; NULL = the context's own stream).  Returns
+ * immediately; results are valid after vpcc_gof_sync() or a stream sync. */
+int vpcc_gof_reconstruct(vpcc_gof* gof, uint32_t first, uint32_t count, void* hip_stream);
+int vpcc_gof_sync(vpcc_gof* gof);
+
+/* Per-frame point counts of the last reconstruct (synchronises). */
+int vpcc_gof_point_counts(vpcc_gof* gof, uint32_t* counts_out /* n_frames */);
+
+/* Device pointers of frame `frame`'s outputs (vpcc_point3[capacity],
+ * vpcc_color3[capacity], uint16_t[capacity] or NULL) and of its device-side
+ * point counter (uint32_t).  Any of the out-pointers may be NULL. */
+int vpcc_gof_device_outputs(vpcc_gof* gof, uint32_t frame, void** d_xyz, void** d_rgb,
+                            void** d_patch_index, void** d_count);
+
+/* Copies one frame's result to host arrays (synchronises). */
+int vpcc_gof_download(vpcc_gof* gof, uint32_t frame, vpcc_point3* xyz_out, vpcc_color3* rgb_out,
+                      uint16_t* patch_index_out, size_t capacity, size_t* n_points);
+
+/* Per-frame status of the last reconstruct: VPCC_OK or VPCC_ERR_CAPACITY. */
+int vpcc_gof_frame_status(vpcc_gof* gof, uint32_t frame);
+
+/* Profile mode (VPCC_GOF_PROFILE): names and milliseconds of the kernels of the
+ * last vpcc_gof_reconstruct, measured with HIP events on the launch stream.
+ * Returns the number of kernels (<= max). */
+int vpcc_gof_kernel_times(vpcc_gof* gof, const char** names_out, float* ms_out, int max);
+
+/* Algorithmic bytes of frame `frame` as SURVEY.md §8(d) defines them
+ * (occupancy + geometry luma + attribute Y/U/V planes read once, 9 B/point
+ * written once), using the measured point count of the last reconstruct. */
+int vpcc_gof_algorithmic_bytes(vpcc_gof* gof, uint32_t frame, uint64_t* bytes_out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* VPCC_RECON_H */

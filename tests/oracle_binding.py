@@ -1,0 +1,142 @@
+"""ctypes binding of oracle/libvpcc_oracle.so — TEST INFRASTRUCTURE ONLY.
+
+Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg import
+this module; nothing under tmc2-rs_amd/ does.
+"""
+import ctypes as C
+import os
+import subprocess
+import sys
+
+import numpy as np
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if os.path.join(REPO, "tmc2-rs_amd") not in sys.path:
+    sys.path.insert(0, os.path.join(REPO, "tmc2-rs_amd"))
+
+from tmc2rs._abi import (COLOR3_DTYPE, POINT3_DTYPE, FrameDesc, Patch,  # noqa: E402
+                         host_frame_desc)
+
+ORACLE_SO = os.path.join(REPO, "oracle", "libvpcc_oracle.so")
+
+
+class OracleFrame(C.Structure):
+    _fields_ = [
+        ("occupancy_map", C.POINTER(C.c_uint8)),
+        ("block_to_patch", C.POINTER(C.c_uint64)),
+        ("positions", C.c_void_p),
+        ("colors16", C.POINTER(C.c_uint16)),
+        ("colors", C.c_void_p),
+        ("partition", C.POINTER(C.c_uint64)),
+        ("point_to_pixel", C.POINTER(C.c_uint32)),
+        ("n_points", C.c_size_t), ("cap_points", C.c_size_t),
+        ("n_blocks", C.c_size_t), ("n_pixels", C.c_size_t),
+    ]
+
+
+class Point3(C.Structure):
+    _fields_ = [("x", C.c_uint16), ("y", C.c_uint16), ("z", C.c_uint16)]
+
+
+class Color3(C.Structure):
+    _fields_ = [("r", C.c_uint8), ("g", C.c_uint8), ("b", C.c_uint8)]
+
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(ORACLE_SO):
+            subprocess.check_call(["make", "-C", REPO, "oracle"])
+        L = C.CDLL(ORACLE_SO)
+        L.vpcc_oracle_patch_to_canvas.argtypes = [C.POINTER(Patch), C.c_uint64, C.c_uint64, C.c_uint64,
+                                                  C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]
+        L.vpcc_oracle_patch_to_canvas.restype = None
+        L.vpcc_oracle_generate_point.argtypes = [C.POINTER(Patch), C.c_uint64, C.c_uint64, C.c_uint16]
+        L.vpcc_oracle_generate_point.restype = Point3
+        L.vpcc_oracle_yuv10_to_rgb8.argtypes = [C.c_uint16, C.c_uint16, C.c_uint16]
+        L.vpcc_oracle_yuv10_to_rgb8.restype = Color3
+        L.vpcc_oracle_block_to_patch.argtypes = [C.POINTER(FrameDesc), C.c_void_p]
+        L.vpcc_oracle_reconstruct_frame.argtypes = [C.POINTER(FrameDesc), C.POINTER(OracleFrame)]
+        L.vpcc_oracle_frame_free.argtypes = [C.POINTER(OracleFrame)]
+        L.vpcc_oracle_frame_free.restype = None
+        L.vpcc_oracle_time_frames.argtypes = [C.POINTER(FrameDesc), C.c_uint32, C.c_uint32,
+                                              C.POINTER(C.c_uint64), C.POINTER(C.c_int)]
+        L.vpcc_oracle_time_frames.restype = C.c_double
+        _lib = L
+    return _lib
+
+
+def make_patch(**kw):
+    p = Patch()
+    p.lod_x = p.lod_y = 1
+    for k, v in kw.items():
+        setattr(p, k, v)
+    return p
+
+
+def yuv_to_rgb(y, u, v):
+    c = lib().vpcc_oracle_yuv10_to_rgb8(y, u, v)
+    return (c.r, c.g, c.b)
+
+
+def generate_point(patch, u, v, depth):
+    p = lib().vpcc_oracle_generate_point(C.byref(patch), u, v, depth)
+    return (p.x, p.y, p.z)
+
+
+def patch_to_canvas(patch, u, v, resolution):
+    x, y = C.c_uint64(), C.c_uint64()
+    lib().vpcc_oracle_patch_to_canvas(C.byref(patch), u, v, resolution, C.byref(x), C.byref(y))
+    return x.value, y.value
+
+
+def block_to_patch(frame):
+    desc, keep = host_frame_desc(frame)
+    R = desc.occupancy_resolution
+    n = (desc.width // R) * (desc.height // R)
+    out = np.zeros(n, dtype=np.uint64)
+    st = lib().vpcc_oracle_block_to_patch(C.byref(desc), out.ctypes.data)
+    return st, out
+
+
+def reconstruct(frame):
+    """Runs the oracle on a frame dict.  Returns (status, result dict of numpy copies)."""
+    desc, keep = host_frame_desc(frame)
+    fr = OracleFrame()
+    st = lib().vpcc_oracle_reconstruct_frame(C.byref(desc), C.byref(fr))
+    if st != 0:
+        return st, None
+    n = fr.n_points
+
+    def arr(ptr, dtype, count):
+        if count == 0:
+            return np.zeros(0, dtype=dtype)
+        nbytes = count * np.dtype(dtype).itemsize
+        buf = (C.c_uint8 * nbytes).from_address(ptr if isinstance(ptr, int) else C.addressof(ptr.contents))
+        return np.frombuffer(buf, dtype=dtype, count=count).copy()
+
+    res = {
+        "n": n,
+        "occupancy_map": arr(fr.occupancy_map, np.uint8, fr.n_pixels).reshape(desc.height, desc.width),
+        "block_to_patch": arr(fr.block_to_patch, np.uint64, fr.n_blocks),
+        "positions": arr(fr.positions, POINT3_DTYPE, n),
+        "colors16": arr(fr.colors16, np.uint16, 3 * n).reshape(-1, 3),
+        "colors": arr(fr.colors, COLOR3_DTYPE, n),
+        "partition": arr(fr.partition, np.uint64, n),
+        "point_to_pixel": arr(fr.point_to_pixel, np.uint32, 3 * n).reshape(-1, 3),
+    }
+    lib().vpcc_oracle_frame_free(C.byref(fr))
+    return st, res
+
+
+def xyz_array(res):
+    p = res["positions"]
+    return np.stack([p["x"], p["y"], p["z"]], axis=1) if len(p) else np.zeros((0, 3), np.uint16)
+
+
+def rgb_array(res):
+    c = res["colors"]
+    return np.stack([c["r"], c["g"], c["b"]], axis=1) if len(c) else np.zeros((0, 3), np.uint8)
