@@ -11,6 +11,7 @@ import pytest
 
 import oracle_binding as ob
 import pyref
+from cases import _patch, _tiny_frame
 from tmc2rs import synth
 from tmc2rs._abi import PATCH_DTYPE
 
@@ -106,30 +107,7 @@ def test_patch_to_canvas_all_orientations():
     assert ob.patch_to_canvas(ob.make_patch(u0=0, v0=0, size_u0=1, size_v0=1, orientation=3), 5, 0, 16)[0] == (1 - 1 - 5) % (1 << 64)
 
 
-# ---- tiny frames built by hand ----------------------------------------------
-def _tiny_frame(patches, occ, W=32, H=32, R=16, prec=4, geo0=None, geo1=None, seed=1):
-    rng = np.random.RandomState(seed)
-    g0 = geo0 if geo0 is not None else (rng.randint(0, 800, size=(H, W))).astype(np.uint16)
-    g1 = geo1 if geo1 is not None else (g0 + 4 * rng.randint(0, 4, size=(H, W))).astype(np.uint16)
-    attr = []
-    for _ in range(2):
-        attr.append((rng.randint(64, 941, size=(H, W)).astype(np.uint16),
-                     rng.randint(64, 961, size=(H // 2, W // 2)).astype(np.uint16),
-                     rng.randint(64, 961, size=(H // 2, W // 2)).astype(np.uint16)))
-    return {"width": W, "height": H, "occupancy_resolution": R, "occupancy_precision": prec,
-            "map_count": 2, "absolute_d1": 1, "attribute_count": 1, "flags": 0,
-            "patches": np.array(patches, dtype=PATCH_DTYPE), "occupancy": occ.astype(np.uint8),
-            "geometry": [g0, g1], "attribute": attr}
-
-
-def _patch(u0, v0, su, sv, view=0, orient=0, u1=0, v1=0, d1=0):
-    n, t, b, mode = synth.VIEW_AXES[view]
-    r = np.zeros((), dtype=PATCH_DTYPE)
-    r["u0"], r["v0"], r["size_u0"], r["size_v0"] = u0, v0, su, sv
-    r["u1"], r["v1"], r["d1"], r["lod_x"], r["lod_y"] = u1, v1, d1, 1, 1
-    r["normal_axis"], r["tangent_axis"], r["bitangent_axis"], r["projection_mode"] = n, t, b, mode
-    r["orientation"] = orient
-    return r
+# ---- tiny frames built by hand (tests/cases.py) ------------------------------
 
 
 def test_duplicate_removal_and_depth_div4():

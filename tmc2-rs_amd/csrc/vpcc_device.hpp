@@ -1,0 +1,75 @@
+// vpcc_device.hpp — structures shared by the host runtime and the gfx950 kernels.
+// Internal to libvpcc_recon.so; the public boundary is include/vpcc_recon.h.
+#pragma once
+
+#include <stdint.h>
+
+#include "vpcc_recon.h"
+
+namespace vpcc {
+
+// Patch as the kernels see it.  patch_to_canvas_helper (reference
+// src/decoder.rs:853-867) is affine in (u, v) for every orientation, so the
+// host folds orientation, uv0 and the reference's "size_uv0 stays in blocks"
+// quirk into integer coefficients: x = ax_u*u + ax_v*v + cx, y likewise.
+struct DevPatch {
+  int32_t ax_u, ax_v, cx;
+  int32_t ay_u, ay_v, cy;
+  uint32_t u1, v1, d1;
+  uint32_t lod_x, lod_y;
+  uint8_t normal_axis, tangent_axis, bitangent_axis, projection_mode;
+  uint32_t size_u0, size_v0;
+  uint32_t vb_base;   // first virtual block of this patch (emission order)
+  uint32_t pad;
+};
+static_assert(sizeof(DevPatch) == 64, "DevPatch is one 64-B record");
+
+// One virtual block = (patch, v0, u0) in the reference's emission order
+// (src/codec.rs:352-385): patch ascending, v0 outer, u0 inner.
+struct VBlock {
+  uint16_t patch;
+  uint16_t u0, v0;
+  uint16_t flags;
+  uint32_t canvas_block;  // patch_block_to_canvas_block(u0, v0)
+  uint32_t pad;
+};
+static_assert(sizeof(VBlock) == 16, "VBlock is 16 B");
+
+// Per-frame descriptor, resident in HBM, read by every kernel.
+struct DevFrame {
+  const uint8_t* occ;
+  const uint16_t* geo[2];
+  const uint16_t* attr_y[2];
+  const uint16_t* attr_u[2];
+  const uint16_t* attr_v[2];
+  const DevPatch* patches;
+  const VBlock* vblocks;
+  uint32_t* block_to_patch;   // bw*bh, 0 = unowned else patch+1
+  uint32_t* vb_count;         // points per virtual block
+  uint32_t* vb_offset;        // exclusive prefix of vb_count
+  vpcc_point3* out_xyz;
+  vpcc_color3* out_rgb;
+  uint16_t* out_patch;        // optional (partition), may be null
+  uint32_t* n_points;         // device counter of this frame
+  uint64_t* scan_state;       // single-pass path: one {status,value} word per work item
+  uint32_t occ_stride, occ_w, occ_h;
+  uint32_t geo_stride[2];
+  uint32_t attr_stride[2], attr_cstride[2];
+  uint32_t width, height, R, prec;
+  uint32_t bw, bh;
+  uint32_t n_patches, n_vblocks;
+  uint32_t map_count, absolute_d1, has_attr;
+  uint32_t capacity;
+  uint32_t pad[2];
+};
+
+// Kernel launchers (vpcc_kernels.hip).  All asynchronous on `stream`.
+void launch_block_owner(const DevFrame* d_frames, uint32_t first, uint32_t count, uint32_t max_vb,
+                        void* stream);
+void launch_count(const DevFrame* d_frames, uint32_t first, uint32_t count, uint32_t max_vb, void* stream);
+void launch_scan(const DevFrame* d_frames, uint32_t first, uint32_t count, void* stream);
+void launch_emit(const DevFrame* d_frames, uint32_t first, uint32_t count, uint32_t max_vb, void* stream);
+void launch_upsample_occupancy(const DevFrame* d_frames, uint32_t frame, uint8_t* d_out, uint32_t width,
+                               uint32_t height, void* stream);
+
+}  // namespace vpcc

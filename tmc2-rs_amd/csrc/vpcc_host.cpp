@@ -1,0 +1,148 @@
+// vpcc_host.cpp — frame validation and patch-table planning (host side, no GPU calls).
+#include "vpcc_host.hpp"
+
+#include <algorithm>
+
+namespace vpcc {
+
+Affine patch_affine(const vpcc_patch& p, int64_t res) {
+  const int64_t u0 = (int64_t)p.u0 * res, v0 = (int64_t)p.v0 * res;
+  const int64_t su = p.size_u0, sv = p.size_v0;   // blocks at every resolution (reference quirk)
+  Affine a{};
+  switch (p.orientation) {
+    case VPCC_ORIENT_DEFAULT: a = {1, 0, u0, 0, 1, v0}; break;
+    case VPCC_ORIENT_ROT90:   a = {0, -1, sv - 1 + u0, 1, 0, v0}; break;
+    case VPCC_ORIENT_ROT180:  a = {-1, 0, su - 1 + u0, 0, -1, sv - 1 + v0}; break;
+    case VPCC_ORIENT_ROT270:  a = {0, 1, u0, -1, 0, su - 1 + v0}; break;
+    case VPCC_ORIENT_MIRROR:  a = {-1, 0, su - 1 + u0, 0, 1, v0}; break;
+    case VPCC_ORIENT_MROT90:  a = {0, -1, sv - 1 + u0, -1, 0, su - 1 + v0}; break;
+    case VPCC_ORIENT_MROT180: a = {1, 0, u0, 0, -1, sv - 1 + v0}; break;
+    case VPCC_ORIENT_MROT270:
+    case VPCC_ORIENT_SWAP:    a = {0, 1, u0, 1, 0, v0}; break;
+    default: break;
+  }
+  return a;
+}
+
+namespace {
+
+// Are all mapped coordinates of u in [0,nu), v in [0,nv) inside [0,w) x [0,h)?  The map is
+// affine, so the extremes sit at the corners.  Signed arithmetic: a negative value is what the
+// reference's wrapping usize turns into a huge number that fails its assert.
+bool extent_inside(const Affine& a, int64_t nu, int64_t nv, int64_t w, int64_t h) {
+  if (nu <= 0 || nv <= 0) return true;   // empty loops never evaluate the assert
+  const int64_t us[2] = {0, nu - 1}, vs[2] = {0, nv - 1};
+  for (int i = 0; i < 2; ++i)
+    for (int j = 0; j < 2; ++j) {
+      const int64_t x = a.ax_u * us[i] + a.ax_v * vs[j] + a.cx;
+      const int64_t y = a.ay_u * us[i] + a.ay_v * vs[j] + a.cy;
+      if (x < 0 || y < 0 || x >= w || y >= h) return false;
+    }
+  return true;
+}
+
+}  // namespace
+
+int validate_frame(const vpcc_frame_desc* f) {
+  if (!f) return VPCC_ERR_INVALID_ARG;
+  if (f->width == 0 || f->height == 0 || f->occupancy_resolution == 0 || f->occupancy_precision == 0)
+    return VPCC_ERR_INVALID_ARG;
+  if (f->width > 32768 || f->height > 32768) return VPCC_ERR_INVALID_ARG;
+  if (f->map_count < 1 || f->map_count > 2) return VPCC_ERR_UNSUPPORTED;       // multiple maps > 2 never produced
+  if (f->attribute_count > 1) return VPCC_ERR_UNSUPPORTED;                      // src/decoder.rs:133
+  if (f->flags & VPCC_FRAME_RGB444) return VPCC_ERR_UNSUPPORTED;                // unreachable in the reference
+  if (f->patch_count && !f->patches) return VPCC_ERR_INVALID_ARG;
+  if (f->patch_count > 65535) return VPCC_ERR_INVALID_ARG;
+  if (!f->occupancy.y || f->occupancy.stride < f->occupancy.width) return VPCC_ERR_INVALID_ARG;
+
+  const int64_t W = f->width, H = f->height, R = f->occupancy_resolution, prec = f->occupancy_precision;
+  const int64_t bw = W / R, bh = H / R;
+
+  // occupancy upsample touches every canvas pixel: Image::get bounds assert, src/decoder.rs:974
+  if ((W - 1) / prec >= (int64_t)f->occupancy.width || (H - 1) / prec >= (int64_t)f->occupancy.height)
+    return VPCC_ERR_PATCH_OUT_OF_CANVAS;
+
+  // geometry frames f*map_count .. must exist: src/codec.rs:317-321
+  for (uint32_t m = 0; m < f->map_count; ++m) {
+    const vpcc_image_u16& G = f->geometry[m];
+    if (!G.y) return VPCC_ERR_SHORT_VIDEO;
+    if (G.stride < G.width) return VPCC_ERR_INVALID_ARG;
+    if ((int64_t)G.width < W || (int64_t)G.height < H) return VPCC_ERR_PATCH_OUT_OF_CANVAS;
+  }
+  if (f->attribute_count) {
+    for (uint32_t m = 0; m < f->map_count; ++m) {
+      const vpcc_image_u16& A = f->attribute[m];
+      if (!A.y || !A.u || !A.v) return VPCC_ERR_SHORT_VIDEO;                    // src/codec.rs:589-590, 637
+      if (A.stride < A.width || A.cstride < A.width / 2) return VPCC_ERR_INVALID_ARG;
+      if ((int64_t)A.width < W || (int64_t)A.height < H) return VPCC_ERR_PATCH_OUT_OF_CANVAS;
+    }
+  }
+
+  uint64_t n_vb = 0;
+  for (uint32_t i = 0; i < f->patch_count; ++i) {
+    const vpcc_patch& p = f->patches[i];
+    if (p.axis_of_additional_plane != 0) return VPCC_ERR_UNSUPPORTED;           // src/codec.rs:437
+    if (p.normal_axis > 2 || p.tangent_axis > 2 || p.bitangent_axis > 2) return VPCC_ERR_INVALID_ARG;
+    if (p.projection_mode > 1) return VPCC_ERR_INVALID_ARG;                     // unreachable!() decoder.rs:886
+    if (p.orientation > VPCC_ORIENT_MROT270) return VPCC_ERR_INVALID_ARG;
+    if (p.size_u0 == 0 || p.size_v0 == 0) continue;
+    if (p.size_u0 > 65535 || p.size_v0 > 65535) return VPCC_ERR_PATCH_OUT_OF_CANVAS;
+    // assert in patch_block_to_canvas_block, src/decoder.rs:835
+    if (!extent_inside(patch_affine(p, 1), p.size_u0, p.size_v0, bw, bh)) return VPCC_ERR_PATCH_OUT_OF_CANVAS;
+    // assert in patch_to_canvas, src/decoder.rs:848
+    if (!extent_inside(patch_affine(p, R), (int64_t)p.size_u0 * R, (int64_t)p.size_v0 * R, W, H))
+      return VPCC_ERR_PATCH_OUT_OF_CANVAS;
+    n_vb += (uint64_t)p.size_u0 * p.size_v0;
+  }
+  if (n_vb > 0x7FFFFFFFull) return VPCC_ERR_INVALID_ARG;
+  return VPCC_OK;
+}
+
+void plan_frame(const vpcc_frame_desc& f, FramePlan* out) {
+  const int64_t R = f.occupancy_resolution;
+  out->bw = f.width / f.occupancy_resolution;
+  out->bh = f.height / f.occupancy_resolution;
+  out->patches.resize(f.patch_count);
+  out->vblocks.clear();
+  out->simple_orientations = true;
+  uint32_t vb_base = 0;
+  for (uint32_t i = 0; i < f.patch_count; ++i) {
+    const vpcc_patch& p = f.patches[i];
+    const Affine px = patch_affine(p, R), bl = patch_affine(p, 1);
+    DevPatch& d = out->patches[i];
+    d = DevPatch{};
+    d.ax_u = (int32_t)px.ax_u; d.ax_v = (int32_t)px.ax_v; d.cx = (int32_t)px.cx;
+    d.ay_u = (int32_t)px.ay_u; d.ay_v = (int32_t)px.ay_v; d.cy = (int32_t)px.cy;
+    d.u1 = p.u1; d.v1 = p.v1; d.d1 = p.d1;
+    d.lod_x = p.lod_x; d.lod_y = p.lod_y;
+    d.normal_axis = p.normal_axis; d.tangent_axis = p.tangent_axis; d.bitangent_axis = p.bitangent_axis;
+    d.projection_mode = p.projection_mode;
+    d.size_u0 = p.size_u0; d.size_v0 = p.size_v0;
+    d.vb_base = vb_base;
+    if (!(p.orientation == VPCC_ORIENT_DEFAULT || p.orientation == VPCC_ORIENT_SWAP ||
+          p.orientation == VPCC_ORIENT_MROT270))
+      out->simple_orientations = false;
+    for (uint32_t v0 = 0; v0 < p.size_v0; ++v0)
+      for (uint32_t u0 = 0; u0 < p.size_u0; ++u0) {
+        VBlock b{};
+        b.patch = (uint16_t)i;
+        b.u0 = (uint16_t)u0;
+        b.v0 = (uint16_t)v0;
+        const int64_t bx = bl.ax_u * u0 + bl.ax_v * v0 + bl.cx, by = bl.ay_u * u0 + bl.ay_v * v0 + bl.cy;
+        b.canvas_block = (uint32_t)(by * out->bw + bx);
+        out->vblocks.push_back(b);
+      }
+    vb_base += p.size_u0 * p.size_v0;
+  }
+  // B = Wo*Ho + M*W*H*2 + M*(W*H*2 + 2*(W/2)*(H/2)*2) + 9*N (N added at run time)
+  uint64_t bytes = (uint64_t)f.occupancy.width * f.occupancy.height;
+  for (uint32_t m = 0; m < f.map_count; ++m) {
+    bytes += (uint64_t)f.geometry[m].width * f.geometry[m].height * 2;
+    if (f.attribute_count)
+      bytes += (uint64_t)f.attribute[m].width * f.attribute[m].height * 2 +
+               2ull * (f.attribute[m].width / 2) * (f.attribute[m].height / 2) * 2;
+  }
+  out->plane_bytes = bytes;
+}
+
+}  // namespace vpcc

@@ -1,0 +1,39 @@
+// vpcc_host.hpp — host-side planning of one atlas frame: validation (the reference's asserts,
+// evaluated up front) and translation of the patch table into the kernels' work lists.
+#pragma once
+
+#include <stdint.h>
+
+#include <vector>
+
+#include "vpcc_device.hpp"
+
+namespace vpcc {
+
+// Integer coefficients of Patch::patch_to_canvas_helper (reference src/decoder.rs:853-867):
+//   x = ax_u*u + ax_v*v + cx ,  y = ay_u*u + ay_v*v + cy      at resolution `res`
+// (res = 1: block map, res = R: pixel map).  size_uv0 stays in BLOCKS at every resolution,
+// exactly as the reference computes it.
+struct Affine {
+  int64_t ax_u, ax_v, cx, ay_u, ay_v, cy;
+};
+Affine patch_affine(const vpcc_patch& p, int64_t res);
+
+struct FramePlan {
+  std::vector<DevPatch> patches;
+  std::vector<VBlock> vblocks;       // every (patch, v0, u0) in emission order
+  uint32_t bw = 0, bh = 0;
+  bool simple_orientations = true;   // only Default / Swap (/MRot270 == Swap) patches
+  uint64_t plane_bytes = 0;          // occupancy + geometry luma + attribute Y,U,V planes
+};
+
+// VPCC_OK or the status that stands for the reference panic this frame would run into.
+// Deliberately stricter than the reference in two data-dependent places (documented in DESIGN.md):
+// geometry/attribute planes must cover the whole canvas, and must be present, regardless of
+// whether an occupied pixel would actually touch the missing part.
+int validate_frame(const vpcc_frame_desc* f);
+
+// Requires validate_frame(f) == VPCC_OK.
+void plan_frame(const vpcc_frame_desc& f, FramePlan* out);
+
+}  // namespace vpcc

@@ -1,0 +1,559 @@
+// vpcc_runtime.hip — host runtime and C ABI (include/vpcc_recon.h) of libvpcc_recon.so.
+//
+// One vpcc_ctx per GPU / worker thread; a vpcc_gof keeps a batch of independent atlas frames
+// (reference: frames of a GOF are independent, src/decoder.rs:186, 403-407) resident in HBM in
+// ONE arena and reconstructs them with batched launches.  There is no CPU fallback anywhere in
+// this file: without a gfx950 device vpcc_ctx_create fails with VPCC_ERR_NO_DEVICE.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "vpcc_device.hpp"
+#include "vpcc_host.hpp"
+
+using namespace vpcc;
+
+// ----------------------------------------------------------------- objects
+struct vpcc_ctx {
+  int device = 0;
+  hipStream_t stream = nullptr;
+  std::string last_error;
+};
+
+struct KernelTiming {
+  const char* name;
+  hipEvent_t start, stop;
+  float ms;
+};
+
+struct vpcc_gof {
+  vpcc_ctx* ctx = nullptr;
+  uint32_t n_frames = 0;
+  uint32_t flags = 0;
+  uint64_t capacity = 0;
+  bool general = true;                 // general kernel sequence (vs single-pass fast path)
+  std::vector<FramePlan> plans;        // host-side per-frame plan
+  std::vector<DevFrame> h_frames;      // host mirror of d_frames
+  void* arena = nullptr;
+  size_t arena_bytes = 0;
+  DevFrame* d_frames = nullptr;
+  uint32_t* d_counts = nullptr;        // n_frames contiguous point counters
+  uint32_t* d_b2p = nullptr;           // all frames' block_to_patch, contiguous
+  size_t b2p_words = 0;
+  uint64_t* d_scan_state = nullptr;    // single-pass path
+  size_t scan_state_words = 0;
+  uint32_t max_vb = 0;
+  uint32_t* h_counts = nullptr;        // pinned
+  bool counts_valid = false;
+  bool launched = false;
+  hipEvent_t upload_done = nullptr;
+  hipStream_t last_stream = nullptr;
+  std::vector<KernelTiming> timings;
+  uint32_t n_timed = 0;
+};
+
+namespace {
+
+int fail(vpcc_ctx* ctx, int status, const std::string& msg) {
+  if (ctx) ctx->last_error = msg;
+  return status;
+}
+
+#define HIP_TRY(ctx, expr)                                                                       \
+  do {                                                                                           \
+    hipError_t _e = (expr);                                                                      \
+    if (_e != hipSuccess)                                                                        \
+      return fail((ctx), VPCC_ERR_DEVICE, std::string(#expr) + ": " + hipGetErrorString(_e));    \
+  } while (0)
+
+size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
+
+struct ArenaLayout {
+  size_t total = 0;
+  size_t take(size_t bytes) {
+    const size_t off = total;
+    total = align_up(total + bytes, 256);
+    return off;
+  }
+};
+
+}  // namespace
+
+// ------------------------------------------------------------------ basics
+extern "C" int vpcc_abi_version(void) { return VPCC_ABI_VERSION; }
+
+extern "C" const char* vpcc_status_string(int status) {
+  switch (status) {
+    case VPCC_OK: return "ok";
+    case VPCC_ERR_INVALID_ARG: return "invalid argument";
+    case VPCC_ERR_UNSUPPORTED: return "outside the supported envelope (reference: unimplemented!)";
+    case VPCC_ERR_PATCH_OUT_OF_CANVAS: return "patch/pixel outside canvas or plane (reference: assert!)";
+    case VPCC_ERR_SHORT_VIDEO: return "video shorter than the atlas (reference: unwrap on None)";
+    case VPCC_ERR_CAPACITY: return "output capacity too small";
+    case VPCC_ERR_DEVICE: return "HIP runtime error";
+    case VPCC_ERR_NO_DEVICE: return "no usable gfx950 device (no CPU fallback)";
+    case VPCC_ERR_STATE: return "call order violated";
+    default: return "unknown status";
+  }
+}
+
+extern "C" int vpcc_ctx_create(int device_id, vpcc_ctx** out) {
+  if (!out) return VPCC_ERR_INVALID_ARG;
+  *out = nullptr;
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess || n <= 0 || device_id < 0 || device_id >= n) return VPCC_ERR_NO_DEVICE;
+  hipDeviceProp_t prop;
+  if (hipGetDeviceProperties(&prop, device_id) != hipSuccess) return VPCC_ERR_NO_DEVICE;
+  if (std::strncmp(prop.gcnArchName, "gfx950", 6) != 0) return VPCC_ERR_NO_DEVICE;   // kernels exist for gfx950 only
+  if (hipSetDevice(device_id) != hipSuccess) return VPCC_ERR_NO_DEVICE;
+  vpcc_ctx* ctx = new vpcc_ctx();
+  ctx->device = device_id;
+  if (hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) != hipSuccess) {
+    delete ctx;
+    return VPCC_ERR_DEVICE;
+  }
+  *out = ctx;
+  return VPCC_OK;
+}
+
+extern "C" void vpcc_ctx_destroy(vpcc_ctx* ctx) {
+  if (!ctx) return;
+  (void)hipSetDevice(ctx->device);
+  if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
+  delete ctx;
+}
+
+extern "C" const char* vpcc_last_error(const vpcc_ctx* ctx) { return ctx ? ctx->last_error.c_str() : ""; }
+
+extern "C" int vpcc_frame_validate(const vpcc_frame_desc* frame) { return validate_frame(frame); }
+
+extern "C" uint64_t vpcc_frame_capacity_bound(const vpcc_frame_desc* frame) {
+  if (!frame) return 0;
+  return (uint64_t)frame->map_count * frame->width * frame->height;
+}
+
+// --------------------------------------------------------------------- gof
+extern "C" void vpcc_gof_destroy(vpcc_gof* gof) {
+  if (!gof) return;
+  (void)hipSetDevice(gof->ctx->device);
+  if (gof->last_stream) (void)hipStreamSynchronize(gof->last_stream);
+  (void)hipStreamSynchronize(gof->ctx->stream);
+  for (auto& t : gof->timings) {
+    (void)hipEventDestroy(t.start);
+    (void)hipEventDestroy(t.stop);
+  }
+  if (gof->upload_done) (void)hipEventDestroy(gof->upload_done);
+  if (gof->arena) (void)hipFree(gof->arena);
+  if (gof->h_counts) (void)hipHostFree(gof->h_counts);
+  delete gof;
+}
+
+namespace {
+
+// Elements of a chroma plane that the flat index (v/2)*cstride + (u/2) can reach.
+size_t chroma_elems(const vpcc_image_u16& a) {
+  if (a.width == 0 || a.height == 0) return 1;
+  return (size_t)((a.height - 1) / 2) * a.cstride + (a.width - 1) / 2 + 1;
+}
+
+// Copies a (possibly strided) host plane into a tight device plane.
+int copy_plane(vpcc_ctx* ctx, void* dst, const void* src, size_t elem, uint32_t width, uint32_t height,
+               uint32_t stride, hipStream_t s) {
+  if (stride == width) {
+    HIP_TRY(ctx, hipMemcpyAsync(dst, src, (size_t)width * height * elem, hipMemcpyHostToDevice, s));
+  } else {
+    HIP_TRY(ctx, hipMemcpy2DAsync(dst, (size_t)width * elem, src, (size_t)stride * elem, (size_t)width * elem, height,
+                                  hipMemcpyHostToDevice, s));
+  }
+  return VPCC_OK;
+}
+
+int gof_create_impl(vpcc_ctx* ctx, const vpcc_frame_desc* frames, uint32_t n_frames, vpcc_memory_kind kind,
+                    uint64_t capacity_points, uint32_t gof_flags, vpcc_gof* g) {
+  g->ctx = ctx;
+  g->n_frames = n_frames;
+  g->flags = gof_flags;
+  g->plans.resize(n_frames);
+  g->h_frames.resize(n_frames);
+
+  // 1. validate + plan every frame on the host (patch table -> affine patches + virtual blocks)
+  bool all_simple = true;
+  uint64_t cap = capacity_points;
+  for (uint32_t i = 0; i < n_frames; ++i) {
+    const int st = validate_frame(&frames[i]);
+    if (st) return fail(ctx, st, "frame " + std::to_string(i) + ": " + vpcc_status_string(st));
+    plan_frame(frames[i], &g->plans[i]);
+    all_simple = all_simple && g->plans[i].simple_orientations;
+    g->max_vb = std::max(g->max_vb, (uint32_t)g->plans[i].vblocks.size());
+    if (capacity_points == 0) cap = std::max<uint64_t>(cap, vpcc_frame_capacity_bound(&frames[i]));
+  }
+  if (cap == 0) cap = 1;
+  if (cap > 0xFFFFFFF0ull) return fail(ctx, VPCC_ERR_INVALID_ARG, "capacity_points exceeds 32 bits");
+  g->capacity = cap;
+  g->general = true;   // the single-pass fast path is selected in vpcc_gof_reconstruct when available
+  (void)all_simple;
+
+  // 2. arena layout
+  ArenaLayout L;
+  const size_t off_frames = L.take(sizeof(DevFrame) * n_frames);
+  const size_t off_counts = L.take(sizeof(uint32_t) * n_frames);
+  struct Off {
+    size_t patches, vblocks, b2p, vb_count, vb_offset, xyz, rgb, pidx, occ, geo[2], ay[2], au[2], av[2];
+  };
+  std::vector<Off> offs(n_frames);
+  // block_to_patch of all frames contiguous: one memset per reconstruct
+  size_t b2p_begin = L.total;
+  for (uint32_t i = 0; i < n_frames; ++i) {
+    const FramePlan& P = g->plans[i];
+    offs[i].b2p = L.total;
+    L.total += sizeof(uint32_t) * (size_t)P.bw * P.bh;
+  }
+  g->b2p_words = (L.total - b2p_begin) / sizeof(uint32_t);
+  L.total = align_up(L.total, 256);
+  for (uint32_t i = 0; i < n_frames; ++i) {
+    const vpcc_frame_desc& F = frames[i];
+    const FramePlan& P = g->plans[i];
+    Off& o = offs[i];
+    o.patches = L.take(sizeof(DevPatch) * std::max<size_t>(P.patches.size(), 1));
+    o.vblocks = L.take(sizeof(VBlock) * std::max<size_t>(P.vblocks.size(), 1));
+    o.vb_count = L.take(sizeof(uint32_t) * std::max<size_t>(P.vblocks.size(), 1));
+    o.vb_offset = L.take(sizeof(uint32_t) * std::max<size_t>(P.vblocks.size(), 1));
+    o.xyz = L.take(sizeof(vpcc_point3) * cap);
+    o.rgb = F.attribute_count ? L.take(sizeof(vpcc_color3) * cap) : 0;
+    o.pidx = (gof_flags & VPCC_GOF_WANT_PATCH_INDEX) ? L.take(sizeof(uint16_t) * cap) : 0;
+    if (kind == VPCC_MEM_HOST) {
+      o.occ = L.take((size_t)F.occupancy.width * F.occupancy.height);
+      for (uint32_t m = 0; m < F.map_count; ++m) {
+        o.geo[m] = L.take((size_t)F.geometry[m].width * F.geometry[m].height * 2);
+        if (F.attribute_count) {
+          o.ay[m] = L.take((size_t)F.attribute[m].width * F.attribute[m].height * 2);
+          o.au[m] = L.take(chroma_elems(F.attribute[m]) * 2);
+          o.av[m] = L.take(chroma_elems(F.attribute[m]) * 2);
+        }
+      }
+    }
+  }
+  g->arena_bytes = L.total;
+  HIP_TRY(ctx, hipMalloc(&g->arena, g->arena_bytes));
+  char* base = (char*)g->arena;
+  g->d_frames = (DevFrame*)(base + off_frames);
+  g->d_counts = (uint32_t*)(base + off_counts);
+  g->d_b2p = (uint32_t*)(base + b2p_begin);
+  HIP_TRY(ctx, hipHostMalloc((void**)&g->h_counts, sizeof(uint32_t) * n_frames, hipHostMallocDefault));
+  HIP_TRY(ctx, hipEventCreateWithFlags(&g->upload_done, hipEventDisableTiming));
+
+  // 3. fill descriptors and upload
+  hipStream_t s = ctx->stream;
+  for (uint32_t i = 0; i < n_frames; ++i) {
+    const vpcc_frame_desc& F = frames[i];
+    const FramePlan& P = g->plans[i];
+    const Off& o = offs[i];
+    DevFrame& D = g->h_frames[i];
+    std::memset(&D, 0, sizeof(D));
+    D.patches = (const DevPatch*)(base + o.patches);
+    D.vblocks = (const VBlock*)(base + o.vblocks);
+    D.block_to_patch = (uint32_t*)(base + o.b2p);
+    D.vb_count = (uint32_t*)(base + o.vb_count);
+    D.vb_offset = (uint32_t*)(base + o.vb_offset);
+    D.out_xyz = (vpcc_point3*)(base + o.xyz);
+    D.out_rgb = F.attribute_count ? (vpcc_color3*)(base + o.rgb) : nullptr;
+    D.out_patch = (gof_flags & VPCC_GOF_WANT_PATCH_INDEX) ? (uint16_t*)(base + o.pidx) : nullptr;
+    D.n_points = g->d_counts + i;
+    D.width = F.width; D.height = F.height; D.R = F.occupancy_resolution; D.prec = F.occupancy_precision;
+    D.bw = P.bw; D.bh = P.bh;
+    D.n_patches = (uint32_t)P.patches.size();
+    D.n_vblocks = (uint32_t)P.vblocks.size();
+    D.map_count = F.map_count; D.absolute_d1 = F.absolute_d1 ? 1u : 0u; D.has_attr = F.attribute_count ? 1u : 0u;
+    D.capacity = (uint32_t)cap;
+    D.occ_w = F.occupancy.width; D.occ_h = F.occupancy.height;
+    if (kind == VPCC_MEM_DEVICE) {
+      D.occ = F.occupancy.y; D.occ_stride = F.occupancy.stride;
+      for (uint32_t m = 0; m < F.map_count; ++m) {
+        D.geo[m] = F.geometry[m].y; D.geo_stride[m] = F.geometry[m].stride;
+        if (F.attribute_count) {
+          D.attr_y[m] = F.attribute[m].y; D.attr_u[m] = F.attribute[m].u; D.attr_v[m] = F.attribute[m].v;
+          D.attr_stride[m] = F.attribute[m].stride; D.attr_cstride[m] = F.attribute[m].cstride;
+        }
+      }
+    } else {
+      D.occ = (const uint8_t*)(base + o.occ); D.occ_stride = F.occupancy.width;
+      int st = copy_plane(ctx, base + o.occ, F.occupancy.y, 1, F.occupancy.width, F.occupancy.height,
+                          F.occupancy.stride, s);
+      if (st) return st;
+      for (uint32_t m = 0; m < F.map_count; ++m) {
+        const vpcc_image_u16& G = F.geometry[m];
+        D.geo[m] = (const uint16_t*)(base + o.geo[m]); D.geo_stride[m] = G.width;
+        st = copy_plane(ctx, base + o.geo[m], G.y, 2, G.width, G.height, G.stride, s);
+        if (st) return st;
+        if (F.attribute_count) {
+          const vpcc_image_u16& A = F.attribute[m];
+          D.attr_y[m] = (const uint16_t*)(base + o.ay[m]);
+          D.attr_u[m] = (const uint16_t*)(base + o.au[m]);
+          D.attr_v[m] = (const uint16_t*)(base + o.av[m]);
+          D.attr_stride[m] = A.width; D.attr_cstride[m] = A.cstride;
+          st = copy_plane(ctx, base + o.ay[m], A.y, 2, A.width, A.height, A.stride, s);
+          if (st) return st;
+          // chroma keeps its source stride: the reference indexes it as a flat array
+          // (v/2)*(width/2)+(u/2), src/decoder.rs:977, which for odd widths runs across rows
+          const size_t ce = chroma_elems(A);
+          HIP_TRY(ctx, hipMemcpyAsync(base + o.au[m], A.u, ce * 2, hipMemcpyHostToDevice, s));
+          HIP_TRY(ctx, hipMemcpyAsync(base + o.av[m], A.v, ce * 2, hipMemcpyHostToDevice, s));
+        }
+      }
+    }
+    if (!P.patches.empty())
+      HIP_TRY(ctx, hipMemcpyAsync(base + o.patches, P.patches.data(), sizeof(DevPatch) * P.patches.size(),
+                                  hipMemcpyHostToDevice, s));
+    if (!P.vblocks.empty())
+      HIP_TRY(ctx, hipMemcpyAsync(base + o.vblocks, P.vblocks.data(), sizeof(VBlock) * P.vblocks.size(),
+                                  hipMemcpyHostToDevice, s));
+  }
+  HIP_TRY(ctx, hipMemcpyAsync(g->d_frames, g->h_frames.data(), sizeof(DevFrame) * n_frames, hipMemcpyHostToDevice, s));
+  HIP_TRY(ctx, hipMemsetAsync(g->d_counts, 0, sizeof(uint32_t) * n_frames, s));
+  HIP_TRY(ctx, hipEventRecord(g->upload_done, s));
+  // the host staging vectors (plans) must stay alive until the copies are done
+  HIP_TRY(ctx, hipStreamSynchronize(s));
+  return VPCC_OK;
+}
+
+}  // namespace
+
+extern "C" int vpcc_gof_create(vpcc_ctx* ctx, const vpcc_frame_desc* frames, uint32_t n_frames,
+                               vpcc_memory_kind planes, uint64_t capacity_points, uint32_t gof_flags,
+                               vpcc_gof** out) {
+  if (!ctx || !frames || !out || n_frames == 0) return VPCC_ERR_INVALID_ARG;
+  if (planes != VPCC_MEM_HOST && planes != VPCC_MEM_DEVICE) return fail(ctx, VPCC_ERR_INVALID_ARG, "memory kind");
+  *out = nullptr;
+  HIP_TRY(ctx, hipSetDevice(ctx->device));
+  vpcc_gof* g = new vpcc_gof();
+  const int st = gof_create_impl(ctx, frames, n_frames, planes, capacity_points, gof_flags, g);
+  if (st) {
+    vpcc_gof_destroy(g);
+    return st;
+  }
+  *out = g;
+  return VPCC_OK;
+}
+
+namespace {
+
+struct Timer {
+  vpcc_gof* g;
+  hipStream_t s;
+  bool on;
+  void begin(const char* name) {
+    if (!on) return;
+    if (g->n_timed == g->timings.size()) {
+      KernelTiming t{};
+      (void)hipEventCreate(&t.start);
+      (void)hipEventCreate(&t.stop);
+      g->timings.push_back(t);
+    }
+    g->timings[g->n_timed].name = name;
+    g->timings[g->n_timed].ms = 0.f;
+    (void)hipEventRecord(g->timings[g->n_timed].start, s);
+  }
+  void end() {
+    if (!on) return;
+    (void)hipEventRecord(g->timings[g->n_timed].stop, s);
+    g->n_timed++;
+  }
+};
+
+}  // namespace
+
+extern "C" int vpcc_gof_reconstruct(vpcc_gof* g, uint32_t first, uint32_t count, void* hip_stream) {
+  if (!g) return VPCC_ERR_INVALID_ARG;
+  vpcc_ctx* ctx = g->ctx;
+  if (count == 0 || first >= g->n_frames || count > g->n_frames - first)
+    return fail(ctx, VPCC_ERR_INVALID_ARG, "frame range");
+  HIP_TRY(ctx, hipSetDevice(ctx->device));
+  hipStream_t s = hip_stream ? (hipStream_t)hip_stream : ctx->stream;
+  g->last_stream = s;
+  g->counts_valid = false;
+  g->n_timed = 0;
+  Timer T{g, s, (g->flags & VPCC_GOF_PROFILE) != 0};
+
+  // general sequence: owner -> count -> scan -> emit
+  size_t b2p_first = 0, b2p_len = 0;
+  for (uint32_t i = 0; i < first + count; ++i) {
+    const size_t n = (size_t)g->plans[i].bw * g->plans[i].bh;
+    if (i < first) b2p_first += n; else b2p_len += n;
+  }
+  if (b2p_len) HIP_TRY(ctx, hipMemsetAsync(g->d_b2p + b2p_first, 0, b2p_len * sizeof(uint32_t), s));
+  uint32_t max_vb = 0;
+  for (uint32_t i = first; i < first + count; ++i) max_vb = std::max(max_vb, (uint32_t)g->plans[i].vblocks.size());
+  T.begin("k_block_owner");
+  launch_block_owner(g->d_frames, first, count, max_vb, s);
+  T.end();
+  T.begin("k_count");
+  launch_count(g->d_frames, first, count, max_vb, s);
+  T.end();
+  T.begin("k_scan");
+  launch_scan(g->d_frames, first, count, s);
+  T.end();
+  T.begin("k_emit");
+  launch_emit(g->d_frames, first, count, max_vb, s);
+  T.end();
+  HIP_TRY(ctx, hipGetLastError());
+  g->launched = true;
+  return VPCC_OK;
+}
+
+extern "C" int vpcc_gof_sync(vpcc_gof* g) {
+  if (!g) return VPCC_ERR_INVALID_ARG;
+  HIP_TRY(g->ctx, hipSetDevice(g->ctx->device));
+  if (g->last_stream) HIP_TRY(g->ctx, hipStreamSynchronize(g->last_stream));
+  return VPCC_OK;
+}
+
+namespace {
+int fetch_counts(vpcc_gof* g) {
+  if (!g->launched) return fail(g->ctx, VPCC_ERR_STATE, "no reconstruct issued");
+  if (g->counts_valid) return VPCC_OK;
+  hipStream_t s = g->last_stream;
+  HIP_TRY(g->ctx, hipMemcpyAsync(g->h_counts, g->d_counts, sizeof(uint32_t) * g->n_frames, hipMemcpyDeviceToHost, s));
+  HIP_TRY(g->ctx, hipStreamSynchronize(s));
+  g->counts_valid = true;
+  return VPCC_OK;
+}
+}  // namespace
+
+extern "C" int vpcc_gof_point_counts(vpcc_gof* g, uint32_t* counts_out) {
+  if (!g || !counts_out) return VPCC_ERR_INVALID_ARG;
+  HIP_TRY(g->ctx, hipSetDevice(g->ctx->device));
+  const int st = fetch_counts(g);
+  if (st) return st;
+  std::memcpy(counts_out, g->h_counts, sizeof(uint32_t) * g->n_frames);
+  return VPCC_OK;
+}
+
+extern "C" int vpcc_gof_device_outputs(vpcc_gof* g, uint32_t frame, void** d_xyz, void** d_rgb, void** d_patch_index,
+                                       void** d_count) {
+  if (!g || frame >= g->n_frames) return VPCC_ERR_INVALID_ARG;
+  const DevFrame& D = g->h_frames[frame];
+  if (d_xyz) *d_xyz = D.out_xyz;
+  if (d_rgb) *d_rgb = D.out_rgb;
+  if (d_patch_index) *d_patch_index = D.out_patch;
+  if (d_count) *d_count = D.n_points;
+  return VPCC_OK;
+}
+
+extern "C" int vpcc_gof_frame_status(vpcc_gof* g, uint32_t frame) {
+  if (!g || frame >= g->n_frames) return VPCC_ERR_INVALID_ARG;
+  HIP_TRY(g->ctx, hipSetDevice(g->ctx->device));
+  const int st = fetch_counts(g);
+  if (st) return st;
+  return g->h_counts[frame] > g->capacity ? VPCC_ERR_CAPACITY : VPCC_OK;
+}
+
+extern "C" int vpcc_gof_download(vpcc_gof* g, uint32_t frame, vpcc_point3* xyz_out, vpcc_color3* rgb_out,
+                                 uint16_t* patch_index_out, size_t capacity, size_t* n_points) {
+  if (!g || frame >= g->n_frames || !n_points) return VPCC_ERR_INVALID_ARG;
+  vpcc_ctx* ctx = g->ctx;
+  HIP_TRY(ctx, hipSetDevice(ctx->device));
+  int st = fetch_counts(g);
+  if (st) return st;
+  const size_t n = g->h_counts[frame];
+  *n_points = n;
+  if (n > g->capacity || n > capacity) return fail(ctx, VPCC_ERR_CAPACITY, "frame produced more points than capacity");
+  const DevFrame& D = g->h_frames[frame];
+  hipStream_t s = g->last_stream;
+  if (n) {
+    if (xyz_out) HIP_TRY(ctx, hipMemcpyAsync(xyz_out, D.out_xyz, n * sizeof(vpcc_point3), hipMemcpyDeviceToHost, s));
+    if (rgb_out && D.out_rgb)
+      HIP_TRY(ctx, hipMemcpyAsync(rgb_out, D.out_rgb, n * sizeof(vpcc_color3), hipMemcpyDeviceToHost, s));
+    if (patch_index_out) {
+      if (!D.out_patch) return fail(ctx, VPCC_ERR_STATE, "gof was created without VPCC_GOF_WANT_PATCH_INDEX");
+      HIP_TRY(ctx, hipMemcpyAsync(patch_index_out, D.out_patch, n * sizeof(uint16_t), hipMemcpyDeviceToHost, s));
+    }
+    HIP_TRY(ctx, hipStreamSynchronize(s));
+  }
+  return VPCC_OK;
+}
+
+extern "C" int vpcc_gof_kernel_times(vpcc_gof* g, const char** names_out, float* ms_out, int max) {
+  if (!g) return 0;
+  (void)hipSetDevice(g->ctx->device);
+  if (g->last_stream) (void)hipStreamSynchronize(g->last_stream);
+  int n = 0;
+  for (uint32_t i = 0; i < g->n_timed && n < max; ++i, ++n) {
+    float ms = 0.f;
+    (void)hipEventElapsedTime(&ms, g->timings[i].start, g->timings[i].stop);
+    g->timings[i].ms = ms;
+    if (names_out) names_out[n] = g->timings[i].name;
+    if (ms_out) ms_out[n] = ms;
+  }
+  return n;
+}
+
+extern "C" int vpcc_gof_algorithmic_bytes(vpcc_gof* g, uint32_t frame, uint64_t* bytes_out) {
+  if (!g || frame >= g->n_frames || !bytes_out) return VPCC_ERR_INVALID_ARG;
+  HIP_TRY(g->ctx, hipSetDevice(g->ctx->device));
+  const int st = fetch_counts(g);
+  if (st) return st;
+  *bytes_out = g->plans[frame].plane_bytes + 9ull * g->h_counts[frame];
+  return VPCC_OK;
+}
+
+// ------------------------------------------------ one-shot seam replacements
+namespace {
+struct OneShot {
+  vpcc_gof* g = nullptr;
+  ~OneShot() { vpcc_gof_destroy(g); }
+};
+}  // namespace
+
+extern "C" int vpcc_generate_block_to_patch(vpcc_ctx* ctx, const vpcc_frame_desc* frame, vpcc_memory_kind planes,
+                                            uint32_t* block_to_patch_out) {
+  if (!ctx || !frame || !block_to_patch_out) return VPCC_ERR_INVALID_ARG;
+  OneShot o;
+  int st = vpcc_gof_create(ctx, frame, 1, planes, 1, VPCC_GOF_FORCE_GENERAL, &o.g);
+  if (st) return st;
+  vpcc_gof* g = o.g;
+  hipStream_t s = ctx->stream;
+  const size_t n = (size_t)g->plans[0].bw * g->plans[0].bh;
+  if (n == 0) return VPCC_OK;
+  HIP_TRY(ctx, hipMemsetAsync(g->d_b2p, 0, n * sizeof(uint32_t), s));
+  launch_block_owner(g->d_frames, 0, 1, (uint32_t)g->plans[0].vblocks.size(), s);
+  HIP_TRY(ctx, hipGetLastError());
+  HIP_TRY(ctx, hipMemcpyAsync(block_to_patch_out, g->d_b2p, n * sizeof(uint32_t), hipMemcpyDeviceToHost, s));
+  HIP_TRY(ctx, hipStreamSynchronize(s));
+  return VPCC_OK;
+}
+
+extern "C" int vpcc_upsample_occupancy(vpcc_ctx* ctx, const vpcc_frame_desc* frame, vpcc_memory_kind planes,
+                                       uint8_t* occupancy_map_out) {
+  if (!ctx || !frame || !occupancy_map_out) return VPCC_ERR_INVALID_ARG;
+  OneShot o;
+  int st = vpcc_gof_create(ctx, frame, 1, planes, 1, VPCC_GOF_FORCE_GENERAL, &o.g);
+  if (st) return st;
+  hipStream_t s = ctx->stream;
+  const size_t n = (size_t)frame->width * frame->height;
+  uint8_t* d_out = nullptr;
+  HIP_TRY(ctx, hipMalloc((void**)&d_out, n));
+  launch_upsample_occupancy(o.g->d_frames, 0, d_out, frame->width, frame->height, s);
+  hipError_t e = hipGetLastError();
+  if (e == hipSuccess) e = hipMemcpyAsync(occupancy_map_out, d_out, n, hipMemcpyDeviceToHost, s);
+  if (e == hipSuccess) e = hipStreamSynchronize(s);
+  (void)hipFree(d_out);
+  if (e != hipSuccess) return fail(ctx, VPCC_ERR_DEVICE, hipGetErrorString(e));
+  return VPCC_OK;
+}
+
+extern "C" int vpcc_reconstruct_frame(vpcc_ctx* ctx, const vpcc_frame_desc* frame, vpcc_memory_kind planes,
+                                      vpcc_point3* xyz_out, vpcc_color3* rgb_out, uint16_t* patch_index_out,
+                                      size_t capacity, size_t* n_points) {
+  if (!ctx || !frame || !n_points) return VPCC_ERR_INVALID_ARG;
+  OneShot o;
+  const uint64_t cap = std::min<uint64_t>(capacity ? capacity : 1, std::max<uint64_t>(vpcc_frame_capacity_bound(frame), 1));
+  int st = vpcc_gof_create(ctx, frame, 1, planes, cap, patch_index_out ? VPCC_GOF_WANT_PATCH_INDEX : 0u, &o.g);
+  if (st) return st;
+  st = vpcc_gof_reconstruct(o.g, 0, 1, nullptr);
+  if (st) return st;
+  return vpcc_gof_download(o.g, 0, xyz_out, rgb_out, patch_index_out, capacity, n_points);
+}

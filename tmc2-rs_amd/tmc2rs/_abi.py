@@ -94,6 +94,18 @@ def _ptr(a):
     return None if a is None else a.ctypes.data
 
 
+def _plane(a, dtype):
+    """(keepalive, pointer, width, height, stride in elements) of a 2-D plane.  A row-strided
+    view (e.g. padded[:, :w]) is passed as is, with its stride; anything else is made contiguous."""
+    a = np.asarray(a)
+    if a.dtype != dtype:
+        a = a.astype(dtype)
+    item = a.dtype.itemsize
+    if not (a.ndim == 2 and a.strides[1] == item and a.strides[0] % item == 0 and a.strides[0] >= a.shape[1] * item):
+        a = np.ascontiguousarray(a)
+    return a, a.ctypes.data, a.shape[1], a.shape[0], a.strides[0] // item
+
+
 def host_frame_desc(frame):
     """Builds a FrameDesc over the numpy arrays of a synthetic/ingested frame
     dict (see synth.make_frame).  Returns (desc, keepalive)."""
@@ -106,28 +118,23 @@ def host_frame_desc(frame):
     d.attribute_count = int(frame.get("attribute_count", 1))
     d.flags = int(frame.get("flags", 0))
     keep = []
-    occ = np.ascontiguousarray(frame["occupancy"], dtype=np.uint8)
+    occ, d.occupancy.y, d.occupancy.width, d.occupancy.height, d.occupancy.stride = _plane(frame["occupancy"], np.uint8)
     keep.append(occ)
-    d.occupancy.y = _ptr(occ)
-    d.occupancy.height, d.occupancy.width = occ.shape
-    d.occupancy.stride = int(frame.get("occupancy_stride", occ.shape[1]))
     for m in range(2):
         g = frame["geometry"][m] if m < len(frame["geometry"]) else None
         if g is not None:
-            g = np.ascontiguousarray(g, dtype=np.uint16)
+            G = d.geometry[m]
+            g, G.y, G.width, G.height, G.stride = _plane(g, np.uint16)
             keep.append(g)
-            d.geometry[m].y = _ptr(g)
-            d.geometry[m].height, d.geometry[m].width = g.shape
-            d.geometry[m].stride = g.shape[1]
-            d.geometry[m].cstride = g.shape[1] // 2
+            G.cstride = G.width // 2
         a = frame["attribute"][m] if m < len(frame["attribute"]) else None
         if a is not None:
-            y, u, v = (np.ascontiguousarray(p, dtype=np.uint16) for p in a)
+            A = d.attribute[m]
+            y, A.y, A.width, A.height, A.stride = _plane(a[0], np.uint16)
+            u, A.u, _, _, A.cstride = _plane(a[1], np.uint16)
+            v, A.v, _, _, cs2 = _plane(a[2], np.uint16)
+            assert cs2 == A.cstride, "U and V planes must share one stride"
             keep += [y, u, v]
-            d.attribute[m].y, d.attribute[m].u, d.attribute[m].v = _ptr(y), _ptr(u), _ptr(v)
-            d.attribute[m].height, d.attribute[m].width = y.shape
-            d.attribute[m].stride = y.shape[1]
-            d.attribute[m].cstride = u.shape[1]
     patches = np.ascontiguousarray(frame["patches"], dtype=PATCH_DTYPE)
     keep.append(patches)
     d.patches = _ptr(patches) if len(patches) else None

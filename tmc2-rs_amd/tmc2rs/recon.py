@@ -1,0 +1,178 @@
+"""Thin Python binding of the C ABI (include/vpcc_recon.h) — used by tests/ and bench.py.
+
+Everything here calls into libvpcc_recon.so (HIP kernels + C++ host runtime).
+There is no Python implementation of the reconstruction: a missing library or a
+missing GPU raises.
+"""
+import ctypes as C
+
+import numpy as np
+
+from . import _abi
+from ._abi import (COLOR3_DTYPE, POINT3_DTYPE, VPCC_GOF_FORCE_GENERAL, VPCC_GOF_PROFILE,
+                   VPCC_GOF_WANT_PATCH_INDEX, VPCC_MEM_DEVICE, VPCC_MEM_HOST, FrameDesc, host_frame_desc)
+
+
+class VpccError(RuntimeError):
+    def __init__(self, status, where, detail=""):
+        self.status = status
+        lib = _abi.load_library()
+        msg = lib.vpcc_status_string(status).decode()
+        super().__init__(f"{where}: status {status} ({msg}) {detail}")
+
+
+def validate_frame(frame):
+    """vpcc_frame_validate on a frame dict — pure host code, no GPU needed."""
+    lib = _abi.load_library()
+    desc, keep = host_frame_desc(frame)
+    return lib.vpcc_frame_validate(C.byref(desc))
+
+
+class Context:
+    """vpcc_ctx: one per GPU / worker thread."""
+
+    def __init__(self, device=0):
+        self.lib = _abi.load_library()
+        self.h = C.c_void_p()
+        st = self.lib.vpcc_ctx_create(int(device), C.byref(self.h))
+        if st:
+            raise VpccError(st, "vpcc_ctx_create")
+        self.device = device
+
+    def close(self):
+        if self.h:
+            self.lib.vpcc_ctx_destroy(self.h)
+            self.h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _check(self, st, where):
+        if st:
+            raise VpccError(st, where, self.lib.vpcc_last_error(self.h).decode())
+
+    # ---- one-shot seam replacements -------------------------------------
+    def generate_block_to_patch(self, frame):
+        desc, keep = host_frame_desc(frame)
+        R = desc.occupancy_resolution
+        out = np.zeros((desc.width // R) * (desc.height // R), dtype=np.uint32)
+        self._check(self.lib.vpcc_generate_block_to_patch(self.h, C.byref(desc), VPCC_MEM_HOST, out.ctypes.data),
+                    "vpcc_generate_block_to_patch")
+        return out
+
+    def upsample_occupancy(self, frame):
+        desc, keep = host_frame_desc(frame)
+        out = np.zeros((desc.height, desc.width), dtype=np.uint8)
+        self._check(self.lib.vpcc_upsample_occupancy(self.h, C.byref(desc), VPCC_MEM_HOST, out.ctypes.data),
+                    "vpcc_upsample_occupancy")
+        return out
+
+    def reconstruct_frame(self, frame, capacity=None, want_patch_index=False):
+        desc, keep = host_frame_desc(frame)
+        cap = int(capacity if capacity is not None else self.lib.vpcc_frame_capacity_bound(C.byref(desc)))
+        xyz = np.zeros(max(cap, 1), dtype=POINT3_DTYPE)
+        rgb = np.zeros(max(cap, 1), dtype=COLOR3_DTYPE)
+        pidx = np.zeros(max(cap, 1), dtype=np.uint16) if want_patch_index else None
+        n = C.c_size_t(0)
+        st = self.lib.vpcc_reconstruct_frame(self.h, C.byref(desc), VPCC_MEM_HOST, xyz.ctypes.data, rgb.ctypes.data,
+                                             pidx.ctypes.data if pidx is not None else None, cap, C.byref(n))
+        self._check(st, "vpcc_reconstruct_frame")
+        k = n.value
+        res = {"n": k, "xyz": _xyz(xyz[:k]), "rgb": _rgb(rgb[:k])}
+        if pidx is not None:
+            res["patch_index"] = pidx[:k].copy()
+        return res
+
+    def gof(self, frames, capacity=0, flags=0, memory=VPCC_MEM_HOST, descs=None):
+        return Gof(self, frames, capacity, flags, memory, descs)
+
+
+def _xyz(a):
+    return np.stack([a["x"], a["y"], a["z"]], axis=1) if len(a) else np.zeros((0, 3), np.uint16)
+
+
+def _rgb(a):
+    return np.stack([a["r"], a["g"], a["b"]], axis=1) if len(a) else np.zeros((0, 3), np.uint8)
+
+
+class Gof:
+    """vpcc_gof: a batch of independent frames resident in HBM."""
+
+    def __init__(self, ctx, frames, capacity=0, flags=0, memory=VPCC_MEM_HOST, descs=None):
+        self.ctx, self.lib = ctx, ctx.lib
+        self.n_frames = len(frames) if descs is None else len(descs)
+        self._keep = []
+        if descs is None:
+            arr = (FrameDesc * self.n_frames)()
+            for i, f in enumerate(frames):
+                d, keep = host_frame_desc(f)
+                arr[i] = d
+                self._keep.append(keep)
+        else:
+            arr = (FrameDesc * self.n_frames)(*descs)
+        self._descs = arr
+        self.h = C.c_void_p()
+        st = self.lib.vpcc_gof_create(ctx.h, arr, self.n_frames, memory, int(capacity), int(flags), C.byref(self.h))
+        ctx._check(st, "vpcc_gof_create")
+        self.flags = flags
+
+    def close(self):
+        if self.h:
+            self.lib.vpcc_gof_destroy(self.h)
+            self.h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def reconstruct(self, first=0, count=None, stream=None):
+        count = self.n_frames - first if count is None else count
+        self.ctx._check(self.lib.vpcc_gof_reconstruct(self.h, first, count, C.c_void_p(stream) if stream else None),
+                        "vpcc_gof_reconstruct")
+
+    def sync(self):
+        self.ctx._check(self.lib.vpcc_gof_sync(self.h), "vpcc_gof_sync")
+
+    def point_counts(self):
+        out = np.zeros(self.n_frames, dtype=np.uint32)
+        self.ctx._check(self.lib.vpcc_gof_point_counts(self.h, out.ctypes.data), "vpcc_gof_point_counts")
+        return out
+
+    def frame_status(self, frame):
+        return self.lib.vpcc_gof_frame_status(self.h, frame)
+
+    def download(self, frame, want_patch_index=False):
+        n = int(self.point_counts()[frame])
+        xyz = np.zeros(max(n, 1), dtype=POINT3_DTYPE)
+        rgb = np.zeros(max(n, 1), dtype=COLOR3_DTYPE)
+        pidx = np.zeros(max(n, 1), dtype=np.uint16) if want_patch_index else None
+        k = C.c_size_t(0)
+        st = self.lib.vpcc_gof_download(self.h, frame, xyz.ctypes.data, rgb.ctypes.data,
+                                        pidx.ctypes.data if pidx is not None else None, max(n, 1), C.byref(k))
+        self.ctx._check(st, "vpcc_gof_download")
+        res = {"n": k.value, "xyz": _xyz(xyz[:k.value]), "rgb": _rgb(rgb[:k.value])}
+        if pidx is not None:
+            res["patch_index"] = pidx[:k.value].copy()
+        return res
+
+    def device_outputs(self, frame):
+        p = [C.c_void_p() for _ in range(4)]
+        self.ctx._check(self.lib.vpcc_gof_device_outputs(self.h, frame, *[C.byref(x) for x in p]),
+                        "vpcc_gof_device_outputs")
+        return tuple(x.value for x in p)
+
+    def kernel_times(self):
+        names = (C.c_char_p * 16)()
+        ms = (C.c_float * 16)()
+        n = self.lib.vpcc_gof_kernel_times(self.h, names, ms, 16)
+        return [(names[i].decode(), float(ms[i])) for i in range(n)]
+
+    def algorithmic_bytes(self, frame):
+        b = C.c_uint64(0)
+        self.ctx._check(self.lib.vpcc_gof_algorithmic_bytes(self.h, frame, C.byref(b)), "vpcc_gof_algorithmic_bytes")
+        return b.value
