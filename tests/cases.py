@@ -114,6 +114,20 @@ def medium_frame(index=0, **kw):
                             size_skew=2.0, overlap_prob=0.3, **kw)
 
 
+def gray_boundary_frame():
+    """Grey pixels (U = V = 512): c*255/1023 is an exact integer whenever luma is a multiple of 341,
+    which is where the IEEE rounding of the reference's division decides the floor — this forces the
+    exact-division branch of the fast colour path (rare on random data)."""
+    f = medium_frame(3)
+    h, w = f["geometry"][0].shape
+    idx = np.arange(h * w, dtype=np.int64).reshape(h, w)
+    y0 = (idx % 1024).astype(np.uint16)
+    y1 = (np.array([0, 341, 682, 1023, 340, 342, 681, 683], dtype=np.uint16))[idx % 8]
+    c = np.full((h // 2, w // 2), 512, dtype=np.uint16)
+    f["attribute"] = [(y0, c, c.copy()), (y1, c.copy(), c.copy())]
+    return f
+
+
 PARITY_CASES = {
     "small0": lambda: synth.small_frame(0),
     "small1_randocc": lambda: synth.small_frame(1, occupancy_values="random"),
@@ -127,6 +141,7 @@ PARITY_CASES = {
     "single_map_extension": single_map_frame,
     "no_attribute": no_attribute_frame,
     "strided_planes": strided_frame,
+    "gray_exact_boundaries": gray_boundary_frame,
     "medium0": lambda: medium_frame(0),
     "medium1_randocc": lambda: medium_frame(1, occupancy_values="random"),
     "empty_no_patches": lambda: _tiny_frame([], np.ones((8, 8), np.uint8)),

@@ -35,6 +35,23 @@ struct VBlock {
 };
 static_assert(sizeof(VBlock) == 16, "VBlock is 16 B");
 
+// Work item of the single-pass tile kernel: one virtual block that OWNS its canvas block, with the
+// patch fields the per-point arithmetic needs folded in (one 32-B scalar load per item).
+struct TileItem {
+  uint16_t x0, y0;        // canvas pixel origin of the block
+  uint16_t patch;         // patch index (partition output)
+  uint8_t flags;          // kTileSwap | kTileMode1
+  uint8_t axes;           // normal | tangent << 2 | bitangent << 4
+  uint32_t tb, bb;        // tangent / bitangent coordinate of the block's first pixel (mod 2^32):
+                          //   u0*R*lod_x + u1 ,  v0*R*lod_y + v1     (src/decoder.rs:875-876)
+  uint32_t d1;
+  uint16_t lod_x, lod_y;
+  uint32_t pad[2];
+};
+static_assert(sizeof(TileItem) == 32, "TileItem is 32 B");
+constexpr uint8_t kTileSwap = 1, kTileMode1 = 2;
+constexpr uint32_t kTileItemsPerGroup = 16;   // 4 waves x 4 items: one ticket / one look-back word per group
+
 // Per-frame descriptor, resident in HBM, read by every kernel.
 struct DevFrame {
   const uint8_t* occ;
@@ -51,7 +68,11 @@ struct DevFrame {
   vpcc_color3* out_rgb;
   uint16_t* out_patch;        // optional (partition), may be null
   uint32_t* n_points;         // device counter of this frame
-  uint64_t* scan_state;       // single-pass path: one {status,value} word per work item
+  // single-pass tile kernel (R == 16, Default/Swap patches, aligned planes)
+  const TileItem* tiles;      // owner-filtered items, emission order
+  uint64_t* scan_state;       // one {status:2 | value:32} word per group of 16 items
+  uint32_t* ticket;           // dynamic group counter (deadlock-free ordering of the look-back chain)
+  uint32_t* error_flag;       // set when a bounded spin gives up
   uint32_t occ_stride, occ_w, occ_h;
   uint32_t geo_stride[2];
   uint32_t attr_stride[2], attr_cstride[2];
@@ -60,7 +81,8 @@ struct DevFrame {
   uint32_t n_patches, n_vblocks;
   uint32_t map_count, absolute_d1, has_attr;
   uint32_t capacity;
-  uint32_t pad[2];
+  uint32_t n_tiles;           // number of tile items
+  uint32_t pad[1];
 };
 
 // Kernel launchers (vpcc_kernels.hip).  All asynchronous on `stream`.
@@ -69,6 +91,7 @@ void launch_block_owner(const DevFrame* d_frames, uint32_t first, uint32_t count
 void launch_count(const DevFrame* d_frames, uint32_t first, uint32_t count, uint32_t max_vb, void* stream);
 void launch_scan(const DevFrame* d_frames, uint32_t first, uint32_t count, void* stream);
 void launch_emit(const DevFrame* d_frames, uint32_t first, uint32_t count, uint32_t max_vb, void* stream);
+void launch_tiles(const DevFrame* d_frames, uint32_t first, uint32_t count, uint32_t max_groups, void* stream);
 void launch_upsample_occupancy(const DevFrame* d_frames, uint32_t frame, uint8_t* d_out, uint32_t width,
                                uint32_t height, void* stream);
 

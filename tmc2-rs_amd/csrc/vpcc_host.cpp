@@ -134,6 +134,37 @@ void plan_frame(const vpcc_frame_desc& f, FramePlan* out) {
       }
     vb_base += p.size_u0 * p.size_v0;
   }
+  // Ownership without looking at the occupancy (single-pass tile kernel).  For Default/Swap patches
+  // the pixels of a virtual block are exactly the pixels of its canvas block, so every covering
+  // patch sees the same occupancy and the reference's ascending overwrite (src/codec.rs:217,
+  // 242-244) leaves "highest covering patch, if any occupancy".  Blocks without occupancy emit
+  // nothing anyway, so the work list is simply the virtual blocks of the highest covering patch,
+  // in emission order, each carrying the patch fields its points need.
+  out->tiles.clear();
+  const uint32_t prec = f.occupancy_precision;
+  out->tile_eligible = out->simple_orientations && f.occupancy_resolution == 16 && (prec < 4 || prec % 4 == 0);
+  if (out->tile_eligible) {
+    std::vector<int32_t> cover((size_t)out->bw * out->bh, -1);
+    for (const VBlock& b : out->vblocks) cover[b.canvas_block] = std::max(cover[b.canvas_block], (int32_t)b.patch);
+    for (const VBlock& b : out->vblocks) {
+      if (cover[b.canvas_block] != (int32_t)b.patch) continue;
+      const vpcc_patch& p = f.patches[b.patch];
+      TileItem t{};
+      t.x0 = (uint16_t)((b.canvas_block % out->bw) * 16u);
+      t.y0 = (uint16_t)((b.canvas_block / out->bw) * 16u);
+      t.patch = b.patch;
+      t.flags = (uint8_t)((p.orientation == VPCC_ORIENT_DEFAULT ? 0 : kTileSwap) | (p.projection_mode ? kTileMode1 : 0));
+      t.axes = (uint8_t)(p.normal_axis | (p.tangent_axis << 2) | (p.bitangent_axis << 4));
+      t.tb = (uint32_t)b.u0 * 16u * p.lod_x + p.u1;
+      t.bb = (uint32_t)b.v0 * 16u * p.lod_y + p.v1;
+      t.d1 = p.d1;
+      t.lod_x = (uint16_t)p.lod_x;
+      t.lod_y = (uint16_t)p.lod_y;
+      if (p.lod_x > 65535u || p.lod_y > 65535u) out->tile_eligible = false;
+      out->tiles.push_back(t);
+    }
+    if (!out->tile_eligible) out->tiles.clear();
+  }
   // B = Wo*Ho + M*W*H*2 + M*(W*H*2 + 2*(W/2)*(H/2)*2) + 9*N (N added at run time)
   uint64_t bytes = (uint64_t)f.occupancy.width * f.occupancy.height;
   for (uint32_t m = 0; m < f.map_count; ++m) {
@@ -143,6 +174,18 @@ void plan_frame(const vpcc_frame_desc& f, FramePlan* out) {
                2ull * (f.attribute[m].width / 2) * (f.attribute[m].height / 2) * 2;
   }
   out->plane_bytes = bytes;
+}
+
+bool tile_planes_aligned(const DevFrame& d) {
+  auto al = [](const void* p, uintptr_t a) { return ((uintptr_t)p % a) == 0; };
+  for (uint32_t m = 0; m < d.map_count; ++m) {
+    if (!al(d.geo[m], 8) || d.geo_stride[m] % 4) return false;
+    if (d.has_attr) {
+      if (!al(d.attr_y[m], 8) || d.attr_stride[m] % 4) return false;
+      if (!al(d.attr_u[m], 4) || !al(d.attr_v[m], 4) || d.attr_cstride[m] % 2) return false;
+    }
+  }
+  return true;
 }
 
 }  // namespace vpcc

@@ -22,6 +22,8 @@ Affine patch_affine(const vpcc_patch& p, int64_t res);
 struct FramePlan {
   std::vector<DevPatch> patches;
   std::vector<VBlock> vblocks;       // every (patch, v0, u0) in emission order
+  std::vector<TileItem> tiles;       // tile kernel work list: the vblocks that own their canvas block
+  bool tile_eligible = false;        // R == 16, Default/Swap only, occupancy precision compatible
   uint32_t bw = 0, bh = 0;
   bool simple_orientations = true;   // only Default / Swap (/MRot270 == Swap) patches
   uint64_t plane_bytes = 0;          // occupancy + geometry luma + attribute Y,U,V planes
@@ -35,5 +37,9 @@ int validate_frame(const vpcc_frame_desc* f);
 
 // Requires validate_frame(f) == VPCC_OK.
 void plan_frame(const vpcc_frame_desc& f, FramePlan* out);
+
+// Alignment preconditions of the tile kernel's vector loads for the planes as the kernels will see
+// them (device pointers and strides): 8-B aligned luma rows, 4-B aligned chroma pairs.
+bool tile_planes_aligned(const DevFrame& d);
 
 }  // namespace vpcc

@@ -16,104 +16,9 @@
 #include <hip/hip_runtime.h>
 
 #include "vpcc_device.hpp"
+#include "vpcc_devfn.hpp"
 
 namespace vpcc {
-
-// ------------------------------------------------------------------ helpers
-__device__ __forceinline__ uint32_t lane_id() { return threadIdx.x & 63u; }
-
-// number of set bits of `mask` below this lane
-__device__ __forceinline__ uint32_t mbcnt(uint64_t mask) {
-  return __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));
-}
-
-struct Pt { uint16_t c[3]; };
-
-// Patch::generate_point, src/decoder.rs:871-888.  Assignment order normal, tangent, bitangent
-// as in the reference; `as u16` truncation.
-__device__ __forceinline__ uint32_t normal_coord(const DevPatch& p, uint32_t depth) {
-  return p.projection_mode == 0 ? depth + p.d1 : (p.d1 > depth ? p.d1 : depth) - depth;
-}
-
-__device__ __forceinline__ Pt make_point(const DevPatch& p, uint32_t u, uint32_t v, uint32_t depth) {
-  Pt r;
-  r.c[0] = r.c[1] = r.c[2] = 0;
-  const uint16_t n = (uint16_t)normal_coord(p, depth);
-  const uint16_t t = (uint16_t)(u * p.lod_x + p.u1);
-  const uint16_t b = (uint16_t)(v * p.lod_y + p.v1);
-#pragma unroll
-  for (int a = 0; a < 3; ++a) {           // select instead of a runtime-indexed array (no scratch)
-    uint16_t val = r.c[a];
-    if (p.normal_axis == a) val = n;
-    if (p.tangent_axis == a) val = t;
-    if (p.bitangent_axis == a) val = b;
-    r.c[a] = val;
-  }
-  return r;
-}
-
-// generate_points, src/codec.rs:517-565: D1 point from D0 point / second geometry sample.
-__device__ __forceinline__ Pt make_point1(const DevFrame& f, const DevPatch& p, uint32_t u, uint32_t v,
-                                          const Pt& p0, uint32_t d1) {
-  if (f.absolute_d1) return make_point(p, u, v, d1);
-  Pt r = p0;
-#pragma unroll
-  for (int a = 0; a < 3; ++a)
-    if (p.normal_axis == a)
-      r.c[a] = p.projection_mode == 0 ? (uint16_t)(r.c[a] + d1) : (uint16_t)(r.c[a] - d1);
-  return r;
-}
-
-__device__ __forceinline__ bool same_point(const Pt& a, const Pt& b) {
-  return a.c[0] == b.c[0] && a.c[1] == b.c[1] && a.c[2] == b.c[2];
-}
-
-// convert_yuv10_to_rgb8, src/codec.rs:661-687: IEEE f64, source order, no contraction.
-__device__ __forceinline__ uint8_t clamp_u8(double x) {
-  if (x < 0.) return 0;
-  if (x > 255.) return 255;
-  return (uint8_t)x;
-}
-
-__device__ __forceinline__ vpcc_color3 yuv10_to_rgb8(uint16_t y16, uint16_t u16, uint16_t v16) {
-  const double offset = 512., scale = 1023.;
-  const double y = (double)y16, u = (double)u16, v = (double)v16;
-  const double r = y + 1.57480 * (v - offset);
-  const double g = y - 0.18733 * (u - offset) - (0.46813 * (v - offset));
-  const double b = y + 1.85563 * (u - offset);
-  vpcc_color3 c;
-  c.r = clamp_u8(__builtin_floor(r / scale * 255.));
-  c.g = clamp_u8(__builtin_floor(g / scale * 255.));
-  c.b = clamp_u8(__builtin_floor(b / scale * 255.));
-  return c;
-}
-
-// Per-pixel work of the enumeration: returns the number of points (0,1,2) and the points.
-struct PixelOut {
-  Pt p0, p1;
-  uint32_t x, y;
-  uint32_t n;
-};
-
-__device__ __forceinline__ PixelOut eval_pixel(const DevFrame& f, const DevPatch& p, uint32_t u, uint32_t v) {
-  PixelOut o;
-  o.n = 0;
-  const int32_t x = p.ax_u * (int32_t)u + p.ax_v * (int32_t)v + p.cx;   // host validated: inside the canvas
-  const int32_t y = p.ay_u * (int32_t)u + p.ay_v * (int32_t)v + p.cy;
-  o.x = (uint32_t)x;
-  o.y = (uint32_t)y;
-  const uint8_t occ = f.occ[(o.y / f.prec) * f.occ_stride + (o.x / f.prec)];   // src/codec.rs:288-301, 393
-  if (occ == 0) return o;
-  const uint32_t d0 = (uint32_t)(f.geo[0][o.y * f.geo_stride[0] + o.x] >> 2);  // depth / 4, codec.rs:534
-  o.p0 = make_point(p, u, v, d0);
-  o.n = 1;
-  if (f.map_count > 1) {
-    const uint32_t d1 = (uint32_t)(f.geo[1][o.y * f.geo_stride[1] + o.x] >> 2);
-    o.p1 = make_point1(f, p, u, v, o.p0, d1);
-    if (!same_point(o.p0, o.p1)) o.n = 2;                                      // codec.rs:422-427
-  }
-  return o;
-}
 
 // ------------------------------------------------------------ k_block_owner
 // One wave per virtual block.  non_zero_pixel > 0  <=>  any occupancy sample under the block's
@@ -231,7 +136,7 @@ __global__ __launch_bounds__(256) void k_emit(const DevFrame* __restrict__ frame
         const uint16_t Y = f.attr_y[j][o.y * f.attr_stride[j] + o.x];
         const uint16_t U = f.attr_u[j][cidx];
         const uint16_t V = f.attr_v[j][cidx];
-        f.out_rgb[k] = yuv10_to_rgb8(Y, U, V);
+        f.out_rgb[k] = yuv10_to_rgb8_fast(Y, U, V);
       }
     }
     base += tot;

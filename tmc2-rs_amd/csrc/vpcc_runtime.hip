@@ -44,10 +44,14 @@ struct vpcc_gof {
   uint32_t* d_counts = nullptr;        // n_frames contiguous point counters
   uint32_t* d_b2p = nullptr;           // all frames' block_to_patch, contiguous
   size_t b2p_words = 0;
-  uint64_t* d_scan_state = nullptr;    // single-pass path
-  size_t scan_state_words = 0;
+  // tile-kernel control words, one contiguous region: [tickets (one 256-B line per frame) | errors | scan states]
+  uint32_t* d_tickets = nullptr;
+  uint32_t* d_errors = nullptr;
+  uint64_t* d_scan = nullptr;
+  std::vector<size_t> scan_off;        // per-frame offset (words) into d_scan, n_frames+1 entries (one word per group)
+  size_t ctrl_bytes = 0;
   uint32_t max_vb = 0;
-  uint32_t* h_counts = nullptr;        // pinned
+  uint32_t* h_counts = nullptr;        // pinned: counts[n_frames] then errors[n_frames]
   bool counts_valid = false;
   bool launched = false;
   hipEvent_t upload_done = nullptr;
@@ -187,14 +191,13 @@ int gof_create_impl(vpcc_ctx* ctx, const vpcc_frame_desc* frames, uint32_t n_fra
     const int st = validate_frame(&frames[i]);
     if (st) return fail(ctx, st, "frame " + std::to_string(i) + ": " + vpcc_status_string(st));
     plan_frame(frames[i], &g->plans[i]);
-    all_simple = all_simple && g->plans[i].simple_orientations;
+    all_simple = all_simple && g->plans[i].tile_eligible;
     g->max_vb = std::max(g->max_vb, (uint32_t)g->plans[i].vblocks.size());
     if (capacity_points == 0) cap = std::max<uint64_t>(cap, vpcc_frame_capacity_bound(&frames[i]));
   }
   if (cap == 0) cap = 1;
   if (cap > 0xFFFFFFF0ull) return fail(ctx, VPCC_ERR_INVALID_ARG, "capacity_points exceeds 32 bits");
   g->capacity = cap;
-  g->general = true;   // the single-pass fast path is selected in vpcc_gof_reconstruct when available
   (void)all_simple;
 
   // 2. arena layout
@@ -202,9 +205,23 @@ int gof_create_impl(vpcc_ctx* ctx, const vpcc_frame_desc* frames, uint32_t n_fra
   const size_t off_frames = L.take(sizeof(DevFrame) * n_frames);
   const size_t off_counts = L.take(sizeof(uint32_t) * n_frames);
   struct Off {
-    size_t patches, vblocks, b2p, vb_count, vb_offset, xyz, rgb, pidx, occ, geo[2], ay[2], au[2], av[2];
+    size_t patches, vblocks, items, b2p, vb_count, vb_offset, xyz, rgb, pidx, occ, geo[2], ay[2], au[2], av[2];
   };
   std::vector<Off> offs(n_frames);
+  // control words of the single-pass path: contiguous so that one memset re-arms a launch
+  g->scan_off.assign(n_frames + 1, 0);
+  for (uint32_t i = 0; i < n_frames; ++i)
+    g->scan_off[i + 1] = g->scan_off[i] + (g->plans[i].tiles.size() + kTileItemsPerGroup - 1) / kTileItemsPerGroup;
+  const size_t ctrl_begin = L.total;
+  const size_t off_tickets = L.total;
+  L.total += 256 * (size_t)n_frames;              // one ticket per 256-B line: same-line atomics serialise
+  const size_t off_errors = L.total;
+  L.total += sizeof(uint32_t) * n_frames;
+  L.total = align_up(L.total, 8);
+  const size_t off_scan = L.total;
+  L.total += sizeof(uint64_t) * std::max<size_t>(g->scan_off[n_frames], 1);
+  g->ctrl_bytes = L.total - ctrl_begin;
+  L.total = align_up(L.total, 256);
   // block_to_patch of all frames contiguous: one memset per reconstruct
   size_t b2p_begin = L.total;
   for (uint32_t i = 0; i < n_frames; ++i) {
@@ -220,6 +237,7 @@ int gof_create_impl(vpcc_ctx* ctx, const vpcc_frame_desc* frames, uint32_t n_fra
     Off& o = offs[i];
     o.patches = L.take(sizeof(DevPatch) * std::max<size_t>(P.patches.size(), 1));
     o.vblocks = L.take(sizeof(VBlock) * std::max<size_t>(P.vblocks.size(), 1));
+    o.items = L.take(sizeof(TileItem) * std::max<size_t>(P.tiles.size(), 1));
     o.vb_count = L.take(sizeof(uint32_t) * std::max<size_t>(P.vblocks.size(), 1));
     o.vb_offset = L.take(sizeof(uint32_t) * std::max<size_t>(P.vblocks.size(), 1));
     o.xyz = L.take(sizeof(vpcc_point3) * cap);
@@ -243,7 +261,10 @@ int gof_create_impl(vpcc_ctx* ctx, const vpcc_frame_desc* frames, uint32_t n_fra
   g->d_frames = (DevFrame*)(base + off_frames);
   g->d_counts = (uint32_t*)(base + off_counts);
   g->d_b2p = (uint32_t*)(base + b2p_begin);
-  HIP_TRY(ctx, hipHostMalloc((void**)&g->h_counts, sizeof(uint32_t) * n_frames, hipHostMallocDefault));
+  g->d_tickets = (uint32_t*)(base + off_tickets);
+  g->d_errors = (uint32_t*)(base + off_errors);
+  g->d_scan = (uint64_t*)(base + off_scan);
+  HIP_TRY(ctx, hipHostMalloc((void**)&g->h_counts, sizeof(uint32_t) * 2 * n_frames, hipHostMallocDefault));
   HIP_TRY(ctx, hipEventCreateWithFlags(&g->upload_done, hipEventDisableTiming));
 
   // 3. fill descriptors and upload
@@ -263,6 +284,11 @@ int gof_create_impl(vpcc_ctx* ctx, const vpcc_frame_desc* frames, uint32_t n_fra
     D.out_rgb = F.attribute_count ? (vpcc_color3*)(base + o.rgb) : nullptr;
     D.out_patch = (gof_flags & VPCC_GOF_WANT_PATCH_INDEX) ? (uint16_t*)(base + o.pidx) : nullptr;
     D.n_points = g->d_counts + i;
+    D.tiles = (const TileItem*)(base + o.items);
+    D.n_tiles = (uint32_t)P.tiles.size();
+    D.scan_state = g->d_scan + g->scan_off[i];
+    D.ticket = g->d_tickets + 64 * (size_t)i;
+    D.error_flag = g->d_errors + i;
     D.width = F.width; D.height = F.height; D.R = F.occupancy_resolution; D.prec = F.occupancy_precision;
     D.bw = P.bw; D.bh = P.bh;
     D.n_patches = (uint32_t)P.patches.size();
@@ -311,9 +337,17 @@ int gof_create_impl(vpcc_ctx* ctx, const vpcc_frame_desc* frames, uint32_t n_fra
     if (!P.vblocks.empty())
       HIP_TRY(ctx, hipMemcpyAsync(base + o.vblocks, P.vblocks.data(), sizeof(VBlock) * P.vblocks.size(),
                                   hipMemcpyHostToDevice, s));
+    if (!P.tiles.empty())
+      HIP_TRY(ctx, hipMemcpyAsync(base + o.items, P.tiles.data(), sizeof(TileItem) * P.tiles.size(),
+                                  hipMemcpyHostToDevice, s));
   }
+  // the tile kernel needs every frame eligible and its vector loads aligned on the final pointers
+  bool tiles_ok = all_simple && !(gof_flags & VPCC_GOF_FORCE_GENERAL);
+  for (uint32_t i = 0; i < n_frames && tiles_ok; ++i) tiles_ok = tile_planes_aligned(g->h_frames[i]);
+  g->general = !tiles_ok;
   HIP_TRY(ctx, hipMemcpyAsync(g->d_frames, g->h_frames.data(), sizeof(DevFrame) * n_frames, hipMemcpyHostToDevice, s));
   HIP_TRY(ctx, hipMemsetAsync(g->d_counts, 0, sizeof(uint32_t) * n_frames, s));
+  HIP_TRY(ctx, hipMemsetAsync(base + ctrl_begin, 0, g->ctrl_bytes, s));
   HIP_TRY(ctx, hipEventRecord(g->upload_done, s));
   // the host staging vectors (plans) must stay alive until the copies are done
   HIP_TRY(ctx, hipStreamSynchronize(s));
@@ -378,6 +412,28 @@ extern "C" int vpcc_gof_reconstruct(vpcc_gof* g, uint32_t first, uint32_t count,
   g->n_timed = 0;
   Timer T{g, s, (g->flags & VPCC_GOF_PROFILE) != 0};
 
+  if (!g->general) {
+    // single-pass tile kernel: re-arm counts, tickets and look-back words, then ONE kernel
+    uint32_t max_groups = 0;
+    for (uint32_t i = first; i < first + count; ++i)
+      max_groups = std::max(max_groups, (uint32_t)(g->scan_off[i + 1] - g->scan_off[i]));
+    HIP_TRY(ctx, hipMemsetAsync(g->d_counts + first, 0, sizeof(uint32_t) * count, s));
+    if (first == 0 && count == g->n_frames) {
+      HIP_TRY(ctx, hipMemsetAsync(g->d_tickets, 0, g->ctrl_bytes, s));
+    } else {
+      HIP_TRY(ctx, hipMemsetAsync(g->d_tickets + 64 * (size_t)first, 0, 256 * (size_t)count, s));
+      HIP_TRY(ctx, hipMemsetAsync(g->d_errors + first, 0, sizeof(uint32_t) * count, s));
+      const size_t w0 = g->scan_off[first], w1 = g->scan_off[first + count];
+      if (w1 > w0) HIP_TRY(ctx, hipMemsetAsync(g->d_scan + w0, 0, sizeof(uint64_t) * (w1 - w0), s));
+    }
+    T.begin("k_recon_tiles");
+    launch_tiles(g->d_frames, first, count, max_groups, s);
+    T.end();
+    HIP_TRY(ctx, hipGetLastError());
+    g->launched = true;
+    return VPCC_OK;
+  }
+
   // general sequence: owner -> count -> scan -> emit
   size_t b2p_first = 0, b2p_len = 0;
   for (uint32_t i = 0; i < first + count; ++i) {
@@ -417,7 +473,12 @@ int fetch_counts(vpcc_gof* g) {
   if (g->counts_valid) return VPCC_OK;
   hipStream_t s = g->last_stream;
   HIP_TRY(g->ctx, hipMemcpyAsync(g->h_counts, g->d_counts, sizeof(uint32_t) * g->n_frames, hipMemcpyDeviceToHost, s));
+  HIP_TRY(g->ctx, hipMemcpyAsync(g->h_counts + g->n_frames, g->d_errors, sizeof(uint32_t) * g->n_frames,
+                                 hipMemcpyDeviceToHost, s));
   HIP_TRY(g->ctx, hipStreamSynchronize(s));
+  for (uint32_t i = 0; i < g->n_frames; ++i)
+    if (g->h_counts[g->n_frames + i])
+      return fail(g->ctx, VPCC_ERR_DEVICE, "look-back spin limit reached in frame " + std::to_string(i));
   g->counts_valid = true;
   return VPCC_OK;
 }
