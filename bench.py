@@ -66,7 +66,10 @@ def main():
     # ---- synthetic GOF of this rank (distinct frames: the working set, ~0.8 GB, is >> the 256 MB
     # Infinity Cache, so planes stream from HBM) -------------------------------------------------
     make = synth.longdress_frame if args.workload == "longdress" else synth.owlii_frame
-    frames = [make(rank * args.frames + i) for i in range(args.frames)]
+    kw = {}
+    if os.environ.get("VPCC_BENCH_SWAP_PROB"):          # diagnostic only: share of Swap-oriented patches
+        kw["swap_prob"] = float(os.environ["VPCC_BENCH_SWAP_PROB"])
+    frames = [make(rank * args.frames + i, **kw) for i in range(args.frames)]
     cap = 1_000_000 if args.workload == "longdress" else 2_400_000
 
     ctx = recon.Context(local_rank)

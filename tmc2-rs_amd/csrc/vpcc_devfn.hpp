@@ -8,6 +8,32 @@
 
 namespace vpcc {
 
+// Pointers read from a descriptor are generic ("flat") to the compiler.  flat_* instructions count
+// on vmcnt AND lgkmcnt and return out of order, which serialises them against LDS traffic, so every
+// plane/output access goes through an explicit global (address space 1) pointer.
+#define VPCC_GLOBAL __attribute__((address_space(1)))
+template <class T>
+__device__ __forceinline__ const VPCC_GLOBAL T* gl(const T* p) {
+  return (const VPCC_GLOBAL T*)p;
+}
+template <class T>
+__device__ __forceinline__ VPCC_GLOBAL T* glw(T* p) {
+  return (VPCC_GLOBAL T*)p;
+}
+
+// Whole-record load from global memory (descriptor tables).
+template <class T>
+__device__ __forceinline__ T gload(const T* p) {
+  T r;
+  __builtin_memcpy(&r, (const VPCC_GLOBAL void*)p, sizeof(T));
+  return r;
+}
+
+template <class T>
+__device__ __forceinline__ void gstore(T* p, const T& v) {
+  __builtin_memcpy((VPCC_GLOBAL void*)p, &v, sizeof(T));
+}
+
 // ------------------------------------------------------------------ helpers
 __device__ __forceinline__ uint32_t lane_id() { return threadIdx.x & 63u; }
 
@@ -118,13 +144,13 @@ __device__ __forceinline__ PixelOut eval_pixel(const DevFrame& f, const DevPatch
   const int32_t y = p.ay_u * (int32_t)u + p.ay_v * (int32_t)v + p.cy;
   o.x = (uint32_t)x;
   o.y = (uint32_t)y;
-  const uint8_t occ = f.occ[(o.y / f.prec) * f.occ_stride + (o.x / f.prec)];   // src/codec.rs:288-301, 393
+  const uint8_t occ = gl(f.occ)[(o.y / f.prec) * f.occ_stride + (o.x / f.prec)];   // src/codec.rs:288-301, 393
   if (occ == 0) return o;
-  const uint32_t d0 = (uint32_t)(f.geo[0][o.y * f.geo_stride[0] + o.x] >> 2);  // depth / 4, codec.rs:534
+  const uint32_t d0 = (uint32_t)(gl(f.geo[0])[o.y * f.geo_stride[0] + o.x] >> 2);  // depth / 4, codec.rs:534
   o.p0 = make_point(p, u, v, d0);
   o.n = 1;
   if (f.map_count > 1) {
-    const uint32_t d1 = (uint32_t)(f.geo[1][o.y * f.geo_stride[1] + o.x] >> 2);
+    const uint32_t d1 = (uint32_t)(gl(f.geo[1])[o.y * f.geo_stride[1] + o.x] >> 2);
     o.p1 = make_point1(f, p, u, v, o.p0, d1);
     if (!same_point(o.p0, o.p1)) o.n = 2;                                      // codec.rs:422-427
   }

@@ -27,17 +27,17 @@ __global__ __launch_bounds__(256) void k_block_owner(const DevFrame* __restrict_
   const DevFrame& f = frames[first + blockIdx.y];
   const uint32_t vb = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (vb >= f.n_vblocks) return;
-  const VBlock b = f.vblocks[vb];
-  const DevPatch& p = f.patches[b.patch];
+  const VBlock b = gload(f.vblocks + vb);
+  const DevPatch p = gload(f.patches + b.patch);
   const uint32_t R = f.R, RR = R * R;
   bool any = false;
   for (uint32_t i = lane_id(); i < RR; i += 64) {
     const uint32_t u = b.u0 * R + (i % R), v = b.v0 * R + (i / R);
     const int32_t x = p.ax_u * (int32_t)u + p.ax_v * (int32_t)v + p.cx;
     const int32_t y = p.ay_u * (int32_t)u + p.ay_v * (int32_t)v + p.cy;
-    any |= f.occ[((uint32_t)y / f.prec) * f.occ_stride + ((uint32_t)x / f.prec)] != 0;
+    any |= gl(f.occ)[((uint32_t)y / f.prec) * f.occ_stride + ((uint32_t)x / f.prec)] != 0;
   }
-  if (__ballot(any) != 0ull && lane_id() == 0) atomicMax(&f.block_to_patch[b.canvas_block], (uint32_t)b.patch + 1u);
+  if (__ballot(any) != 0ull && lane_id() == 0) atomicMax(f.block_to_patch + b.canvas_block, (uint32_t)b.patch + 1u);
 }
 
 // ------------------------------------------------------------------ k_count
@@ -45,11 +45,11 @@ __global__ __launch_bounds__(256) void k_count(const DevFrame* __restrict__ fram
   const DevFrame& f = frames[first + blockIdx.y];
   const uint32_t vb = blockIdx.x;
   if (vb >= f.n_vblocks) return;
-  const VBlock b = f.vblocks[vb];
+  const VBlock b = gload(f.vblocks + vb);
   __shared__ uint32_t wave_sum[4];
   uint32_t total = 0;
-  if (f.block_to_patch[b.canvas_block] == (uint32_t)b.patch + 1u) {           // codec.rs:379
-    const DevPatch p = f.patches[b.patch];
+  if (gl(f.block_to_patch)[b.canvas_block] == (uint32_t)b.patch + 1u) {       // codec.rs:379
+    const DevPatch p = gload(f.patches + b.patch);
     const uint32_t R = f.R, RR = R * R;
     uint32_t mine = 0;
     for (uint32_t i = threadIdx.x; i < RR; i += 256) {
@@ -61,7 +61,7 @@ __global__ __launch_bounds__(256) void k_count(const DevFrame* __restrict__ fram
     __syncthreads();
     total = wave_sum[0] + wave_sum[1] + wave_sum[2] + wave_sum[3];
   }
-  if (threadIdx.x == 0) f.vb_count[vb] = total;
+  if (threadIdx.x == 0) glw(f.vb_count)[vb] = total;
 }
 
 // ------------------------------------------------------------------- k_scan
@@ -75,7 +75,7 @@ __global__ __launch_bounds__(1024) void k_scan(const DevFrame* __restrict__ fram
   const uint32_t n = f.n_vblocks;
   for (uint32_t base = 0; base < n; base += 1024) {
     const uint32_t i = base + threadIdx.x;
-    const uint32_t c = i < n ? f.vb_count[i] : 0u;
+    const uint32_t c = i < n ? gl(f.vb_count)[i] : 0u;
     uint32_t incl = c;
     for (int off = 1; off < 64; off <<= 1) {
       const uint32_t t = __shfl_up(incl, off, 64);
@@ -86,12 +86,12 @@ __global__ __launch_bounds__(1024) void k_scan(const DevFrame* __restrict__ fram
     uint32_t wbase = 0;
     for (uint32_t w = 0; w < (threadIdx.x >> 6); ++w) wbase += wsum[w];
     const uint32_t carry = carry_s;
-    if (i < n) f.vb_offset[i] = carry + wbase + incl - c;
+    if (i < n) glw(f.vb_offset)[i] = carry + wbase + incl - c;
     __syncthreads();
     if (threadIdx.x == 1023) carry_s = carry + wbase + incl;
     __syncthreads();
   }
-  if (threadIdx.x == 0) *f.n_points = carry_s;
+  if (threadIdx.x == 0) *glw(f.n_points) = carry_s;
 }
 
 // ------------------------------------------------------------------- k_emit
@@ -99,11 +99,11 @@ __global__ __launch_bounds__(256) void k_emit(const DevFrame* __restrict__ frame
   const DevFrame& f = frames[first + blockIdx.y];
   const uint32_t vb = blockIdx.x;
   if (vb >= f.n_vblocks) return;
-  if (f.vb_count[vb] == 0) return;
-  const VBlock b = f.vblocks[vb];
-  const DevPatch p = f.patches[b.patch];
+  if (gl(f.vb_count)[vb] == 0) return;
+  const VBlock b = gload(f.vblocks + vb);
+  const DevPatch p = gload(f.patches + b.patch);
   __shared__ uint32_t wave_sum[4];
-  uint32_t base = f.vb_offset[vb];
+  uint32_t base = gl(f.vb_offset)[vb];
   const uint32_t R = f.R, RR = R * R;
   const uint32_t wave = threadIdx.x >> 6;
   for (uint32_t i0 = 0; i0 < RR; i0 += 256) {                                  // raster chunks keep the order
@@ -129,14 +129,14 @@ __global__ __launch_bounds__(256) void k_emit(const DevFrame* __restrict__ frame
       const Pt& pt = j == 0 ? o.p0 : o.p1;
       vpcc_point3 q;
       q.x = pt.c[0]; q.y = pt.c[1]; q.z = pt.c[2];
-      f.out_xyz[k] = q;
-      if (f.out_patch) f.out_patch[k] = b.patch;                                // partition, codec.rs:452
+      gstore(f.out_xyz + k, q);
+      if (f.out_patch) glw(f.out_patch)[k] = b.patch;                           // partition, codec.rs:452
       if (f.has_attr) {                                                         // color_point_cloud, codec.rs:626-644
         const uint32_t cidx = (o.y >> 1) * f.attr_cstride[j] + (o.x >> 1);     // chroma nearest neighbour
-        const uint16_t Y = f.attr_y[j][o.y * f.attr_stride[j] + o.x];
-        const uint16_t U = f.attr_u[j][cidx];
-        const uint16_t V = f.attr_v[j][cidx];
-        f.out_rgb[k] = yuv10_to_rgb8_fast(Y, U, V);
+        const uint16_t Y = gl(f.attr_y[j])[o.y * f.attr_stride[j] + o.x];
+        const uint16_t U = gl(f.attr_u[j])[cidx];
+        const uint16_t V = gl(f.attr_v[j])[cidx];
+        gstore(f.out_rgb + k, yuv10_to_rgb8_fast(Y, U, V));
       }
     }
     base += tot;
@@ -150,7 +150,7 @@ __global__ __launch_bounds__(256) void k_upsample_occupancy(const DevFrame* __re
                                                             uint8_t* __restrict__ out) {
   const DevFrame& f = frames[frame];
   const uint32_t x = blockIdx.x * 256 + threadIdx.x, y = blockIdx.y;
-  if (x < f.width) out[(size_t)y * f.width + x] = f.occ[(y / f.prec) * f.occ_stride + (x / f.prec)];
+  if (x < f.width) out[(size_t)y * f.width + x] = gl(f.occ)[(y / f.prec) * f.occ_stride + (x / f.prec)];
 }
 
 // ----------------------------------------------------------------- launchers

@@ -1,26 +1,34 @@
 // vpcc_tiles.hip — single-pass, wave-per-tile reconstruction kernel for gfx950 (CDNA4, wave64).
 //
-// This is the production path for the common configuration (block size R = 16, Default/Swap
-// patches, 8-byte aligned luma rows).  One launch per batch of frames; every plane is read once,
-// every output byte written once.
+// Production path for the common configuration (block size R = 16, Default/Swap patches, 8-byte
+// aligned luma rows).  One launch per batch of frames; every plane is read from HBM once, every
+// output byte written once.
 //
 // Work decomposition
 //   item   = one virtual block that owns its canvas block (host-filtered, see vpcc_host.cpp), in
 //            the reference's emission order (src/codec.rs:352-385);
-//   wave   = 4 consecutive items, processed one after the other; lane l of the wave owns the 4
-//            pixels u1 = 4*(l&3)..+3 of row v1 = l>>2 of the 16x16 block, in PATCH-LOCAL
-//            coordinates, so "lane order, then pixel order inside the lane" IS the reference's
-//            emission order for both orientations.  Default tiles read 8 B per lane per plane
-//            (canvas rows); Swap tiles read the transposed pixels with four 2-B loads per plane;
-//   group  = one 256-thread workgroup = 16 consecutive items = one ticket and one look-back word.
+//   wave   = 4 consecutive items, one after the other.  Lane l reads the 4 CANVAS pixels
+//            x0 + 4*(l&3)..+3 of canvas row y0 + (l>>2): 8 contiguous bytes per plane.  For Default
+//            patches "lane order, then pixel order inside the lane" is the reference's emission order;
+//            for Swap patches (u runs down the canvas column) the per-pixel ranks are transposed
+//            through a 16x16 byte matrix in LDS instead of transposing the loads;
+//   group  = one 256-thread workgroup = 4 waves = 16 consecutive items = one ticket and one
+//            look-back word.
 //
-// Per group: (1) every wave loads occupancy + both geometry layers of its 4 items, then — only
-// where occupied — both attribute layers (these loads fly during the look-back); (2) points are
-// counted per item (D1 is dropped when it equals D0, src/codec.rs:422-427) and the group total is
-// published; (3) wave 0 obtains the group's output offset by decoupled look-back over the earlier
-// groups of the frame; (4) each wave compacts its items' points into LDS slots at their rank,
-// colour converted on the way (src/codec.rs:626-644, 661-687), and streams the slots out with
-// contiguous unaligned dwordx3 stores (2 points / 4 colours per lane).
+// Per group
+//   1. count: occupancy + both geometry layers of the 16 items; a D1 point is dropped when it equals
+//      the D0 point (src/codec.rs:422-427); the group total is published;
+//   2. wave 0 obtains the group's output offset by decoupled look-back over the earlier groups of
+//      the frame, while every wave already fetches its first item's samples again (L2-hot);
+//   3. per item (rolled loop, next item's samples prefetched): every lane writes one 8-B record
+//      {depth, pixel, layer | Y, U, V} per point into the wave's LDS slots at the point's rank
+//      (= compaction in emission order); then lane <-> point: back-projection
+//      (src/decoder.rs:871-888), colour conversion (src/codec.rs:661-687) and contiguous stores
+//      (6 + 3 bytes per lane: the pattern that streams best on gfx950, tools/micro/store_bw.hip).
+//   PMC counters and in-kernel stamps (tools/pmc.sh, tools/stamps.py) show wave lifetime — the
+//   chain of dependent memory round trips — and instruction issue bounding this kernel, not HBM:
+//   hence the dense lane<->point loop with one colour site, the exact INTEGER colour path, the
+//   axes-specialised packing and the small code footprint.
 //
 // Cross-workgroup ordering is placement-independent (cdna_hip_programming.md §6 Guideline 16):
 // groups are drawn from a per-frame TICKET counter, so a look-back only waits for tickets that
@@ -43,10 +51,10 @@ constexpr uint64_t kPrefix = 2ull << kStatusShift;
 constexpr uint32_t kSpinLimit = 1u << 22;
 
 __device__ __forceinline__ uint64_t st_load(const uint64_t* p) {
-  return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  return __hip_atomic_load(gl(p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 __device__ __forceinline__ void st_store(uint64_t* p, uint64_t v) {
-  __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  __hip_atomic_store(glw(p), v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
 // Exclusive prefix of group `g` within its frame.  One full wave; same result in every lane.
@@ -62,7 +70,7 @@ __device__ uint32_t look_back_groups(const DevFrame& f, uint32_t g) {
       s = st_load(f.scan_state + my);
       while ((s >> kStatusShift) == 0) {
         __builtin_amdgcn_s_sleep(8);
-        if (++spins > kSpinLimit) {
+        if (++spins > kSpinLimit) {               // never reached in a healthy run; reported by the host
           atomicOr(f.error_flag, 1u);
           s = kPrefix;
           break;
@@ -81,6 +89,15 @@ __device__ uint32_t look_back_groups(const DevFrame& f, uint32_t g) {
   return excl;
 }
 
+// Orders this wave's LDS writes before its later LDS reads across lanes (and vice versa).  A wave's
+// DS instructions execute in issue order, so no counter wait is needed — only the compiler has to
+// keep the accesses on their side of this point.
+__device__ __forceinline__ void wave_sync() {
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
 struct Px4 { uint32_t lo, hi; };   // four u16 samples, pixel j in bits 16*(j&1) of (j<2 ? lo : hi)
 
 template <int J>
@@ -88,27 +105,127 @@ __device__ __forceinline__ uint32_t px(const Px4& v) {
   return J == 0 ? (v.lo & 0xFFFFu) : J == 1 ? (v.lo >> 16) : J == 2 ? (v.hi & 0xFFFFu) : (v.hi >> 16);
 }
 
-struct TileRegs {
-  Px4 g0, g1;          // geometry D0 / D1 samples of the lane's 4 pixels
+// Scalar (wave-uniform) view of one work item.
+struct Item {
+  uint32_t x0, y0, patch, flags, axes, tb, bb, d1, lod_x, lod_y;
+};
+
+__device__ __forceinline__ Item load_item(const TileItem* p) {
+  uint32_t w[6];
+  __builtin_memcpy(w, (const VPCC_GLOBAL void*)p, 24);
+#pragma unroll
+  for (int k = 0; k < 6; ++k) w[k] = __builtin_amdgcn_readfirstlane(w[k]);
+  Item it;
+  it.x0 = w[0] & 0xFFFFu; it.y0 = w[0] >> 16;
+  it.patch = w[1] & 0xFFFFu; it.flags = (w[1] >> 16) & 0xFFu; it.axes = w[1] >> 24;
+  it.tb = w[2]; it.bb = w[3]; it.d1 = w[4];
+  it.lod_x = w[5] & 0xFFFFu; it.lod_y = w[5] >> 16;
+  return it;
+}
+
+struct Samples {       // one item's samples of the lane's 4 pixels
+  Px4 g0, g1;          // geometry D0 / D1
   Px4 y0, y1;          // attribute luma, layer 0 / 1
   uint32_t u0, v0, u1, v1;   // chroma: sample for pixels 0,1 in the low half, for pixels 2,3 in the high half
   uint32_t occ;        // bit j: pixel j occupied
-  uint32_t dup;        // bit j: D1 point equals D0 point (or single map): one point only
-  uint32_t cnt;        // points this lane emits
 };
 
-__device__ __forceinline__ Px4 load4_row(const uint16_t* p) {       // 8-B aligned by construction
-  const uint2 v = *reinterpret_cast<const uint2*>(p);
-  return Px4{v.x, v.y};
+__device__ __forceinline__ Px4 load4_row(const VPCC_GLOBAL uint16_t* p) {   // 8-B aligned by construction
+  Px4 v;
+  __builtin_memcpy(&v, p, 8);
+  return v;
 }
-__device__ __forceinline__ Px4 load4_col(const uint16_t* p, uint32_t stride) {
-  const uint32_t a = p[0], b = p[stride], c = p[2 * stride], d = p[3 * stride];
-  return Px4{a | (b << 16), c | (d << 16)};
+__device__ __forceinline__ uint32_t load2(const VPCC_GLOBAL uint16_t* p) {   // 4-B aligned by construction
+  return *reinterpret_cast<const VPCC_GLOBAL uint32_t*>(p);
+}
+// Lane l always reads the 4 CANVAS pixels x0 + 4*(l&3) .. +3 of canvas row y0 + (l>>2): 8 contiguous
+// bytes per plane, whatever the patch orientation.  For Default patches this is already the
+// emission order; for Swap patches (u runs down the canvas column) the ranks are transposed through
+// LDS instead of the loads (see pixel_ranks).
+__device__ __forceinline__ void lane_origin(const Item& it, uint32_t lane, uint32_t& px0, uint32_t& py0) {
+  px0 = it.x0 + 4u * (lane & 3u);
+  py0 = it.y0 + (lane >> 2);
 }
 
-// Coordinates of one point as the reference builds them (src/decoder.rs:871-888): assignment order
-// normal, tangent, bitangent; `as u16` truncation.  Returns {x | y << 16, z}.
-__device__ __forceinline__ uint2 pack_point(const TileItem& it, uint32_t n, uint32_t t, uint32_t b) {
+// Occupancy bits of the lane's 4 pixels, through the low-resolution plane (src/codec.rs:288-301, 393).
+__device__ __forceinline__ uint32_t load_occupancy(const DevFrame& f, const Item& it, bool valid, uint32_t lane) {
+  if (!valid) return 0;
+  uint32_t px0, py0;
+  lane_origin(it, lane, px0, py0);
+  if (f.prec >= 4)                                    // the 4 pixels share one occupancy sample
+    return gl(f.occ)[(py0 / f.prec) * f.occ_stride + px0 / f.prec] ? 0xFu : 0u;
+  uint32_t occ = 0;
+#pragma unroll
+  for (uint32_t j = 0; j < 4; ++j)
+    occ |= (gl(f.occ)[(py0 / f.prec) * f.occ_stride + (px0 + j) / f.prec] ? 1u : 0u) << j;
+  return occ;
+}
+
+__device__ __forceinline__ void load_geometry(const DevFrame& f, const Item& it, uint32_t lane, Samples& s) {
+  s.g0 = Px4{0, 0}; s.g1 = Px4{0, 0};
+  if (s.occ == 0) return;
+  uint32_t px0, py0;
+  lane_origin(it, lane, px0, py0);
+  s.g0 = load4_row(gl(f.geo[0]) + py0 * f.geo_stride[0] + px0);
+  if (f.map_count > 1) s.g1 = load4_row(gl(f.geo[1]) + py0 * f.geo_stride[1] + px0);
+}
+
+// Attribute samples of the occupied lanes; chroma is nearest-neighbour (src/decoder.rs:977): pixels
+// 0,1 of the lane use chroma sample px0/2, pixels 2,3 the next one.
+__device__ __forceinline__ void load_attributes(const DevFrame& f, const Item& it, uint32_t lane, Samples& s) {
+  s.y0 = Px4{0, 0}; s.y1 = Px4{0, 0};
+  s.u0 = s.v0 = s.u1 = s.v1 = 0;
+  if (s.occ == 0 || !f.has_attr) return;
+  uint32_t px0, py0;
+  lane_origin(it, lane, px0, py0);
+  const uint32_t c0 = (py0 >> 1) * f.attr_cstride[0] + (px0 >> 1);
+  s.y0 = load4_row(gl(f.attr_y[0]) + py0 * f.attr_stride[0] + px0);
+  s.u0 = load2(gl(f.attr_u[0]) + c0);
+  s.v0 = load2(gl(f.attr_v[0]) + c0);
+  if (f.map_count > 1) {
+    const uint32_t c1 = (py0 >> 1) * f.attr_cstride[1] + (px0 >> 1);
+    s.y1 = load4_row(gl(f.attr_y[1]) + py0 * f.attr_stride[1] + px0);
+    s.u1 = load2(gl(f.attr_u[1]) + c1);
+    s.v1 = load2(gl(f.attr_v[1]) + c1);
+  }
+}
+
+__device__ __forceinline__ uint32_t normal_of(const Item& it, uint32_t depth) {          // decoder.rs:881-888
+  return (it.flags & kTileMode1) ? (it.d1 > depth ? it.d1 : depth) - depth : depth + it.d1;
+}
+
+// Which D1 points duplicate their D0 point (src/codec.rs:422-427), and the lane's point count.
+//   absolute D1: the two points differ only in the normal coordinate — unless a later assignment
+//     overwrites it (degenerate axes), then they are always equal;
+//   relative D1: point0[normal_axis] +- d1 as u16 leaves the point unchanged only for d1 == 0.
+__device__ __forceinline__ void classify(const DevFrame& f, const Item& it, const Samples& s, uint32_t& dup,
+                                         uint32_t& cnt) {
+  dup = 0xFu;                                         // single map: D0 only
+  if (f.map_count > 1) {
+    dup = 0;
+    const uint32_t na = it.axes & 3u;
+    const bool normal_visible = na != ((it.axes >> 2) & 3u) && na != ((it.axes >> 4) & 3u);
+    const uint32_t a0[4] = {px<0>(s.g0) >> 2, px<1>(s.g0) >> 2, px<2>(s.g0) >> 2, px<3>(s.g0) >> 2};   // depth / 4
+    const uint32_t a1[4] = {px<0>(s.g1) >> 2, px<1>(s.g1) >> 2, px<2>(s.g1) >> 2, px<3>(s.g1) >> 2};
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      bool d;
+      if (f.absolute_d1) d = !normal_visible || ((normal_of(it, a0[j]) ^ normal_of(it, a1[j])) & 0xFFFFu) == 0;
+      else d = a1[j] == 0;
+      dup |= (d ? 1u : 0u) << j;
+    }
+  }
+  cnt = 2u * (uint32_t)__builtin_popcount(s.occ) - (uint32_t)__builtin_popcount(s.occ & dup);
+}
+
+// {x | y << 16, z} of a point as the reference builds it (src/decoder.rs:871-888): assignment order
+// normal, tangent, bitangent, `as u16` truncation.  The three axis tables of set_view_id
+// (src/decoder.rs:790-796) get straight-line code; anything else takes the generic selects.
+__device__ __forceinline__ uint2 pack_point(const Item& it, uint32_t n, uint32_t t, uint32_t b) {
+  n &= 0xFFFFu; t &= 0xFFFFu; b &= 0xFFFFu;
+  if (it.axes == (0u | (2u << 2) | (1u << 4))) return make_uint2(n | (b << 16), t);   // axes (0,2,1)
+  if (it.axes == (1u | (2u << 2) | (0u << 4))) return make_uint2(b | (n << 16), t);   // axes (1,2,0)
+  if (it.axes == (2u | (0u << 2) | (1u << 4))) return make_uint2(t | (b << 16), n);   // axes (2,0,1)
   const uint32_t na = it.axes & 3u, ta = (it.axes >> 2) & 3u, ba = (it.axes >> 4) & 3u;
   uint32_t c[3];
 #pragma unroll
@@ -117,17 +234,13 @@ __device__ __forceinline__ uint2 pack_point(const TileItem& it, uint32_t n, uint
     if (na == a) v = n;
     if (ta == a) v = t;
     if (ba == a) v = b;
-    c[a] = v & 0xFFFFu;
+    c[a] = v;
   }
   return make_uint2(c[0] | (c[1] << 16), c[2]);
 }
 
-__device__ __forceinline__ uint32_t normal_of(const TileItem& it, uint32_t depth) {
-  return (it.flags & kTileMode1) ? (it.d1 > depth ? it.d1 : depth) - depth : depth + it.d1;
-}
-
 // D1 point in relative mode (src/codec.rs:551-559): point0 with +-d1 on coordinate index normal_axis.
-__device__ __forceinline__ uint2 relative_point(const TileItem& it, uint2 p0, uint32_t d1) {
+__device__ __forceinline__ uint2 relative_point(const Item& it, uint2 p0, uint32_t d1) {
   const uint32_t na = it.axes & 3u;
   uint32_t c[3] = {p0.x & 0xFFFFu, p0.x >> 16, p0.y & 0xFFFFu};
 #pragma unroll
@@ -136,179 +249,156 @@ __device__ __forceinline__ uint2 relative_point(const TileItem& it, uint2 p0, ui
   return make_uint2(c[0] | (c[1] << 16), c[2]);
 }
 
-__device__ __forceinline__ uint32_t pack_rgb(vpcc_color3 c) {
-  return (uint32_t)c.r | ((uint32_t)c.g << 8) | ((uint32_t)c.b << 16);
+// ---- convert_yuv10_to_rgb8 (src/codec.rs:661-687), exact integer form --------------------------
+// With T = c*255/1023 the reference's result is clamp(floor(p)), p = fl(fl(c/1023)*255), |p - T| < 2e-13
+// for 10-bit samples (two roundings of the division/multiplication plus the roundings inside c).
+// Using the decimal coefficients, T is the rational
+//     R: 17*(2500*Y + 3937*dv) / 170500        G: 17*(100000*Y - 18733*du - 46813*dv) / 6820000
+//     B: 17*(100000*Y + 185563*du) / 6820000   (du = U-512, dv = V-512; the double constants differ
+// from the decimals by < 1.2e-16, i.e. by < 3e-14 in T).  A non-integer T is at least 1/6820000 away
+// from every integer, far more than those errors, so floor(p) == floor(T) == integer quotient; when
+// the division is exact (10 364 of the 2^30 triplets, e.g. grey with luma a multiple of 341) the lane
+// takes the IEEE f64 path.  Verified against the f64 formula on all 2^30 10-bit triplets
+// (tests/colour_exhaustive.c).  Samples above 1023 also take the f64 path.
+__device__ __forceinline__ int colour_channel(int32_t n, uint32_t d) {
+  if (n <= 0) return 0;
+  const uint32_t x = 17u * (uint32_t)n;
+  const uint32_t q = x / d;
+  if (q * d == x) return -1;
+  return q > 255u ? 255 : (int)q;
 }
 
-// ---- phase 1a: occupancy + geometry of one item ------------------------------------------------
-__device__ __forceinline__ void load_geometry(const DevFrame& f, const TileItem& it, bool valid, uint32_t lane,
-                                              TileRegs& t) {
-  t.occ = 0; t.dup = 0; t.cnt = 0;
-  t.g0 = Px4{0, 0}; t.g1 = Px4{0, 0};
-  if (!valid) return;
-  const uint32_t q = lane & 3u, r = lane >> 2;
-  const bool swap = it.flags & kTileSwap;
-  // first pixel of the lane and the canvas step between its 4 pixels
-  const uint32_t px0 = swap ? it.x0 + r : it.x0 + 4u * q;
-  const uint32_t py0 = swap ? it.y0 + 4u * q : it.y0 + r;
-  if (f.prec >= 4) {                                  // the 4 pixels share one occupancy sample
-    t.occ = f.occ[(py0 / f.prec) * f.occ_stride + px0 / f.prec] ? 0xFu : 0u;     // src/codec.rs:288-301, 393
-  } else {
+__device__ __forceinline__ uint32_t yuv10_to_rgb8_int(uint32_t Y, uint32_t U, uint32_t V) {
+  const int32_t y = (int32_t)Y, du = (int32_t)U - 512, dv = (int32_t)V - 512;
+  const int r = colour_channel(2500 * y + 3937 * dv, 170500u);
+  const int g = colour_channel(100000 * y - 18733 * du - 46813 * dv, 6820000u);
+  const int b = colour_channel(100000 * y + 185563 * du, 6820000u);
+  uint32_t rgb = (uint32_t)r | ((uint32_t)g << 8) | ((uint32_t)b << 16);
+  if ((Y | U | V) > 1023u || (r | g | b) < 0) {       // rare: exact IEEE division path
+    const vpcc_color3 c = yuv10_to_rgb8((uint16_t)Y, (uint16_t)U, (uint16_t)V);
+    rgb = (uint32_t)c.r | ((uint32_t)c.g << 8) | ((uint32_t)c.b << 16);
+  }
+  return rgb;
+}
+
+// 8-B point record:
+//   x: depth | pixel << 16 | layer << 24      (pixel = 4*lane + j: du = pixel & 15, dv = pixel >> 4)
+//   y: Y | U << 10 | V << 20 | wide << 30     (wide: some sample exceeds 10 bits; the consumer then
+//                                              re-reads the three samples from the planes)
+// A D1 record always directly follows the D0 record of its pixel (relative D1 reads its depth there).
+__device__ __forceinline__ uint32_t pack_yuv(uint32_t y, uint32_t u, uint32_t v) {
+  const uint32_t wide = (y | u | v) > 1023u ? 1u : 0u;
+  return (y & 1023u) | ((u & 1023u) << 10) | ((v & 1023u) << 20) | (wide << 30);
+}
+
+// Writes the records of the lane's pixel J at rank `rank` (and rank + 1 for a distinct D1 point).
+// `pixel` = dv * 16 + du, the pixel's patch-local offsets inside the block.
+template <int J>
+__device__ __forceinline__ void put_records(const Samples& s, uint32_t dup, uint32_t pixel, uint32_t rank,
+                                            uint2* slots) {
+  if (!((s.occ >> J) & 1u)) return;
+  const uint32_t u0 = J < 2 ? (s.u0 & 0xFFFFu) : (s.u0 >> 16), v0 = J < 2 ? (s.v0 & 0xFFFFu) : (s.v0 >> 16);
+  slots[rank] = make_uint2((px<J>(s.g0) >> 2) | (pixel << 16), pack_yuv(px<J>(s.y0), u0, v0));
+  if (!((dup >> J) & 1u)) {
+    const uint32_t u1 = J < 2 ? (s.u1 & 0xFFFFu) : (s.u1 >> 16), v1 = J < 2 ? (s.v1 & 0xFFFFu) : (s.v1 >> 16);
+    slots[rank + 1u] = make_uint2((px<J>(s.g1) >> 2) | (pixel << 16) | (1u << 24), pack_yuv(px<J>(s.y1), u1, v1));
+  }
+}
+
+// Inclusive scan over the 64 lanes.
+__device__ __forceinline__ uint32_t wave_inclusive_scan(uint32_t v, uint32_t lane) {
+  for (int off = 1; off < 64; off <<= 1) {
+    const uint32_t t = __shfl_up(v, off, 64);
+    if ((int)lane >= off) v += t;
+  }
+  return v;
+}
+
+// Ranks of the lane's 4 pixels inside the item, emission order (src/codec.rs:382-385: v1 outer, u1 inner).
+//   Default patch: u runs along the canvas row, so lane order then pixel order is the emission order.
+//   Swap patch   : u runs down the canvas column.  The per-pixel counts go through a 16x16 byte matrix
+//                  in LDS (the wave's own, not yet used slot area): every lane re-reads the counts of
+//                  4 pixels that are consecutive in COLUMN-major order, scans, and scatters the ranks
+//                  back to the row-major owners.
+__device__ __forceinline__ void pixel_ranks(const Item& it, const Samples& s, uint32_t dup, uint32_t cnt,
+                                            uint32_t lane, unsigned char* scratch, uint32_t rk[4]) {
+  uint32_t c[4];
 #pragma unroll
-    for (uint32_t j = 0; j < 4; ++j) {
-      const uint32_t x = swap ? px0 : px0 + j, y = swap ? py0 + j : py0;
-      t.occ |= (f.occ[(y / f.prec) * f.occ_stride + x / f.prec] ? 1u : 0u) << j;
-    }
+  for (int j = 0; j < 4; ++j) c[j] = ((s.occ >> j) & 1u) ? (((dup >> j) & 1u) ? 1u : 2u) : 0u;
+  if (!(it.flags & kTileSwap)) {
+    const uint32_t first = wave_inclusive_scan(cnt, lane) - cnt;
+    rk[0] = first; rk[1] = rk[0] + c[0]; rk[2] = rk[1] + c[1]; rk[3] = rk[2] + c[2];
+    return;
   }
-  if (t.occ == 0) return;
-  if (!swap) {
-    t.g0 = load4_row(f.geo[0] + py0 * f.geo_stride[0] + px0);
-    if (f.map_count > 1) t.g1 = load4_row(f.geo[1] + py0 * f.geo_stride[1] + px0);
-  } else {
-    t.g0 = load4_col(f.geo[0] + py0 * f.geo_stride[0] + px0, f.geo_stride[0]);
-    if (f.map_count > 1) t.g1 = load4_col(f.geo[1] + py0 * f.geo_stride[1] + px0, f.geo_stride[1]);
+  uint32_t* m32 = reinterpret_cast<uint32_t*>(scratch);                   // counts M[y][x], one byte each
+  uint16_t* r16 = reinterpret_cast<uint16_t*>(scratch + 256);             // ranks  R[y][x], u16 each
+  m32[lane] = c[0] | (c[1] << 8) | (c[2] << 16) | (c[3] << 24);            // row y = lane>>2, x = 4*(lane&3)..+3
+  wave_sync();
+  const uint32_t x = lane >> 2, yq = 4u * (lane & 3u);                     // column-major chunk: x, y = yq..yq+3
+  uint32_t t[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) t[j] = scratch[(yq + j) * 16u + x];
+  const uint32_t sum = t[0] + t[1] + t[2] + t[3];
+  uint32_t r = wave_inclusive_scan(sum, lane) - sum;
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    r16[(yq + j) * 16u + x] = (uint16_t)r;
+    r += t[j];
   }
+  wave_sync();
+  const uint2 back = *reinterpret_cast<const uint2*>(r16 + 4u * lane);    // R[lane>>2][4*(lane&3) .. +3]
+  rk[0] = back.x & 0xFFFFu; rk[1] = back.x >> 16; rk[2] = back.y & 0xFFFFu; rk[3] = back.y >> 16;
+  wave_sync();                                                             // scratch is overwritten by records next
 }
 
-// ---- phase 1b: attribute samples of the occupied lanes ------------------------------------------
-__device__ __forceinline__ void load_attributes(const DevFrame& f, const TileItem& it, uint32_t lane, TileRegs& t) {
-  t.y0 = Px4{0, 0}; t.y1 = Px4{0, 0};
-  t.u0 = t.v0 = t.u1 = t.v1 = 0;
-  if (t.occ == 0 || !f.has_attr) return;
-  const uint32_t q = lane & 3u, r = lane >> 2;
-  const bool swap = it.flags & kTileSwap;
-  const uint32_t px0 = swap ? it.x0 + r : it.x0 + 4u * q;
-  const uint32_t py0 = swap ? it.y0 + 4u * q : it.y0 + r;
-  if (!swap) {
-    // chroma nearest neighbour (src/decoder.rs:977): pixels 0,1 -> sample (px0/2), pixels 2,3 -> next
-    const uint32_t c0 = (py0 >> 1) * f.attr_cstride[0] + (px0 >> 1);
-    t.y0 = load4_row(f.attr_y[0] + py0 * f.attr_stride[0] + px0);
-    t.u0 = *reinterpret_cast<const uint32_t*>(f.attr_u[0] + c0);
-    t.v0 = *reinterpret_cast<const uint32_t*>(f.attr_v[0] + c0);
-    if (f.map_count > 1) {
-      const uint32_t c1 = (py0 >> 1) * f.attr_cstride[1] + (px0 >> 1);
-      t.y1 = load4_row(f.attr_y[1] + py0 * f.attr_stride[1] + px0);
-      t.u1 = *reinterpret_cast<const uint32_t*>(f.attr_u[1] + c1);
-      t.v1 = *reinterpret_cast<const uint32_t*>(f.attr_v[1] + c1);
-    }
-  } else {
-    // pixels run down a canvas column: 0,1 share chroma row py0/2, pixels 2,3 the next one
-    const uint32_t c0 = (py0 >> 1) * f.attr_cstride[0] + (px0 >> 1);
-    t.y0 = load4_col(f.attr_y[0] + py0 * f.attr_stride[0] + px0, f.attr_stride[0]);
-    t.u0 = (uint32_t)f.attr_u[0][c0] | ((uint32_t)f.attr_u[0][c0 + f.attr_cstride[0]] << 16);
-    t.v0 = (uint32_t)f.attr_v[0][c0] | ((uint32_t)f.attr_v[0][c0 + f.attr_cstride[0]] << 16);
-    if (f.map_count > 1) {
-      const uint32_t c1 = (py0 >> 1) * f.attr_cstride[1] + (px0 >> 1);
-      t.y1 = load4_col(f.attr_y[1] + py0 * f.attr_stride[1] + px0, f.attr_stride[1]);
-      t.u1 = (uint32_t)f.attr_u[1][c1] | ((uint32_t)f.attr_u[1][c1 + f.attr_cstride[1]] << 16);
-      t.v1 = (uint32_t)f.attr_v[1][c1] | ((uint32_t)f.attr_v[1][c1 + f.attr_cstride[1]] << 16);
-    }
-  }
-}
+// Diagnostic build only (variant bit 64): per-phase cycle sums of waves 0 and 8 of every group.
+// Never read by the kernel; fetched with vpcc_debug_read_stamps().
+__device__ unsigned long long g_stamps[16];
 
-// ---- phase 2: which D1 points are duplicates, and the lane's point count -----------------------
-template <int J>
-__device__ __forceinline__ void classify_pixel(const DevFrame& f, const TileItem& it, bool normal_visible,
-                                               TileRegs& t) {
-  if (!((t.occ >> J) & 1u)) return;
-  bool dup = true;                                     // single map: D0 only
-  if (f.map_count > 1) {
-    const uint32_t d0 = px<J>(t.g0) >> 2, d1 = px<J>(t.g1) >> 2;      // depth / 4, src/codec.rs:534, 548
-    if (f.absolute_d1)
-      dup = !normal_visible || ((normal_of(it, d0) ^ normal_of(it, d1)) & 0xFFFFu) == 0;
-    else
-      dup = d1 == 0;                                   // u16 += / -= d1 leaves the point unchanged only for 0
-  }
-  t.dup |= (dup ? 1u : 0u) << J;
-  t.cnt += dup ? 1u : 2u;
+__device__ __forceinline__ unsigned long long stamp() {
+  unsigned long long t;
+  asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t)::"memory");
+  return t;
 }
+#define VPCC_STAMP(slot)                                                                  \
+  if (variant & 64u) {                                                                      \
+    const unsigned long long now_ = stamp();                                                \
+    t_acc[slot] = now_ - t_prev;                                                            \
+    t_prev = now_;                                                                          \
+  }
+#define VPCC_STAMP_FLUSH()                                                                \
+  if ((variant & 64u) && lane == 0) {                           \
+    for (int q_ = 0; q_ < 10; ++q_) atomicAdd(&g_stamps[q_], t_acc[q_]);                    \
+    atomicAdd(&g_stamps[15], 1ull);                                                         \
+  }
 
-// ---- phase 4: emit the lane's points of pixel J into the staging slots -------------------------
-template <int J>
-__device__ __forceinline__ void emit_pixel(const DevFrame& f, const TileItem& it, const TileRegs& t, uint32_t lane,
-                                           uint32_t& rank, uint2* sx, uint32_t* sc) {
-  if (!((t.occ >> J) & 1u)) return;
-  const uint32_t du = 4u * (lane & 3u) + J, dv = lane >> 2;            // patch-local offsets inside the block
-  const uint32_t tg = it.tb + du * it.lod_x, bt = it.bb + dv * it.lod_y;
-  const uint32_t d0 = px<J>(t.g0) >> 2;
-  const uint2 p0 = pack_point(it, normal_of(it, d0), tg, bt);
-  sx[rank] = p0;
-  if (f.has_attr) {
-    const uint32_t u = J < 2 ? (t.u0 & 0xFFFFu) : (t.u0 >> 16), v = J < 2 ? (t.v0 & 0xFFFFu) : (t.v0 >> 16);
-    sc[rank] = pack_rgb(yuv10_to_rgb8_fast((uint16_t)px<J>(t.y0), (uint16_t)u, (uint16_t)v));
-  }
-  ++rank;
-  if (!((t.dup >> J) & 1u)) {
-    const uint32_t d1 = px<J>(t.g1) >> 2;
-    sx[rank] = f.absolute_d1 ? pack_point(it, normal_of(it, d1), tg, bt) : relative_point(it, p0, d1);
-    if (f.has_attr) {
-      const uint32_t u = J < 2 ? (t.u1 & 0xFFFFu) : (t.u1 >> 16), v = J < 2 ? (t.v1 & 0xFFFFu) : (t.v1 >> 16);
-      sc[rank] = pack_rgb(yuv10_to_rgb8_fast((uint16_t)px<J>(t.y1), (uint16_t)u, (uint16_t)v));
-    }
-    ++rank;
-  }
-}
-
-struct __attribute__((packed)) U3 { uint32_t a, b, c; };
-
-// Streams `n` staged points to out_xyz/out_rgb[base ...): 2 points (12 B) resp. 4 colours (12 B) per lane.
-__device__ __forceinline__ void flush_item(const DevFrame& f, const TileItem& it, uint32_t base, uint32_t n,
-                                           uint32_t lane, const uint2* sx, const uint32_t* sc) {
-  unsigned char* gx = reinterpret_cast<unsigned char*>(f.out_xyz) + (size_t)base * 6u;
-  for (uint32_t pi = lane; 2u * pi < n; pi += 64u) {
-    const uint4 a = *reinterpret_cast<const uint4*>(sx + 2u * pi);     // two 8-B slots
-    if (2u * pi + 1u < n) {
-      const U3 o{a.x, (a.y & 0xFFFFu) | (a.z << 16), (a.z >> 16) | (a.w << 16)};
-      __builtin_memcpy(gx + 12u * pi, &o, 12);
-    } else {
-      const uint32_t x = a.x;
-      const uint16_t z = (uint16_t)a.y;
-      __builtin_memcpy(gx + 12u * pi, &x, 4);
-      __builtin_memcpy(gx + 12u * pi + 4, &z, 2);
-    }
-    if (f.out_patch) {                                                 // partition, src/codec.rs:452
-      f.out_patch[base + 2u * pi] = it.patch;
-      if (2u * pi + 1u < n) f.out_patch[base + 2u * pi + 1u] = it.patch;
-    }
-  }
-  if (!f.has_attr) return;
-  unsigned char* gc = reinterpret_cast<unsigned char*>(f.out_rgb) + (size_t)base * 3u;
-  for (uint32_t qi = lane; 4u * qi < n; qi += 64u) {
-    const uint4 c = *reinterpret_cast<const uint4*>(sc + 4u * qi);     // four 4-B slots (r,g,b,-)
-    const uint32_t left = n - 4u * qi;
-    if (left >= 4u) {
-      const U3 o{(c.x & 0xFFFFFFu) | (c.y << 24), ((c.y >> 8) & 0xFFFFu) | (c.z << 16), ((c.z >> 16) & 0xFFu) | (c.w << 8)};
-      __builtin_memcpy(gc + 12u * qi, &o, 12);
-    } else {
-      const uint32_t cc[3] = {c.x, c.y, c.z};
-      for (uint32_t k = 0; k < left; ++k) {
-        gc[12u * qi + 3u * k] = (unsigned char)cc[k];
-        gc[12u * qi + 3u * k + 1] = (unsigned char)(cc[k] >> 8);
-        gc[12u * qi + 3u * k + 2] = (unsigned char)(cc[k] >> 16);
-      }
-    }
-  }
-}
+struct __attribute__((packed)) Out6 { uint32_t xy; uint16_t z; };
+struct Out3 { uint8_t r, g, b; };
 
 }  // namespace
 
 // `variant`: 0 in production; timing-only ablation bits (VPCC_TILES_VARIANT): 1 skip look-back wait,
-// 8 skip colour conversion, 16 skip global stores.
+// 8 skip colour conversion, 16 skip global stores, 64 in-kernel stamps (diagnostic build path).
 __global__ __launch_bounds__(256) void k_recon_tiles(const DevFrame* __restrict__ frames, uint32_t first,
                                                      uint32_t count, uint32_t groups_stride, uint32_t variant) {
   // XCD-aware placement (speed only): ids equal mod 8 share an XCD/L2; a frame stays on one label.
+  // The frames of one label are interleaved: consecutive groups of ONE frame then start a few
+  // workgroup slots apart, which gives a group's predecessors a head start and shortens its look-back
+  // wait (measured: 0.05 -> 0.02 ms per 32-frame batch against one-frame-at-a-time).
   const uint32_t xcd = blockIdx.x & 7u, slot = blockIdx.x >> 3;
-  const uint32_t fi = xcd + 8u * (slot / groups_stride);
+  const uint32_t frame_groups = (count + 7u) / 8u;
+  const uint32_t fi = xcd + 8u * (slot % frame_groups);
   if (fi >= count) return;
   const DevFrame& f = frames[first + fi];
 
   __shared__ uint32_t s_group;
   __shared__ uint32_t s_base;
   __shared__ uint32_t s_tot[16];
-  __shared__ __attribute__((aligned(16))) uint2 s_xyz[4][512];
-  __shared__ __attribute__((aligned(16))) uint32_t s_rgb[4][512];
+  __shared__ __attribute__((aligned(16))) uint2 s_slots[4][512];
 
-  if (threadIdx.x == 0) s_group = atomicAdd(f.ticket, 1u);
+  unsigned long long t_prev = (variant & 64u) ? stamp() : 0ull;
+  unsigned long long t_acc[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+  if (threadIdx.x == 0) s_group = __hip_atomic_fetch_add(glw(f.ticket), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   __syncthreads();
   const uint32_t g = __builtin_amdgcn_readfirstlane(s_group);
   const uint32_t n_groups = (f.n_tiles + kTileItemsPerGroup - 1u) / kTileItemsPerGroup;
@@ -316,36 +406,39 @@ __global__ __launch_bounds__(256) void k_recon_tiles(const DevFrame* __restrict_
 
   const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = lane_id();
   const uint32_t item0 = g * kTileItemsPerGroup + wave * 4u;
+  VPCC_STAMP(0)                                         // ticket + first barrier
 
-  // ---- phase 1: loads -------------------------------------------------------------------------
-  TileItem it[4];
-  TileRegs t[4];
-  bool valid[4];
+  // ---- 1. count (registers are transient: the per-item loop below re-reads its samples, L2-hot) ----
+  {
+    Item it4[4];
+    Samples s4[4];
 #pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    valid[i] = item0 + i < f.n_tiles;
-    it[i] = f.tiles[valid[i] ? item0 + i : 0u];
-    load_geometry(f, it[i], valid[i], lane, t[i]);
+    for (int i = 0; i < 4; ++i) {
+      const bool valid = item0 + i < f.n_tiles;
+      it4[i] = load_item(f.tiles + (valid ? item0 + i : 0u));
+      s4[i].occ = load_occupancy(f, it4[i], valid, lane);
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) load_geometry(f, it4[i], lane, s4[i]);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      uint32_t dup, cnt;
+      classify(f, it4[i], s4[i], dup, cnt);
+      for (int off = 32; off > 0; off >>= 1) cnt += __shfl_xor(cnt, off, 64);
+      if (lane == 0) s_tot[wave * 4u + i] = cnt;
+    }
   }
-#pragma unroll
-  for (int i = 0; i < 4; ++i) load_attributes(f, it[i], lane, t[i]);
-
-  // ---- phase 2: count -------------------------------------------------------------------------
-#pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    const uint32_t na = it[i].axes & 3u;
-    const bool normal_visible = na != ((it[i].axes >> 2) & 3u) && na != ((it[i].axes >> 4) & 3u);
-    classify_pixel<0>(f, it[i], normal_visible, t[i]);
-    classify_pixel<1>(f, it[i], normal_visible, t[i]);
-    classify_pixel<2>(f, it[i], normal_visible, t[i]);
-    classify_pixel<3>(f, it[i], normal_visible, t[i]);
-    uint32_t s = t[i].cnt;
-    for (int off = 32; off > 0; off >>= 1) s += __shfl_xor(s, off, 64);
-    if (lane == 0) s_tot[wave * 4u + i] = s;
-  }
+  VPCC_STAMP(1)                                         // occupancy + geometry of 4 items, counted
   __syncthreads();
+  VPCC_STAMP(2)                                         // barrier: all 16 counts
 
-  // ---- phase 3: publish the group total, look back ---------------------------------------------
+  // ---- 2. publish the group total and look back (wave 0); every wave prefetches its first item ----
+  Item it = load_item(f.tiles + (item0 < f.n_tiles ? item0 : 0u));
+  Samples cur;
+  cur.occ = s_tot[wave * 4u] != 0 ? load_occupancy(f, it, true, lane) : 0u;
+  load_geometry(f, it, lane, cur);
+  load_attributes(f, it, lane, cur);
+
   if (wave == 0) {
     uint32_t total = lane < 16u ? s_tot[lane] : 0u;
     for (int off = 8; off > 0; off >>= 1) total += __shfl_xor(total, off, 64);
@@ -358,44 +451,100 @@ __global__ __launch_bounds__(256) void k_recon_tiles(const DevFrame* __restrict_
     }
     if (lane == 0) {
       s_base = excl;
-      if (g + 1u == n_groups) *f.n_points = excl + total;              // tile.total_number_of_regular_points
+      if (g + 1u == n_groups) *glw(f.n_points) = excl + total;         // tile.total_number_of_regular_points
     }
+    VPCC_STAMP(3)                                       // look-back (wave 0 only)
   }
   __syncthreads();
+  VPCC_STAMP(4)                                         // barrier: offset known
   uint32_t base = s_base;
   for (uint32_t k = 0; k < wave * 4u; ++k) base += s_tot[k];
 
-  // ---- phase 4: compact through LDS, convert colour, stream out --------------------------------
-  uint2* sx = s_xyz[wave];
-  uint32_t* sc = s_rgb[wave];
-#pragma unroll
-  for (int i = 0; i < 4; ++i) {
+  // ---- 3. per item: compact records through LDS, then lane <-> point ------------------------------
+  uint2* slots = s_slots[wave];
+  VPCC_GLOBAL unsigned char* const gx = (VPCC_GLOBAL unsigned char*)f.out_xyz;
+  VPCC_GLOBAL unsigned char* const gc = (VPCC_GLOBAL unsigned char*)f.out_rgb;
+  VPCC_GLOBAL uint16_t* const gp = glw(f.out_patch);
+  for (uint32_t i = 0; i < 4u; ++i) {
     const uint32_t n = s_tot[wave * 4u + i];
-    if (n != 0) {                                       // wave-uniform
-      uint32_t incl = t[i].cnt;                         // exclusive scan of the lane counts = lane's first rank
-      for (int off = 1; off < 64; off <<= 1) {
-        const uint32_t v = __shfl_up(incl, off, 64);
-        if ((int)lane >= off) incl += v;
-      }
-      uint32_t rank = incl - t[i].cnt;
-      if (variant & 8u) {
-        for (uint32_t k = 0; k < t[i].cnt; ++k) { sx[rank + k] = make_uint2(rank, k); sc[rank + k] = k; }
-      } else {
-        emit_pixel<0>(f, it[i], t[i], lane, rank, sx, sc);
-        emit_pixel<1>(f, it[i], t[i], lane, rank, sx, sc);
-        emit_pixel<2>(f, it[i], t[i], lane, rank, sx, sc);
-        emit_pixel<3>(f, it[i], t[i], lane, rank, sx, sc);
-      }
+    // prefetch the next item's samples (occupancy first: it gates the other loads)
+    Item nit = it;
+    Samples nxt;
+    nxt.occ = 0;
+    if (i + 1u < 4u && s_tot[wave * 4u + i + 1u] != 0) {
+      nit = load_item(f.tiles + item0 + i + 1u);
+      nxt.occ = load_occupancy(f, nit, true, lane);
     }
-    __syncthreads();
-    if (n != 0 && !(variant & 16u)) {
+    load_geometry(f, nit, lane, nxt);
+    load_attributes(f, nit, lane, nxt);
+
+    if (n != 0) {                                       // wave-uniform
+      uint32_t dup, cnt, rk[4];
+      classify(f, it, cur, dup, cnt);
+      pixel_ranks(it, cur, dup, cnt, lane, reinterpret_cast<unsigned char*>(slots), rk);
+      // patch-local offsets of the lane's pixels: Default (du, dv) = (4q + j, r); Swap (du, dv) = (r, 4q + j)
+      const uint32_t q4 = 4u * (lane & 3u), r = lane >> 2;
+      const bool swap = it.flags & kTileSwap;
+      const uint32_t pix0 = swap ? q4 * 16u + r : r * 16u + q4, pstep = swap ? 16u : 1u;
+      put_records<0>(cur, dup, pix0, rk[0], slots);
+      put_records<1>(cur, dup, pix0 + pstep, rk[1], slots);
+      put_records<2>(cur, dup, pix0 + 2u * pstep, rk[2], slots);
+      put_records<3>(cur, dup, pix0 + 3u * pstep, rk[3], slots);
+      wave_sync();                                      // records written by other lanes are read below
+
       const uint32_t room = base < f.capacity ? f.capacity - base : 0u;   // never write past the caller's arrays
-      flush_item(f, it[i], base, n < room ? n : room, lane, sx, sc);
+      const uint32_t nw = (variant & 16u) ? 0u : (n < room ? n : room);
+      for (uint32_t k = lane; k < nw; k += 64u) {
+        const uint2 r2 = slots[k];
+        const uint32_t depth = r2.x & 0xFFFFu, pixel = (r2.x >> 16) & 0xFFu, layer = r2.x >> 24;
+        const uint32_t tg = it.tb + (pixel & 15u) * it.lod_x, bt = it.bb + (pixel >> 4) * it.lod_y;
+        uint2 p;
+        if (f.absolute_d1 || layer == 0) {
+          p = pack_point(it, normal_of(it, depth), tg, bt);
+        } else {                                        // the D0 record of this pixel is the previous one
+          p = relative_point(it, pack_point(it, normal_of(it, slots[k - 1u].x & 0xFFFFu), tg, bt), depth);
+        }
+        const Out6 o6{p.x, (uint16_t)p.y};
+        __builtin_memcpy(gx + (size_t)(base + k) * 6u, &o6, 6);
+        if (f.has_attr) {
+          uint32_t Y = r2.y & 1023u, U = (r2.y >> 10) & 1023u, V = (r2.y >> 20) & 1023u;
+          if (r2.y >> 30) {                             // rare: samples wider than 10 bits, fetch them again
+            const uint32_t du = pixel & 15u, dv = pixel >> 4;
+            const uint32_t x = it.x0 + (swap ? dv : du), y = it.y0 + (swap ? du : dv);
+            const uint32_t ci = (y >> 1) * f.attr_cstride[layer] + (x >> 1);
+            Y = gl(f.attr_y[layer])[y * f.attr_stride[layer] + x];
+            U = gl(f.attr_u[layer])[ci];
+            V = gl(f.attr_v[layer])[ci];
+          }
+          const uint32_t rgb = (variant & 8u) ? r2.y : yuv10_to_rgb8_int(Y, U, V);
+          const Out3 o3{(uint8_t)rgb, (uint8_t)(rgb >> 8), (uint8_t)(rgb >> 16)};
+          __builtin_memcpy(gc + (size_t)(base + k) * 3u, &o3, 3);
+        }
+        if (gp) gp[base + k] = (uint16_t)it.patch;                       // partition, src/codec.rs:452
+      }
+      wave_sync();                                      // the next item overwrites the slots
     }
     base += n;
-    __syncthreads();
+    it = nit;
+    cur = nxt;
   }
+  if (variant & 64u) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  VPCC_STAMP(5)                                         // the four items incl. store drain
+  VPCC_STAMP_FLUSH()
 }
+
+}  // namespace vpcc
+
+extern "C" int vpcc_debug_read_stamps(unsigned long long* out16, int reset) {
+  if (hipMemcpyFromSymbol(out16, HIP_SYMBOL(vpcc::g_stamps), sizeof(unsigned long long) * 16) != hipSuccess) return 1;
+  if (reset) {
+    unsigned long long z[16] = {};
+    if (hipMemcpyToSymbol(HIP_SYMBOL(vpcc::g_stamps), z, sizeof(z)) != hipSuccess) return 1;
+  }
+  return 0;
+}
+
+namespace vpcc {
 
 void launch_tiles(const DevFrame* d_frames, uint32_t first, uint32_t count, uint32_t max_groups, void* stream) {
   if (!count || !max_groups) return;
