@@ -29,6 +29,22 @@ sys.path.insert(0, os.path.join(REPO, "tmc2-rs_amd"))
 HBM_PEAK_GBPS = 8000.0   # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6300 GB/s is the measured copy rate
 
 
+def measured_traffic(kernel, workload, frames):
+    """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes
+    (profiles/rNN/traffic.json: FETCH_SIZE x2 + WRITE_SIZE, calibrated there), or None."""
+    import glob
+    best = None
+    for path in sorted(glob.glob(os.path.join(REPO, "profiles", "r*", "traffic.json"))):
+        try:
+            d = json.load(open(path))
+        except Exception:
+            continue
+        if kernel.split("<")[0] in d.get("kernel", "") and workload in d.get("workload", "") \
+                and f"{frames} frames" in d.get("workload", ""):
+            best = d
+    return best["hbm_bytes_per_launch"] if best else None
+
+
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -125,7 +141,8 @@ def main():
         dom_ms = kernels[dom]
         achieved = alg_bytes / (dom_ms * 1e-3) / 1e9
         roofline = {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 1), "peak": HBM_PEAK_GBPS,
-                    "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBPS, 4), "traffic": None,
+                    "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBPS, 4),
+                    "traffic": measured_traffic(dom, args.workload, args.frames),
                     "algorithmic_bytes_per_launch": alg_bytes, "kernel_ms": round(dom_ms, 4),
                     "all_kernels_ms": {k: round(v, 4) for k, v in kernels.items()},
                     "pipeline_achieved": round(alg_bytes / (sum(kernels.values()) * 1e-3) / 1e9, 1)}

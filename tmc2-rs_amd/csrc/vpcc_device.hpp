@@ -50,7 +50,8 @@ struct TileItem {
 };
 static_assert(sizeof(TileItem) == 32, "TileItem is 32 B");
 constexpr uint8_t kTileSwap = 1, kTileMode1 = 2;
-constexpr uint32_t kTileItemsPerGroup = 16;   // 4 waves x 4 items: one ticket / one look-back word per group
+constexpr uint32_t kTileItemsPerWave = 4;
+constexpr uint32_t kTileItemsPerGroup = 4 * kTileItemsPerWave;   // 4 waves: one ticket / one look-back word per group
 
 // Per-frame descriptor, resident in HBM, read by every kernel.
 struct DevFrame {

@@ -147,6 +147,25 @@ __device__ __forceinline__ void lane_origin(const Item& it, uint32_t lane, uint3
   py0 = it.y0 + (lane >> 2);
 }
 
+// Item descriptor kept in LDS for the per-item loop (read back with lgkmcnt, not vmcnt).
+__device__ __forceinline__ void store_item(uint32_t* w, const Item& it) {
+  w[0] = it.x0 | (it.y0 << 16);
+  w[1] = it.patch | (it.flags << 16) | (it.axes << 24);
+  w[2] = it.tb; w[3] = it.bb; w[4] = it.d1;
+  w[5] = it.lod_x | (it.lod_y << 16);
+}
+__device__ __forceinline__ Item fetch_item(const uint32_t* w6) {
+  uint32_t w[6];
+#pragma unroll
+  for (int k = 0; k < 6; ++k) w[k] = __builtin_amdgcn_readfirstlane(w6[k]);
+  Item it;
+  it.x0 = w[0] & 0xFFFFu; it.y0 = w[0] >> 16;
+  it.patch = w[1] & 0xFFFFu; it.flags = (w[1] >> 16) & 0xFFu; it.axes = w[1] >> 24;
+  it.tb = w[2]; it.bb = w[3]; it.d1 = w[4];
+  it.lod_x = w[5] & 0xFFFFu; it.lod_y = w[5] >> 16;
+  return it;
+}
+
 // Occupancy bits of the lane's 4 pixels, through the low-resolution plane (src/codec.rs:288-301, 393).
 __device__ __forceinline__ uint32_t load_occupancy(const DevFrame& f, const Item& it, bool valid, uint32_t lane) {
   if (!valid) return 0;
@@ -361,7 +380,7 @@ __device__ __forceinline__ unsigned long long stamp() {
   return t;
 }
 #define VPCC_STAMP(slot)                                                                  \
-  if (variant & 64u) {                                                                      \
+  if constexpr (kStamps) {                                                                  \
     const unsigned long long now_ = stamp();                                                \
     t_acc[slot] = now_ - t_prev;                                                            \
     t_prev = now_;                                                                          \
@@ -375,10 +394,22 @@ __device__ __forceinline__ unsigned long long stamp() {
 struct __attribute__((packed)) Out6 { uint32_t xy; uint16_t z; };
 struct Out3 { uint8_t r, g, b; };
 
+// One point's 6 B (dword + short) / one colour's 3 B at a 32-bit byte offset from a uniform base:
+// consecutive lanes write consecutive points, so a wave covers 384 / 192 contiguous bytes.
+__device__ __forceinline__ void store_xyz(VPCC_GLOBAL unsigned char* base, uint32_t byte_off, uint2 p) {
+  const Out6 o6{p.x, (uint16_t)p.y};
+  __builtin_memcpy(base + byte_off, &o6, 6);
+}
+__device__ __forceinline__ void store_rgb(VPCC_GLOBAL unsigned char* base, uint32_t byte_off, uint32_t rgb) {
+  const Out3 o3{(uint8_t)rgb, (uint8_t)(rgb >> 8), (uint8_t)(rgb >> 16)};
+  __builtin_memcpy(base + byte_off, &o3, 3);
+}
+
 }  // namespace
 
 // `variant`: 0 in production; timing-only ablation bits (VPCC_TILES_VARIANT): 1 skip look-back wait,
 // 8 skip colour conversion, 16 skip global stores, 64 in-kernel stamps (diagnostic build path).
+template <bool kStamps>
 __global__ __launch_bounds__(256) void k_recon_tiles(const DevFrame* __restrict__ frames, uint32_t first,
                                                      uint32_t count, uint32_t groups_stride, uint32_t variant) {
   // XCD-aware placement (speed only): ids equal mod 8 share an XCD/L2; a frame stays on one label.
@@ -393,11 +424,12 @@ __global__ __launch_bounds__(256) void k_recon_tiles(const DevFrame* __restrict_
 
   __shared__ uint32_t s_group;
   __shared__ uint32_t s_base;
-  __shared__ uint32_t s_tot[16];
+  __shared__ uint32_t s_tot[kTileItemsPerGroup];
+  __shared__ uint32_t s_items[kTileItemsPerGroup][6];                   // the 16 item descriptors (scalar-loaded once)
   __shared__ __attribute__((aligned(16))) uint2 s_slots[4][512];
 
-  unsigned long long t_prev = (variant & 64u) ? stamp() : 0ull;
-  unsigned long long t_acc[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+  [[maybe_unused]] unsigned long long t_prev = kStamps ? stamp() : 0ull;
+  [[maybe_unused]] unsigned long long t_acc[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
   if (threadIdx.x == 0) s_group = __hip_atomic_fetch_add(glw(f.ticket), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   __syncthreads();
   const uint32_t g = __builtin_amdgcn_readfirstlane(s_group);
@@ -405,27 +437,34 @@ __global__ __launch_bounds__(256) void k_recon_tiles(const DevFrame* __restrict_
   if (g >= n_groups) return;                            // surplus workgroups of this frame
 
   const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = lane_id();
-  const uint32_t item0 = g * kTileItemsPerGroup + wave * 4u;
+  constexpr uint32_t K = kTileItemsPerWave;
+  const uint32_t item0 = g * kTileItemsPerGroup + wave * K;
   VPCC_STAMP(0)                                         // ticket + first barrier
 
-  // ---- 1. count (registers are transient: the per-item loop below re-reads its samples, L2-hot) ----
+  // ---- 1. count.  Geometry registers are transient (the per-item loop re-reads its samples, L2-hot);
+  // what IS kept is what the loop's loads would otherwise have to wait for: the four occupancy
+  // nibbles (one register) and the item descriptors (LDS).  On CDNA4 vmcnt retires in order and counts
+  // stores, so any dependent load inside the loop would also drain the previous item's stores.
+  uint32_t occ_all = 0;
   {
-    Item it4[4];
-    Samples s4[4];
+    Item it4[K];
+    Samples s4[K];
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
+    for (int i = 0; i < (int)K; ++i) {
       const bool valid = item0 + i < f.n_tiles;
       it4[i] = load_item(f.tiles + (valid ? item0 + i : 0u));
+      if (lane == 0) store_item(s_items[wave * K + i], it4[i]);
       s4[i].occ = load_occupancy(f, it4[i], valid, lane);
+      occ_all |= s4[i].occ << (4 * i);
     }
 #pragma unroll
-    for (int i = 0; i < 4; ++i) load_geometry(f, it4[i], lane, s4[i]);
+    for (int i = 0; i < (int)K; ++i) load_geometry(f, it4[i], lane, s4[i]);
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
+    for (int i = 0; i < (int)K; ++i) {
       uint32_t dup, cnt;
       classify(f, it4[i], s4[i], dup, cnt);
       for (int off = 32; off > 0; off >>= 1) cnt += __shfl_xor(cnt, off, 64);
-      if (lane == 0) s_tot[wave * 4u + i] = cnt;
+      if (lane == 0) s_tot[wave * K + i] = cnt;
     }
   }
   VPCC_STAMP(1)                                         // occupancy + geometry of 4 items, counted
@@ -433,15 +472,15 @@ __global__ __launch_bounds__(256) void k_recon_tiles(const DevFrame* __restrict_
   VPCC_STAMP(2)                                         // barrier: all 16 counts
 
   // ---- 2. publish the group total and look back (wave 0); every wave prefetches its first item ----
-  Item it = load_item(f.tiles + (item0 < f.n_tiles ? item0 : 0u));
+  Item it = fetch_item(s_items[wave * K]);
   Samples cur;
-  cur.occ = s_tot[wave * 4u] != 0 ? load_occupancy(f, it, true, lane) : 0u;
+  cur.occ = occ_all & 0xFu;
   load_geometry(f, it, lane, cur);
   load_attributes(f, it, lane, cur);
 
   if (wave == 0) {
-    uint32_t total = lane < 16u ? s_tot[lane] : 0u;
-    for (int off = 8; off > 0; off >>= 1) total += __shfl_xor(total, off, 64);
+    uint32_t total = lane < kTileItemsPerGroup ? s_tot[lane] : 0u;
+    for (int off = 16; off > 0; off >>= 1) total += __shfl_xor(total, off, 64);
     total = __shfl(total, 0, 64);
     if (lane == 0) st_store(f.scan_state + g, (g == 0 ? kPrefix : kAggregate) | total);
     uint32_t excl = 0;
@@ -458,22 +497,22 @@ __global__ __launch_bounds__(256) void k_recon_tiles(const DevFrame* __restrict_
   __syncthreads();
   VPCC_STAMP(4)                                         // barrier: offset known
   uint32_t base = s_base;
-  for (uint32_t k = 0; k < wave * 4u; ++k) base += s_tot[k];
+  for (uint32_t k = 0; k < wave * K; ++k) base += s_tot[k];
 
   // ---- 3. per item: compact records through LDS, then lane <-> point ------------------------------
   uint2* slots = s_slots[wave];
   VPCC_GLOBAL unsigned char* const gx = (VPCC_GLOBAL unsigned char*)f.out_xyz;
   VPCC_GLOBAL unsigned char* const gc = (VPCC_GLOBAL unsigned char*)f.out_rgb;
   VPCC_GLOBAL uint16_t* const gp = glw(f.out_patch);
-  for (uint32_t i = 0; i < 4u; ++i) {
-    const uint32_t n = s_tot[wave * 4u + i];
-    // prefetch the next item's samples (occupancy first: it gates the other loads)
+  for (uint32_t i = 0; i < K; ++i) {
+    const uint32_t n = s_tot[wave * K + i];
+    // prefetch the next item's samples; nothing here depends on an outstanding global load
     Item nit = it;
     Samples nxt;
     nxt.occ = 0;
-    if (i + 1u < 4u && s_tot[wave * 4u + i + 1u] != 0) {
-      nit = load_item(f.tiles + item0 + i + 1u);
-      nxt.occ = load_occupancy(f, nit, true, lane);
+    if (i + 1u < K) {
+      nit = fetch_item(s_items[wave * K + i + 1u]);
+      nxt.occ = (occ_all >> (4u * (i + 1u))) & 0xFu;
     }
     load_geometry(f, nit, lane, nxt);
     load_attributes(f, nit, lane, nxt);
@@ -491,6 +530,11 @@ __global__ __launch_bounds__(256) void k_recon_tiles(const DevFrame* __restrict_
       put_records<2>(cur, dup, pix0 + 2u * pstep, rk[2], slots);
       put_records<3>(cur, dup, pix0 + 3u * pstep, rk[3], slots);
       wave_sync();                                      // records written by other lanes are read below
+      // Take delivery of the prefetched samples NOW, before this item's stores are issued: waited for
+      // later, the in-order vmcnt would make that wait cover the stores as well.
+      asm volatile("" : "+v"(nxt.g0.lo), "+v"(nxt.g0.hi), "+v"(nxt.g1.lo), "+v"(nxt.g1.hi), "+v"(nxt.y0.lo),
+                   "+v"(nxt.y0.hi), "+v"(nxt.y1.lo), "+v"(nxt.y1.hi));
+      asm volatile("" : "+v"(nxt.u0), "+v"(nxt.v0), "+v"(nxt.u1), "+v"(nxt.v1));
 
       const uint32_t room = base < f.capacity ? f.capacity - base : 0u;   // never write past the caller's arrays
       const uint32_t nw = (variant & 16u) ? 0u : (n < room ? n : room);
@@ -504,8 +548,7 @@ __global__ __launch_bounds__(256) void k_recon_tiles(const DevFrame* __restrict_
         } else {                                        // the D0 record of this pixel is the previous one
           p = relative_point(it, pack_point(it, normal_of(it, slots[k - 1u].x & 0xFFFFu), tg, bt), depth);
         }
-        const Out6 o6{p.x, (uint16_t)p.y};
-        __builtin_memcpy(gx + (size_t)(base + k) * 6u, &o6, 6);
+        store_xyz(gx, (base + k) * 6u, p);
         if (f.has_attr) {
           uint32_t Y = r2.y & 1023u, U = (r2.y >> 10) & 1023u, V = (r2.y >> 20) & 1023u;
           if (r2.y >> 30) {                             // rare: samples wider than 10 bits, fetch them again
@@ -517,8 +560,7 @@ __global__ __launch_bounds__(256) void k_recon_tiles(const DevFrame* __restrict_
             V = gl(f.attr_v[layer])[ci];
           }
           const uint32_t rgb = (variant & 8u) ? r2.y : yuv10_to_rgb8_int(Y, U, V);
-          const Out3 o3{(uint8_t)rgb, (uint8_t)(rgb >> 8), (uint8_t)(rgb >> 16)};
-          __builtin_memcpy(gc + (size_t)(base + k) * 3u, &o3, 3);
+          store_rgb(gc, (base + k) * 3u, rgb);
         }
         if (gp) gp[base + k] = (uint16_t)it.patch;                       // partition, src/codec.rs:452
       }
@@ -528,7 +570,7 @@ __global__ __launch_bounds__(256) void k_recon_tiles(const DevFrame* __restrict_
     it = nit;
     cur = nxt;
   }
-  if (variant & 64u) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  if constexpr (kStamps) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   VPCC_STAMP(5)                                         // the four items incl. store drain
   VPCC_STAMP_FLUSH()
 }
@@ -554,8 +596,12 @@ void launch_tiles(const DevFrame* d_frames, uint32_t first, uint32_t count, uint
   }();
   const uint32_t frame_groups = (count + 7u) / 8u;
   const uint32_t grid = 8u * frame_groups * max_groups;
-  hipLaunchKernelGGL(k_recon_tiles, dim3(grid), dim3(256), 0, (hipStream_t)stream, d_frames, first, count, max_groups,
-                     variant);
+  if (variant & 64u)
+    hipLaunchKernelGGL(k_recon_tiles<true>, dim3(grid), dim3(256), 0, (hipStream_t)stream, d_frames, first, count,
+                       max_groups, variant);
+  else
+    hipLaunchKernelGGL(k_recon_tiles<false>, dim3(grid), dim3(256), 0, (hipStream_t)stream, d_frames, first, count,
+                       max_groups, variant);
 }
 
 }  // namespace vpcc
