@@ -222,6 +222,25 @@ int vpcc_gof_kernel_times(vpcc_gof* gof, const char** names_out, float* ms_out, 
  * written once), using the measured point count of the last reconstruct. */
 int vpcc_gof_algorithmic_bytes(vpcc_gof* gof, uint32_t frame, uint64_t* bytes_out);
 
+/* ------------------------------------------------- host mirror of the library API */
+/* C view of the C++ class tmc2rs::Decoder (tmc2-rs_amd/csrc/decoder.hpp), which mirrors the
+ * reference's public API: Decoder::new (src/lib.rs:71-78), start() (:97-138), recv_frame() (:143-145).
+ * Input: a decoded-GOF container (.vpccgof) — patch tables + decoded planes, the state after the
+ * reference's three decompress() calls.  Frames are sharded over `devices` and delivered in
+ * presentation order through a capacity-1 channel. */
+typedef struct vpcc_decoder vpcc_decoder;
+int  vpcc_decoder_open(const char* path, const int* devices, int n_devices, vpcc_decoder** out);
+/* VPCC_ERR_STATE when called twice (the reference panics: "can only be started once"). */
+int  vpcc_decoder_start(vpcc_decoder* dec);
+/* 1 and the next frame (pointers valid until the next call), or 0 at end of stream — also after a
+ * failure in the worker, like the reference's consumer sees None after a worker panic. */
+int  vpcc_decoder_recv_frame(vpcc_decoder* dec, size_t* n_points, const vpcc_point3** xyz, const vpcc_color3** rgb);
+const char* vpcc_decoder_error(vpcc_decoder* dec);
+void vpcc_decoder_close(vpcc_decoder* dec);
+
+/* writer::PlyWriter::write, ASCII (src/writer.rs:25-74); rgb may be NULL (no colour properties). */
+int  vpcc_write_ply(const char* path, const vpcc_point3* xyz, const vpcc_color3* rgb, size_t n_points);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,0 +1,43 @@
+"""The C++ Decoder mirror end to end on the GPU: container -> start() -> frames in presentation order."""
+import numpy as np
+import pytest
+
+import cases
+import oracle_binding as ob
+from tmc2rs import container, recon, synth
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("devices", [(0,), (0, 0)])     # (0, 0): two contexts -> the sharding / re-sequencing path
+def test_decoder_streams_frames_in_order(tmp_path, devices):
+    gofs = [[cases.medium_frame(i) for i in range(3)],
+            [cases.medium_frame(10 + i, occupancy_values="random") for i in range(2)] + [synth.small_frame(0)]]
+    path = tmp_path / "s.vpccgof"
+    container.write_container(path, gofs)
+    d = recon.Decoder(path, devices=devices)
+    d.start()
+    frames = list(d)
+    assert d.error() == ""
+    expected = [f for g in gofs for f in g]
+    assert len(frames) == len(expected)
+    for got, f in zip(frames, expected):
+        st, ref = ob.reconstruct(f)
+        assert st == 0 and got["n"] == ref["n"]
+        assert np.array_equal(got["xyz"], ob.xyz_array(ref)) and np.array_equal(got["rgb"], ob.rgb_array(ref))
+    assert d.recv_frame() is None                       # None forever after the last frame
+    d.close()
+
+
+def test_decoder_error_ends_stream_early(tmp_path):
+    bad = cases.medium_frame(0)
+    bad["patches"] = bad["patches"].copy()
+    bad["patches"]["u0"][0] = 10_000                    # patch outside the canvas: assert in the reference
+    path = tmp_path / "bad.vpccgof"
+    container.write_container(path, [[cases.medium_frame(1)], [bad]])
+    d = recon.Decoder(path)
+    d.start()
+    frames = list(d)
+    assert len(frames) == 1                             # first GOF delivered, then the stream just ends
+    assert "canvas" in d.error()
+    d.close()

@@ -1,0 +1,99 @@
+"""Host logic that needs no GPU: the C++ Decoder mirror's API contract, the PLY writer, the container,
+and the multi-GPU bookkeeping over gloo (world size 2)."""
+import os
+
+import numpy as np
+import pytest
+
+import cases
+from tmc2rs import _abi, container, recon, sharding
+
+
+def _have_gpu():
+    import torch
+    return torch.cuda.device_count() > 0
+
+
+def test_ply_writer_matches_reference_format(tmp_path):
+    # src/writer.rs:32-74: header lines and "x y z r g b" body, ASCII
+    xyz = np.array([[1, 2, 3], [65535, 0, 7]], np.uint16)
+    rgb = np.array([[255, 0, 9], [1, 2, 3]], np.uint8)
+    p = tmp_path / "0000.ply"
+    recon.write_ply(p, xyz, rgb)
+    expected = ("ply\nformat ascii 1.0\nelement vertex 2\nproperty uint x\nproperty uint y\nproperty uint z\n"
+                "property uchar red\nproperty uchar green\nproperty uchar blue\nelement face 0\n"
+                "property list uint8 int32 vertex_index\nend_header\n1 2 3 255 0 9\n65535 0 7 1 2 3\n")
+    assert p.read_text() == expected
+    recon.write_ply(p, xyz, None)       # with_colors == false: no colour properties, no colour columns
+    assert p.read_text() == ("ply\nformat ascii 1.0\nelement vertex 2\nproperty uint x\nproperty uint y\nproperty uint z\n"
+                             "element face 0\nproperty list uint8 int32 vertex_index\nend_header\n1 2 3\n65535 0 7\n")
+
+
+def test_decoder_api_contract_without_gpu(tmp_path):
+    path = tmp_path / "a.vpccgof"
+    container.write_container(path, [[cases.medium_frame(0)]])
+    d = recon.Decoder(path)
+    d.start()
+    with pytest.raises(recon.VpccError) as e:      # the reference panics: "can only be started once"
+        d.start()
+    assert e.value.status == _abi.VPCC_ERR_STATE
+    if not _have_gpu():
+        # no GPU: the worker fails, and — like a worker panic in the reference — the consumer just sees
+        # the end of the stream; the product never falls back to a CPU path
+        assert d.recv_frame() is None and d.recv_frame() is None
+        assert "gfx950" in d.error()
+    d.close()
+
+
+def test_decoder_rejects_garbage(tmp_path):
+    p = tmp_path / "bad.vpccgof"
+    p.write_bytes(b"not a container at all")
+    d = recon.Decoder(p)
+    with pytest.raises(recon.VpccError):
+        d.start()
+    d.close()
+    d = recon.Decoder(tmp_path / "missing.vpccgof")
+    with pytest.raises(recon.VpccError):           # the reference unwraps the io error on the caller's thread
+        d.start()
+    d.close()
+
+
+def test_frame_dealing():
+    assert sharding.frames_of_rank(10, 0, 4) == [0, 4, 8]
+    assert sharding.frames_of_rank(10, 3, 4) == [3, 7]
+    seen = sorted(f for r in range(3) for f in sharding.frames_of_rank(32, r, 3))
+    assert seen == list(range(32))
+    for f in range(32):
+        r, i = sharding.owner_of_frame(f, 3)
+        assert sharding.frames_of_rank(32, r, 3)[i] == f
+
+
+def _gloo_worker(rank, world, port, n_frames, q):
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    mine = sharding.frames_of_rank(n_frames, rank, world)
+    local_counts = [1000 * f + 7 for f in mine]             # stand-in for the per-frame point counts of this rank
+    counts = sharding.presentation_order_counts(dist, local_counts, n_frames)
+    elapsed, points = sharding.job_totals(dist, 0.5 + rank, sum(local_counts))
+    q.put((rank, counts, elapsed, points))
+    dist.destroy_process_group()
+
+
+def test_multi_rank_bookkeeping_over_gloo():
+    import torch.multiprocessing as mp
+    world, n_frames = 2, 7
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 29500 + (os.getpid() % 2000)
+    procs = [ctx.Process(target=_gloo_worker, args=(r, world, port, n_frames, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=120) for _ in range(world)]
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    for rank, counts, elapsed, points in res:
+        assert counts == [1000 * f + 7 for f in range(n_frames)]       # presentation order on every rank
+        assert elapsed == 1.5                                           # MAX over ranks
+        assert points == sum(1000 * f + 7 for f in range(n_frames))    # SUM over ranks

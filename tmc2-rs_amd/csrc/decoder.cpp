@@ -1,0 +1,263 @@
+// decoder.cpp — C++ host mirror of src/lib.rs + the per-GOF driver of src/decoder.rs:188-314, running the
+// reconstruction on one or several MI355X through the C ABI (include/vpcc_recon.h).
+#include "decoder.hpp"
+
+#include <cstdio>
+#include <cstring>
+#include <fstream>
+#include <memory>
+#include <sstream>
+#include <stdexcept>
+
+namespace tmc2rs {
+
+// ------------------------------------------------------------------ container (.vpccgof)
+//   header : "VPCCGOF1" | u32 version (1) | u32 gof_count
+//   gof    : u32 frame_count | frame*
+//   frame  : 16 x u32 { width, height, occupancy_resolution, occupancy_precision, map_count, absolute_d1,
+//                       attribute_count, flags, occ_w, occ_h, geo_w, geo_h, attr_w, attr_h, patch_count, 0 }
+//            vpcc_patch[patch_count] | occupancy u8[occ_w*occ_h] | geometry Y u16[geo_w*geo_h] x map_count
+//            | (Y u16[attr_w*attr_h], U, V u16[(attr_w/2)*((attr_h+1)/2)]) x map_count   (if attribute_count)
+//   every section is padded to a multiple of 8 bytes.
+namespace {
+struct Cursor {
+  const unsigned char* p;
+  size_t left;
+  bool take(size_t n, const unsigned char** out) {
+    const size_t padded = (n + 7) & ~size_t(7);
+    if (padded > left) return false;
+    *out = p;
+    p += padded;
+    left -= padded;
+    return true;
+  }
+};
+}  // namespace
+
+bool parse_container(const std::vector<unsigned char>& buf, std::vector<DecodedGof>* gofs, std::string* err) {
+  Cursor c{buf.data(), buf.size()};
+  const unsigned char* h;
+  if (!c.take(16, &h) || std::memcmp(h, "VPCCGOF1", 8) != 0) { *err = "not a .vpccgof container"; return false; }
+  uint32_t version, gof_count;
+  std::memcpy(&version, h + 8, 4);
+  std::memcpy(&gof_count, h + 12, 4);
+  if (version != 1) { *err = "unsupported container version"; return false; }
+  gofs->clear();
+  for (uint32_t g = 0; g < gof_count; ++g) {
+    const unsigned char* q;
+    if (!c.take(8, &q)) { *err = "truncated container"; return false; }
+    uint32_t frame_count;
+    std::memcpy(&frame_count, q, 4);
+    DecodedGof gof;
+    for (uint32_t f = 0; f < frame_count; ++f) {
+      if (!c.take(64, &q)) { *err = "truncated container"; return false; }
+      uint32_t w[16];
+      std::memcpy(w, q, 64);
+      vpcc_frame_desc d{};
+      d.width = w[0]; d.height = w[1]; d.occupancy_resolution = w[2]; d.occupancy_precision = w[3];
+      d.map_count = w[4]; d.absolute_d1 = w[5]; d.attribute_count = w[6]; d.flags = w[7];
+      const uint32_t occ_w = w[8], occ_h = w[9], geo_w = w[10], geo_h = w[11], attr_w = w[12], attr_h = w[13];
+      d.patch_count = w[14];
+      if (d.map_count < 1 || d.map_count > 2) { *err = "map_count out of range"; return false; }
+      if (!c.take(sizeof(vpcc_patch) * (size_t)d.patch_count, &q)) { *err = "truncated container"; return false; }
+      d.patches = d.patch_count ? reinterpret_cast<const vpcc_patch*>(q) : nullptr;
+      if (!c.take((size_t)occ_w * occ_h, &q)) { *err = "truncated container"; return false; }
+      d.occupancy = vpcc_image_u8{q, occ_w, occ_h, occ_w};
+      for (uint32_t m = 0; m < d.map_count; ++m) {
+        if (!c.take((size_t)geo_w * geo_h * 2, &q)) { *err = "truncated container"; return false; }
+        d.geometry[m] = vpcc_image_u16{reinterpret_cast<const uint16_t*>(q), nullptr, nullptr, geo_w, geo_h, geo_w, geo_w / 2};
+      }
+      if (d.attribute_count) {
+        const size_t cw = attr_w / 2, ch = (attr_h + 1) / 2;
+        for (uint32_t m = 0; m < d.map_count; ++m) {
+          const unsigned char *y, *u, *v;
+          if (!c.take((size_t)attr_w * attr_h * 2, &y) || !c.take(cw * ch * 2, &u) || !c.take(cw * ch * 2, &v)) {
+            *err = "truncated container";
+            return false;
+          }
+          d.attribute[m] = vpcc_image_u16{reinterpret_cast<const uint16_t*>(y), reinterpret_cast<const uint16_t*>(u),
+                                          reinterpret_cast<const uint16_t*>(v), attr_w, attr_h, attr_w, (uint32_t)cw};
+        }
+      }
+      gof.frames.push_back(d);
+    }
+    gofs->push_back(std::move(gof));
+  }
+  return true;
+}
+
+// ------------------------------------------------------------------ Decoder
+Decoder::Decoder(Params params) : params_(std::move(params)) {}
+
+Decoder::~Decoder() {
+  chan_.drop_rx();                            // receiver dropped: the worker's next send fails and it stops
+  if (thread_.joinable()) thread_.join();
+}
+
+void Decoder::start() {
+  if (started_) throw std::logic_error("library decoder can only be started once");   // src/lib.rs:108-111
+  started_ = true;
+  // Bitstream::from_file on the caller's thread (src/lib.rs:98); the reference unwraps the io error
+  std::ifstream in(params_.compressed_stream_path, std::ios::binary | std::ios::ate);
+  if (!in) throw std::runtime_error("cannot open " + params_.compressed_stream_path);
+  file_.resize((size_t)in.tellg());
+  in.seekg(0);
+  in.read(reinterpret_cast<char*>(file_.data()), (std::streamsize)file_.size());
+  std::string err;
+  if (!parse_container(file_, &gofs_, &err)) throw std::runtime_error(err);
+  thread_ = std::thread([this] { worker(); });
+}
+
+std::optional<PointSet3> Decoder::recv_frame() { return chan_.recv(); }
+
+namespace {
+struct CtxDeleter { void operator()(vpcc_ctx* c) const { vpcc_ctx_destroy(c); } };
+struct GofDeleter { void operator()(vpcc_gof* g) const { vpcc_gof_destroy(g); } };
+}  // namespace
+
+void Decoder::worker() {
+  // one context per GPU; frames of a GOF are dealt round-robin (frame f -> device f % G) and delivered in
+  // presentation order — they are independent (src/decoder.rs:186), so no data moves between GPUs.
+  const size_t G = params_.devices.empty() ? 1 : params_.devices.size();
+  std::vector<std::unique_ptr<vpcc_ctx, CtxDeleter>> ctxs(G);
+  for (size_t d = 0; d < G; ++d) {
+    vpcc_ctx* c = nullptr;
+    const int st = vpcc_ctx_create(params_.devices.empty() ? 0 : params_.devices[d], &c);
+    if (st) { error_ = std::string("vpcc_ctx_create: ") + vpcc_status_string(st); chan_.close_tx(); return; }
+    ctxs[d].reset(c);
+  }
+  for (const DecodedGof& gof : gofs_) {       // while ssvu.get_v3c_unit_count() > 0, src/lib.rs:118
+    const size_t n = gof.frames.size();
+    std::vector<std::vector<vpcc_frame_desc>> part(G);
+    for (size_t f = 0; f < n; ++f) part[f % G].push_back(gof.frames[f]);
+    std::vector<std::unique_ptr<vpcc_gof, GofDeleter>> dg(G);
+    for (size_t d = 0; d < G; ++d) {
+      if (part[d].empty()) continue;
+      vpcc_gof* g = nullptr;
+      int st = vpcc_gof_create(ctxs[d].get(), part[d].data(), (uint32_t)part[d].size(), VPCC_MEM_HOST, 0, 0, &g);
+      if (st == VPCC_OK) {
+        dg[d].reset(g);
+        st = vpcc_gof_reconstruct(g, 0, (uint32_t)part[d].size(), nullptr);     // asynchronous: all GPUs run concurrently
+      }
+      if (st) {
+        error_ = std::string(vpcc_status_string(st)) + ": " + vpcc_last_error(ctxs[d].get());
+        chan_.close_tx();                     // reference: panic in the worker -> consumer sees end-of-stream
+        return;
+      }
+    }
+    std::vector<std::vector<uint32_t>> counts(G);
+    for (size_t d = 0; d < G; ++d) {
+      if (!dg[d]) continue;
+      counts[d].resize(part[d].size());
+      const int st = vpcc_gof_point_counts(dg[d].get(), counts[d].data());
+      if (st) { error_ = vpcc_last_error(ctxs[d].get()); chan_.close_tx(); return; }
+    }
+    for (size_t f = 0; f < n; ++f) {          // presentation order, src/decoder.rs:188
+      const size_t d = f % G, local = f / G;
+      PointSet3 ps;
+      ps.with_colors = gof.frames[f].attribute_count > 0;
+      const size_t np = counts[d][local];
+      ps.positions.resize(np);
+      if (ps.with_colors) ps.colors.resize(np);
+      size_t got = 0;
+      const int st = vpcc_gof_download(dg[d].get(), (uint32_t)local, ps.positions.data(),
+                                       ps.with_colors ? ps.colors.data() : nullptr, nullptr, np ? np : 1, &got);
+      if (st || got != np) { error_ = vpcc_last_error(ctxs[d].get()); chan_.close_tx(); return; }
+      if (!chan_.send(std::move(ps))) { chan_.close_tx(); return; }            // receiver dropped, src/decoder.rs:311-313
+    }
+  }
+  chan_.close_tx();                           // drop(tx), src/lib.rs:136
+}
+
+// ------------------------------------------------------------------ PlyWriter (src/writer.rs:25-74)
+std::string PlyWriter::to_string() const {
+  std::string s;
+  s.reserve(64 + pc_.len() * 24);
+  s += "ply\n";
+  s += "format ascii 1.0\n";
+  s += "element vertex " + std::to_string(pc_.len()) + "\n";
+  s += "property uint x\nproperty uint y\nproperty uint z\n";
+  if (pc_.with_colors) s += "property uchar red\nproperty uchar green\nproperty uchar blue\n";
+  s += "element face 0\n";
+  s += "property list uint8 int32 vertex_index\n";
+  s += "end_header\n";
+  char line[64];
+  for (size_t i = 0; i < pc_.len(); ++i) {
+    const vpcc_point3& p = pc_.positions[i];
+    int n = std::snprintf(line, sizeof line, "%u %u %u", (unsigned)p.x, (unsigned)p.y, (unsigned)p.z);
+    if (pc_.with_colors) {
+      const vpcc_color3& c = pc_.colors[i];
+      n += std::snprintf(line + n, sizeof line - n, " %u %u %u", (unsigned)c.r, (unsigned)c.g, (unsigned)c.b);
+    }
+    line[n++] = '\n';
+    s.append(line, (size_t)n);
+  }
+  return s;
+}
+
+bool PlyWriter::write(const std::string& path) const {
+  std::ofstream out(path, std::ios::binary);
+  if (!out) return false;
+  const std::string s = to_string();
+  out.write(s.data(), (std::streamsize)s.size());
+  return (bool)out;
+}
+
+}  // namespace tmc2rs
+
+// ------------------------------------------------------------------ C ABI of the host mirror
+struct vpcc_decoder {
+  tmc2rs::Decoder dec;
+  std::optional<tmc2rs::PointSet3> cur;
+  std::string err;
+  explicit vpcc_decoder(tmc2rs::Params p) : dec(std::move(p)) {}
+};
+
+extern "C" int vpcc_decoder_open(const char* path, const int* devices, int n_devices, vpcc_decoder** out) {
+  if (!path || !out) return VPCC_ERR_INVALID_ARG;
+  tmc2rs::Params p{std::string(path)};
+  if (devices && n_devices > 0) p.devices.assign(devices, devices + n_devices);
+  *out = new vpcc_decoder(std::move(p));
+  return VPCC_OK;
+}
+
+extern "C" int vpcc_decoder_start(vpcc_decoder* d) {
+  if (!d) return VPCC_ERR_INVALID_ARG;
+  try {
+    d->dec.start();
+  } catch (const std::logic_error& e) {
+    d->err = e.what();
+    return VPCC_ERR_STATE;
+  } catch (const std::exception& e) {
+    d->err = e.what();
+    return VPCC_ERR_INVALID_ARG;
+  }
+  return VPCC_OK;
+}
+
+extern "C" int vpcc_decoder_recv_frame(vpcc_decoder* d, size_t* n_points, const vpcc_point3** xyz,
+                                       const vpcc_color3** rgb) {
+  if (!d || !n_points) return 0;
+  d->cur = d->dec.recv_frame();
+  if (!d->cur) return 0;                      // None: end of stream (or the worker failed: vpcc_decoder_error)
+  *n_points = d->cur->len();
+  if (xyz) *xyz = d->cur->positions.data();
+  if (rgb) *rgb = d->cur->with_colors ? d->cur->colors.data() : nullptr;
+  return 1;
+}
+
+extern "C" const char* vpcc_decoder_error(vpcc_decoder* d) {
+  if (!d) return "";
+  return d->dec.last_error().empty() ? d->err.c_str() : d->dec.last_error().c_str();   // the worker's error wins
+}
+
+extern "C" void vpcc_decoder_close(vpcc_decoder* d) { delete d; }
+
+extern "C" int vpcc_write_ply(const char* path, const vpcc_point3* xyz, const vpcc_color3* rgb, size_t n) {
+  if (!path || (n && !xyz)) return VPCC_ERR_INVALID_ARG;
+  tmc2rs::PointSet3 ps;
+  ps.positions.assign(xyz, xyz + n);
+  ps.with_colors = rgb != nullptr;
+  if (rgb) ps.colors.assign(rgb, rgb + n);
+  return tmc2rs::PlyWriter(ps, tmc2rs::Format::Ascii).write(path) ? VPCC_OK : VPCC_ERR_INVALID_ARG;
+}

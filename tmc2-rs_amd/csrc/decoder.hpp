@@ -1,0 +1,127 @@
+// decoder.hpp — C++ host mirror of the reference's public library API (src/lib.rs:15-154):
+//   Params, Decoder::new / start() / recv_frame() / Iterator<Item = PointSet3>, and writer::PlyWriter
+//   (src/writer.rs:8-74).  Same names, argument meaning and observable behaviour:
+//   * start() reads the input on the CALLER's thread, then spawns ONE worker thread; calling it twice
+//     throws (the reference panics: "library decoder can only be started once", src/lib.rs:108-111);
+//   * frames arrive in presentation order through a capacity-1 channel (crossbeam bounded(1), src/lib.rs:72):
+//     the producer is at most one frame ahead of the consumer;
+//   * any failure in the worker ends the stream early — recv_frame() returns nullopt from then on, as the
+//     reference's consumer sees None after a worker panic (src/lib.rs:113-145).
+// The reconstruction itself is the GPU path behind include/vpcc_recon.h.  Input is a decoded-GOF
+// container (.vpccgof: patch tables + decoded planes, i.e. the state after the reference's three
+// decompress() calls, src/decoder.rs:82-171); V3C parsing and HEVC decoding are out of scope here.
+#pragma once
+
+#include <condition_variable>
+#include <deque>
+#include <mutex>
+#include <optional>
+#include <string>
+#include <thread>
+#include <vector>
+
+#include "vpcc_recon.h"
+
+namespace tmc2rs {
+
+struct Params {                       // src/lib.rs:23-57
+  std::string compressed_stream_path;
+  std::vector<int> devices{0};        // GPUs to shard frames over (extension; the reference is single-threaded)
+  bool keep_intermediate_files = false;
+  explicit Params(std::string path = {}) : compressed_stream_path(std::move(path)) {}
+};
+
+struct PointSet3 {                    // src/codec.rs:20-36 (public part)
+  std::vector<vpcc_point3> positions;
+  std::vector<vpcc_color3> colors;
+  bool with_colors = false;
+  size_t len() const { return positions.size(); }
+};
+
+// Capacity-bounded single-producer/single-consumer channel with close(), like crossbeam bounded(n).
+template <class T>
+class BoundedChannel {
+ public:
+  explicit BoundedChannel(size_t cap) : cap_(cap) {}
+  bool send(T v) {                    // false when the receiver is gone
+    std::unique_lock<std::mutex> lk(m_);
+    cv_.wait(lk, [&] { return q_.size() < cap_ || rx_dropped_; });
+    if (rx_dropped_) return false;
+    q_.push_back(std::move(v));
+    cv_.notify_all();
+    return true;
+  }
+  std::optional<T> recv() {           // nullopt once the sender is closed and the queue is drained
+    std::unique_lock<std::mutex> lk(m_);
+    cv_.wait(lk, [&] { return !q_.empty() || tx_closed_; });
+    if (q_.empty()) return std::nullopt;
+    T v = std::move(q_.front());
+    q_.pop_front();
+    cv_.notify_all();
+    return v;
+  }
+  void close_tx() { std::lock_guard<std::mutex> lk(m_); tx_closed_ = true; cv_.notify_all(); }
+  void drop_rx() { std::lock_guard<std::mutex> lk(m_); rx_dropped_ = true; cv_.notify_all(); }
+
+ private:
+  size_t cap_;
+  std::mutex m_;
+  std::condition_variable cv_;
+  std::deque<T> q_;
+  bool tx_closed_ = false, rx_dropped_ = false;
+};
+
+// One decoded GOF: frame descriptors pointing into the container buffer.
+struct DecodedGof {
+  std::vector<vpcc_frame_desc> frames;
+};
+
+// Parses a .vpccgof container held in `buf` (kept alive by the caller).  Returns false + message on error.
+bool parse_container(const std::vector<unsigned char>& buf, std::vector<DecodedGof>* gofs, std::string* err);
+
+class Decoder {
+ public:
+  explicit Decoder(Params params);
+  ~Decoder();
+  Decoder(const Decoder&) = delete;
+  Decoder& operator=(const Decoder&) = delete;
+
+  void start();                               // src/lib.rs:97-138
+  std::optional<PointSet3> recv_frame();      // src/lib.rs:143-145
+  const std::string& last_error() const { return error_; }   // extension: why the stream ended early
+
+  struct iterator {                           // impl Iterator for Decoder, src/lib.rs:148-154
+    Decoder* d;
+    std::optional<PointSet3> cur;
+    PointSet3& operator*() { return *cur; }
+    iterator& operator++() { cur = d->recv_frame(); return *this; }
+    bool operator!=(const iterator&) const { return cur.has_value(); }
+  };
+  iterator begin() { iterator it{this, std::nullopt}; ++it; return it; }
+  iterator end() { return iterator{this, std::nullopt}; }
+
+ private:
+  void worker();
+  Params params_;
+  BoundedChannel<PointSet3> chan_{1};
+  std::vector<unsigned char> file_;
+  std::vector<DecodedGof> gofs_;
+  std::thread thread_;
+  bool started_ = false;
+  std::string error_;
+};
+
+enum class Format { Ascii };                  // src/writer.rs:8-12
+
+class PlyWriter {                             // src/writer.rs:14-74
+ public:
+  PlyWriter(const PointSet3& pc, Format format) : pc_(pc), format_(format) {}
+  bool write(const std::string& path) const;
+  std::string to_string() const;
+
+ private:
+  const PointSet3& pc_;
+  Format format_;
+};
+
+}  // namespace tmc2rs

@@ -183,5 +183,13 @@ def load_library():
     lib.vpcc_gof_frame_status.argtypes = [vp, u32]
     lib.vpcc_gof_kernel_times.argtypes = [vp, C.POINTER(C.c_char_p), C.POINTER(C.c_float), C.c_int]
     lib.vpcc_gof_algorithmic_bytes.argtypes = [vp, u32, C.POINTER(u64)]
+    lib.vpcc_decoder_open.argtypes = [C.c_char_p, C.POINTER(C.c_int), C.c_int, C.POINTER(vp)]
+    lib.vpcc_decoder_start.argtypes = [vp]
+    lib.vpcc_decoder_recv_frame.argtypes = [vp, C.POINTER(sz), C.POINTER(vp), C.POINTER(vp)]
+    lib.vpcc_decoder_error.argtypes = [vp]
+    lib.vpcc_decoder_error.restype = C.c_char_p
+    lib.vpcc_decoder_close.argtypes = [vp]
+    lib.vpcc_decoder_close.restype = None
+    lib.vpcc_write_ply.argtypes = [C.c_char_p, vp, vp, sz]
     _lib = lib
     return lib

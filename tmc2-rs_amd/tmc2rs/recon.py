@@ -176,3 +176,67 @@ class Gof:
         b = C.c_uint64(0)
         self.ctx._check(self.lib.vpcc_gof_algorithmic_bytes(self.h, frame, C.byref(b)), "vpcc_gof_algorithmic_bytes")
         return b.value
+
+
+class Decoder:
+    """Binding of the C++ tmc2rs::Decoder (mirror of the reference's Decoder::new / start / recv_frame /
+    Iterator, src/lib.rs:70-154).  Iterating yields dicts {n, xyz, rgb} in presentation order."""
+
+    def __init__(self, path, devices=(0,)):
+        self.lib = _abi.load_library()
+        self.h = C.c_void_p()
+        dev = (C.c_int * len(devices))(*devices)
+        st = self.lib.vpcc_decoder_open(str(path).encode(), dev, len(devices), C.byref(self.h))
+        if st:
+            raise VpccError(st, "vpcc_decoder_open")
+
+    def start(self):
+        st = self.lib.vpcc_decoder_start(self.h)
+        if st:
+            raise VpccError(st, "vpcc_decoder_start", self.error())
+
+    def error(self):
+        return self.lib.vpcc_decoder_error(self.h).decode()
+
+    def recv_frame(self):
+        n, px, pc = C.c_size_t(0), C.c_void_p(), C.c_void_p()
+        if not self.lib.vpcc_decoder_recv_frame(self.h, C.byref(n), C.byref(px), C.byref(pc)):
+            return None
+        k = n.value
+        xyz = np.zeros((k, 3), np.uint16)
+        rgb = np.zeros((k, 3), np.uint8)
+        if k:
+            C.memmove(xyz.ctypes.data, px.value, k * 6)
+            if pc.value:
+                C.memmove(rgb.ctypes.data, pc.value, k * 3)
+        return {"n": k, "xyz": xyz, "rgb": rgb if pc.value else None}
+
+    def __iter__(self):
+        return self
+
+    def __next__(self):
+        f = self.recv_frame()
+        if f is None:
+            raise StopIteration
+        return f
+
+    def close(self):
+        if self.h:
+            self.lib.vpcc_decoder_close(self.h)
+            self.h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+def write_ply(path, xyz, rgb=None):
+    """writer::PlyWriter (ASCII), through the C++ mirror."""
+    lib = _abi.load_library()
+    x = np.ascontiguousarray(xyz, dtype=np.uint16)
+    c = np.ascontiguousarray(rgb, dtype=np.uint8) if rgb is not None else None
+    st = lib.vpcc_write_ply(str(path).encode(), x.ctypes.data, c.ctypes.data if c is not None else None, len(x))
+    if st:
+        raise VpccError(st, "vpcc_write_ply")
