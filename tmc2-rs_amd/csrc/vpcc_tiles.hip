@@ -400,6 +400,16 @@ __device__ __forceinline__ void store_xyz(VPCC_GLOBAL unsigned char* base, uint3
   const Out6 o6{p.x, (uint16_t)p.y};
   __builtin_memcpy(base + byte_off, &o6, 6);
 }
+struct Out12 { uint32_t a, b, c; };
+struct __attribute__((packed)) Out6c { uint32_t a; uint16_t b; };
+__device__ __forceinline__ void store_xyz2(VPCC_GLOBAL unsigned char* base, uint32_t byte_off, uint2 p, uint2 q) {
+  const Out12 o{p.x, (p.y & 0xFFFFu) | (q.x << 16), (q.x >> 16) | (q.y << 16)};
+  __builtin_memcpy(base + byte_off, &o, 12);            // one unaligned dwordx3
+}
+__device__ __forceinline__ void store_rgb2(VPCC_GLOBAL unsigned char* base, uint32_t byte_off, uint32_t c0, uint32_t c1) {
+  const Out6c o{(c0 & 0xFFFFFFu) | (c1 << 24), (uint16_t)(c1 >> 8)};
+  __builtin_memcpy(base + byte_off, &o, 6);
+}
 __device__ __forceinline__ void store_rgb(VPCC_GLOBAL unsigned char* base, uint32_t byte_off, uint32_t rgb) {
   const Out3 o3{(uint8_t)rgb, (uint8_t)(rgb >> 8), (uint8_t)(rgb >> 16)};
   __builtin_memcpy(base + byte_off, &o3, 3);
@@ -463,6 +473,7 @@ __global__ __launch_bounds__(256) void k_recon_tiles(const DevFrame* __restrict_
     for (int i = 0; i < (int)K; ++i) {
       uint32_t dup, cnt;
       classify(f, it4[i], s4[i], dup, cnt);
+      occ_all |= (dup & s4[i].occ) << (16 + 4 * i);     // the per-item loop reuses the duplicate mask
       for (int off = 32; off > 0; off >>= 1) cnt += __shfl_xor(cnt, off, 64);
       if (lane == 0) s_tot[wave * K + i] = cnt;
     }
@@ -518,8 +529,9 @@ __global__ __launch_bounds__(256) void k_recon_tiles(const DevFrame* __restrict_
     load_attributes(f, nit, lane, nxt);
 
     if (n != 0) {                                       // wave-uniform
-      uint32_t dup, cnt, rk[4];
-      classify(f, it, cur, dup, cnt);
+      uint32_t rk[4];
+      const uint32_t dup = (occ_all >> (16u + 4u * i)) & 0xFu;          // from the count phase
+      const uint32_t cnt = 2u * (uint32_t)__builtin_popcount(cur.occ) - (uint32_t)__builtin_popcount(dup);
       pixel_ranks(it, cur, dup, cnt, lane, reinterpret_cast<unsigned char*>(slots), rk);
       // patch-local offsets of the lane's pixels: Default (du, dv) = (4q + j, r); Swap (du, dv) = (r, 4q + j)
       const uint32_t q4 = 4u * (lane & 3u), r = lane >> 2;
@@ -538,31 +550,49 @@ __global__ __launch_bounds__(256) void k_recon_tiles(const DevFrame* __restrict_
 
       const uint32_t room = base < f.capacity ? f.capacity - base : 0u;   // never write past the caller's arrays
       const uint32_t nw = (variant & 16u) ? 0u : (n < room ? n : room);
-      for (uint32_t k = lane; k < nw; k += 64u) {
-        const uint2 r2 = slots[k];
-        const uint32_t depth = r2.x & 0xFFFFu, pixel = (r2.x >> 16) & 0xFFu, layer = r2.x >> 24;
-        const uint32_t tg = it.tb + (pixel & 15u) * it.lod_x, bt = it.bb + (pixel >> 4) * it.lod_y;
-        uint2 p;
-        if (f.absolute_d1 || layer == 0) {
-          p = pack_point(it, normal_of(it, depth), tg, bt);
-        } else {                                        // the D0 record of this pixel is the previous one
-          p = relative_point(it, pack_point(it, normal_of(it, slots[k - 1u].x & 0xFFFFu), tg, bt), depth);
-        }
-        store_xyz(gx, (base + k) * 6u, p);
-        if (f.has_attr) {
-          uint32_t Y = r2.y & 1023u, U = (r2.y >> 10) & 1023u, V = (r2.y >> 20) & 1023u;
-          if (r2.y >> 30) {                             // rare: samples wider than 10 bits, fetch them again
-            const uint32_t du = pixel & 15u, dv = pixel >> 4;
-            const uint32_t x = it.x0 + (swap ? dv : du), y = it.y0 + (swap ? du : dv);
-            const uint32_t ci = (y >> 1) * f.attr_cstride[layer] + (x >> 1);
-            Y = gl(f.attr_y[layer])[y * f.attr_stride[layer] + x];
-            U = gl(f.attr_u[layer])[ci];
-            V = gl(f.attr_v[layer])[ci];
+      // Two consecutive points per lane: one 16-B record read, one 12-B xyz store and one 6-B rgb store
+      // per lane and step — half the loop trips and less than half the store instructions of a
+      // point-per-lane loop (the CU issues a vector-memory instruction only every few cycles).
+      for (uint32_t k = 2u * lane; k < nw; k += 128u) {
+        const uint4 rr = *reinterpret_cast<const uint4*>(slots + k);       // records k and k+1
+        const bool two = k + 1u < nw;
+        uint2 p[2];
+        uint32_t rgb[2];
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+          // an odd tail has no second record: reuse the first (never a stale slot — its fields index planes)
+          const uint32_t rx = (h && two) ? rr.z : rr.x, ry = (h && two) ? rr.w : rr.y;
+          const uint32_t depth = rx & 0xFFFFu, pixel = (rx >> 16) & 0xFFu, layer = rx >> 24;
+          const uint32_t tg = it.tb + (pixel & 15u) * it.lod_x, bt = it.bb + (pixel >> 4) * it.lod_y;
+          if (f.absolute_d1 || layer == 0) {
+            p[h] = pack_point(it, normal_of(it, depth), tg, bt);
+          } else {                                      // relative D1: the D0 record of this pixel precedes it
+            const uint32_t d0 = h ? (rr.x & 0xFFFFu) : (slots[k - 1u].x & 0xFFFFu);
+            p[h] = relative_point(it, pack_point(it, normal_of(it, d0), tg, bt), depth);
           }
-          const uint32_t rgb = (variant & 8u) ? r2.y : yuv10_to_rgb8_int(Y, U, V);
-          store_rgb(gc, (base + k) * 3u, rgb);
+          rgb[h] = 0;
+          if (f.has_attr) {
+            uint32_t Y = ry & 1023u, U = (ry >> 10) & 1023u, V = (ry >> 20) & 1023u;
+            if (ry >> 30) {                             // rare: samples wider than 10 bits, fetch them again
+              const uint32_t du = pixel & 15u, dv = pixel >> 4;
+              const uint32_t x = it.x0 + (swap ? dv : du), y = it.y0 + (swap ? du : dv);
+              const uint32_t ci = (y >> 1) * f.attr_cstride[layer] + (x >> 1);
+              Y = gl(f.attr_y[layer])[y * f.attr_stride[layer] + x];
+              U = gl(f.attr_u[layer])[ci];
+              V = gl(f.attr_v[layer])[ci];
+            }
+            rgb[h] = (variant & 8u) ? ry : yuv10_to_rgb8_int(Y, U, V);
+          }
         }
-        if (gp) gp[base + k] = (uint16_t)it.patch;                       // partition, src/codec.rs:452
+        if (two) {
+          store_xyz2(gx, (base + k) * 6u, p[0], p[1]);
+          if (f.has_attr) store_rgb2(gc, (base + k) * 3u, rgb[0], rgb[1]);
+          if (gp) { gp[base + k] = (uint16_t)it.patch; gp[base + k + 1u] = (uint16_t)it.patch; }   // partition, codec.rs:452
+        } else {
+          store_xyz(gx, (base + k) * 6u, p[0]);
+          if (f.has_attr) store_rgb(gc, (base + k) * 3u, rgb[0]);
+          if (gp) gp[base + k] = (uint16_t)it.patch;
+        }
       }
       wave_sync();                                      // the next item overwrites the slots
     }
