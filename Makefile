@@ -17,8 +17,8 @@ PRODUCT_SRC := $(wildcard $(CSRC)/*.hip) $(wildcard $(CSRC)/*.cpp)
 PRODUCT_HDR := $(wildcard $(CSRC)/*.hpp) $(wildcard $(CSRC)/*.h) include/vpcc_recon.h
 
 ORACLE_SO  := oracle/libvpcc_oracle.so
-ORACLE_SRC := oracle/vpcc_oracle.c
-ORACLE_HDR := oracle/vpcc_oracle.h include/vpcc_recon.h
+ORACLE_SRC := oracle/vpcc_oracle.c oracle/vpcc_smoothing_spec.c
+ORACLE_HDR := oracle/vpcc_oracle.h oracle/vpcc_smoothing_spec.h include/vpcc_recon.h
 
 all: product oracle
 product: $(PRODUCT_SO)

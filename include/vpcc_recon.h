@@ -222,6 +222,29 @@ int vpcc_gof_kernel_times(vpcc_gof* gof, const char** names_out, float* ms_out, 
  * written once), using the measured point count of the last reconstruct. */
 int vpcc_gof_algorithmic_bytes(vpcc_gof* gof, uint32_t frame, uint64_t* bytes_out);
 
+/* ------------------------------------------------------- smoothing */
+/* Grid-based geometry / colour smoothing of reconstructed frames, in place in HBM.  The reference has
+ * only unimplemented!() hooks here (src/decoder.rs:291-299, 630-658; src/codec.rs:498-500) and parses
+ * just the SEI syntax (src/bitstream/reader.rs:1452-1505), so there is no reference result: the
+ * behaviour is this library's own integer specification "gs1"/"cs1" (oracle/vpcc_smoothing_spec.h),
+ * against which the kernels are tested bit for bit. */
+typedef struct vpcc_smoothing_params {
+  uint32_t geometry_bitdepth_3d;        /* gi.geometry_3d_coordinates_bitdepth_minus1 + 1               */
+  uint32_t flags;                       /* VPCC_SMOOTH_GEOMETRY | VPCC_SMOOTH_COLOR                       */
+  uint32_t grid_size;                   /* SeiGeometrySmoothing::grid_size_minus_2 + 2                    */
+  uint32_t threshold;                   /* SeiGeometrySmoothing::threshold                                */
+  uint32_t color_grid_size;             /* ColorSmoothingParams::_cgrid_size   (src/codec.rs:180-186)     */
+  uint32_t color_threshold_smoothing;   /* ColorSmoothingParams::_threshold_color_smoothing               */
+  uint32_t color_threshold_difference;  /* ColorSmoothingParams::_threshold_color_difference              */
+  uint32_t reserved;
+} vpcc_smoothing_params;
+#define VPCC_SMOOTH_GEOMETRY 0x1u
+#define VPCC_SMOOTH_COLOR    0x2u
+/* Smooths frames [first, first+count) of the last reconstruct.  The gof must have been created with
+ * VPCC_GOF_WANT_PATCH_INDEX (the filters need each point's patch).  Geometry first, then colour. */
+int vpcc_gof_smooth(vpcc_gof* gof, uint32_t first, uint32_t count, const vpcc_smoothing_params* params,
+                    void* hip_stream);
+
 /* ------------------------------------------------- host mirror of the library API */
 /* C view of the C++ class tmc2rs::Decoder (tmc2-rs_amd/csrc/decoder.hpp), which mirrors the
  * reference's public API: Decoder::new (src/lib.rs:71-78), start() (:97-138), recv_frame() (:143-145).

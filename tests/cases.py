@@ -128,6 +128,18 @@ def gray_boundary_frame():
     return f
 
 
+def overlapping_3d_frame(index=0, base=None):
+    """Patches whose 3-D footprints overlap (all placed around (100..300)^3): many grid cells hold
+    points of several patches, which is what the smoothing filters act on."""
+    f = base if base is not None else medium_frame(20 + index)
+    p = f["patches"].copy()
+    p["u1"] = 100 + (np.arange(len(p)) % 5) * 3
+    p["v1"] = 100 + (np.arange(len(p)) % 7) * 2
+    p["d1"] = np.where(p["projection_mode"] == 0, 100, 300)
+    f["patches"] = p
+    return f
+
+
 PARITY_CASES = {
     "small0": lambda: synth.small_frame(0),
     "small1_randocc": lambda: synth.small_frame(1, occupancy_values="random"),

@@ -65,8 +65,30 @@ def lib():
         L.vpcc_oracle_time_frames.argtypes = [C.POINTER(FrameDesc), C.c_uint32, C.c_uint32,
                                               C.POINTER(C.c_uint64), C.POINTER(C.c_int)]
         L.vpcc_oracle_time_frames.restype = C.c_double
+        L.vpcc_spec_smooth_geometry.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_uint32, C.c_uint32, C.c_uint32]
+        L.vpcc_spec_smooth_color.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_uint32, C.c_uint32,
+                                             C.c_uint32, C.c_uint32]
         _lib = L
     return _lib
+
+
+def spec_smooth_geometry(xyz, patch_index, bitdepth, grid_size, threshold):
+    """oracle/vpcc_smoothing_spec.c "gs1" on an (N,3) u16 array; returns the smoothed copy."""
+    out = np.ascontiguousarray(xyz, dtype=np.uint16).copy()
+    pi = np.ascontiguousarray(patch_index, dtype=np.uint16)
+    st = lib().vpcc_spec_smooth_geometry(out.ctypes.data, pi.ctypes.data, len(out), bitdepth, grid_size, threshold)
+    assert st == 0
+    return out
+
+
+def spec_smooth_color(xyz, rgb, patch_index, bitdepth, grid_size, ts, td):
+    """oracle/vpcc_smoothing_spec.c "cs1"; returns the smoothed colours."""
+    x = np.ascontiguousarray(xyz, dtype=np.uint16)
+    out = np.ascontiguousarray(rgb, dtype=np.uint8).copy()
+    pi = np.ascontiguousarray(patch_index, dtype=np.uint16)
+    st = lib().vpcc_spec_smooth_color(x.ctypes.data, out.ctypes.data, pi.ctypes.data, len(x), bitdepth, grid_size, ts, td)
+    assert st == 0
+    return out
 
 
 def make_patch(**kw):

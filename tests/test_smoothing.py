@@ -1,0 +1,108 @@
+"""Smoothing.  The reference has no implementation (unimplemented!()), so the behaviour is
+this repository's own integer specification (oracle/vpcc_smoothing_spec.h).  CPU tests pin the spec on
+hand-made cases; GPU tests require the HIP kernels to reproduce the spec bit for bit."""
+import numpy as np
+import pytest
+
+import cases
+import oracle_binding as ob
+from tmc2rs import _abi, synth
+
+
+# ---------------------------------------------------------------- the spec itself (CPU)
+def test_single_patch_cells_are_left_alone():
+    rng = np.random.RandomState(1)
+    xyz = rng.randint(0, 1024, size=(5000, 3)).astype(np.uint16)
+    patch = np.zeros(5000, np.uint16)                      # one patch everywhere: no cell is "mixed"
+    assert np.array_equal(ob.spec_smooth_geometry(xyz, patch, 10, 8, 0), xyz)
+    rgb = rng.randint(0, 256, size=(5000, 3)).astype(np.uint8)
+    assert np.array_equal(ob.spec_smooth_color(xyz, rgb, patch, 10, 8, 0, 255 * 3), rgb)
+
+
+def test_geometry_hand_case():
+    # two points of different patches in ONE cell (grid 8, cell [8,16)^3); a far point in another cell
+    xyz = np.array([[9, 9, 9], [15, 15, 15], [500, 500, 500]], np.uint16)
+    patch = np.array([0, 1, 0], np.uint16)
+    out = ob.spec_smooth_geometry(xyz, patch, 10, 8, 0)
+    # point 0: r = 1 < 4 -> lower cell s = 0 (empty), upper cell = its own with weight t = 2*(9-4)+1 = 11 per axis
+    # centroid = (9+15)/2 = 12 exactly, whatever the weight; moved since d2 > 0
+    assert tuple(out[0]) == (12, 12, 12) and tuple(out[1]) == (12, 12, 12)
+    assert tuple(out[2]) == (500, 500, 500)                 # its cell holds one patch only
+    # threshold gates the move: |p - C| = 3*sqrt(3) = 5.2 per point -> T = 6 keeps, T = 5 moves
+    assert np.array_equal(ob.spec_smooth_geometry(xyz, patch, 10, 8, 6), xyz)
+    assert tuple(ob.spec_smooth_geometry(xyz, patch, 10, 8, 5)[0]) == (12, 12, 12)
+
+
+def test_geometry_trilinear_weights_hand_case():
+    # point at x = 17 (cell 2, r = 1 < 4): x-pair = cells 1 and 2, t = 2*(17 - (8+4)) + 1 = 11, weights (5, 11).
+    # y, z = 12 (r = 4): pair = cells 1 and 2 with t = 2*(12-12)+1 = 1 -> weights (15, 1); cells 2 in y/z are empty.
+    xyz = np.array([[17, 12, 12], [10, 12, 12], [18, 12, 12]], np.uint16)      # cells (2,1,1), (1,1,1), (2,1,1)
+    patch = np.array([0, 1, 1], np.uint16)                                      # cell (2,1,1) is mixed
+    out = ob.spec_smooth_geometry(xyz, patch, 10, 8, 0)
+    # for point 0: num_x = 5*15*15*10 + 11*15*15*(17+18), den = 5*225*1 + 11*225*2 -> C = (50 + 385)/27 = 16.11
+    c16 = (16 * (5 * 10 + 11 * 35) * 225 + (27 * 225) // 2) // (27 * 225)
+    assert out[0][0] == (c16 + 8) >> 4 == 16
+    assert out[0][1] == 12 and out[0][2] == 12
+
+
+def test_color_hand_case():
+    xyz = np.array([[9, 9, 9], [15, 15, 15], [10, 10, 10]], np.uint16)
+    patch = np.array([0, 1, 0], np.uint16)
+    rgb = np.array([[10, 20, 30], [40, 50, 60], [70, 80, 90]], np.uint8)
+    out = ob.spec_smooth_color(xyz, rgb, patch, 10, 8, 1, 0)
+    assert all(tuple(c) == (40, 50, 60) for c in out)       # mean of the single mixed cell, rounded
+    assert np.array_equal(ob.spec_smooth_color(xyz, rgb, patch, 10, 8, 1000, 0), rgb)   # Ts gate
+
+
+def test_spec_on_a_reconstructed_frame_moves_only_patch_boundaries():
+    f = cases.overlapping_3d_frame(0)
+    st, ref = ob.reconstruct(f)
+    xyz, part = ob.xyz_array(ref), ref["partition"].astype(np.uint16)
+    out = ob.spec_smooth_geometry(xyz, part, 10, 8, 2)
+    moved = np.any(out != xyz, axis=1)
+    assert 0 < moved.sum() < len(xyz) // 2
+
+
+# ---------------------------------------------------------------- HIP kernels vs the spec (GPU)
+@pytest.mark.gpu
+@pytest.mark.parametrize("frames,params", [
+    ("medium", dict(grid_size=8, threshold=2, color_grid_size=8, color_threshold_smoothing=10, color_threshold_difference=60)),
+    ("medium", dict(grid_size=4, threshold=0, color_grid_size=2, color_threshold_smoothing=0, color_threshold_difference=765)),
+    ("medium", dict(grid_size=16, threshold=5)),
+    ("longdress", dict(grid_size=8, threshold=3, color_grid_size=8, color_threshold_smoothing=20, color_threshold_difference=100)),
+])
+def test_hip_smoothing_matches_spec(frames, params):
+    from tmc2rs import recon
+    fr = ([cases.overlapping_3d_frame(i) for i in range(3)] if frames == "medium"
+          else [cases.overlapping_3d_frame(0, base=synth.longdress_frame(1))])
+    ctx = recon.Context(0)
+    g = ctx.gof(fr, flags=_abi.VPCC_GOF_WANT_PATCH_INDEX)
+    g.reconstruct()
+    before = [g.download(i, want_patch_index=True) for i in range(len(fr))]
+    g.smooth(10, **params)
+    for i, b in enumerate(before):
+        after = g.download(i)
+        exp_xyz = ob.spec_smooth_geometry(b["xyz"], b["patch_index"], 10, params["grid_size"], params["threshold"])
+        assert np.array_equal(after["xyz"], exp_xyz)
+        assert np.any(exp_xyz != b["xyz"])                  # the case really exercises the filter
+        if params.get("color_grid_size"):
+            exp_rgb = ob.spec_smooth_color(exp_xyz, b["rgb"], b["patch_index"], 10, params["color_grid_size"],
+                                           params["color_threshold_smoothing"], params["color_threshold_difference"])
+            assert np.array_equal(after["rgb"], exp_rgb)
+        else:
+            assert np.array_equal(after["rgb"], b["rgb"])
+    g.close()
+    ctx.close()
+
+
+@pytest.mark.gpu
+def test_smoothing_needs_patch_index():
+    from tmc2rs import recon
+    ctx = recon.Context(0)
+    g = ctx.gof([cases.medium_frame(0)])
+    g.reconstruct()
+    with pytest.raises(recon.VpccError) as e:
+        g.smooth(10, grid_size=8, threshold=1)
+    assert e.value.status == _abi.VPCC_ERR_STATE
+    g.close()
+    ctx.close()

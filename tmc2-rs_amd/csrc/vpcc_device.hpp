@@ -86,6 +86,22 @@ struct DevFrame {
   uint32_t pad[1];
 };
 
+// One grid cell of the smoothing filters (oracle/vpcc_smoothing_spec.h): all-zero = empty.
+struct SmoothCell {
+  uint32_t count;
+  uint32_t s[3];        // coordinate sums (geometry) or R,G,B sums (colour)
+  uint32_t negminp;     // max over points of (65535 - patch index): lets a zeroed cell take atomicMax
+  uint32_t maxp;        // max patch index
+};
+static_assert(sizeof(SmoothCell) == 24, "SmoothCell is 24 B");
+
+void launch_smooth_stats(const DevFrame* d_frames, uint32_t first, uint32_t count, uint32_t max_points, SmoothCell* grids,
+                         uint32_t w, uint32_t G, uint32_t mode, void* stream);
+void launch_smooth_apply_geometry(const DevFrame* d_frames, uint32_t first, uint32_t count, uint32_t max_points,
+                                  const SmoothCell* grids, uint32_t w, uint32_t G, uint32_t T, void* stream);
+void launch_smooth_apply_color(const DevFrame* d_frames, uint32_t first, uint32_t count, uint32_t max_points,
+                               const SmoothCell* grids, uint32_t w, uint32_t G, uint32_t Ts, uint32_t Td, void* stream);
+
 // Kernel launchers (vpcc_kernels.hip).  All asynchronous on `stream`.
 void launch_block_owner(const DevFrame* d_frames, uint32_t first, uint32_t count, uint32_t max_vb,
                         void* stream);

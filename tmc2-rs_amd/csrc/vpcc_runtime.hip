@@ -58,6 +58,8 @@ struct vpcc_gof {
   hipStream_t last_stream = nullptr;
   std::vector<KernelTiming> timings;
   uint32_t n_timed = 0;
+  void* smooth_grid = nullptr;         // dense cell grids of the smoothing filters (scratch, on demand)
+  size_t smooth_bytes = 0;
 };
 
 namespace {
@@ -151,6 +153,7 @@ extern "C" void vpcc_gof_destroy(vpcc_gof* gof) {
     (void)hipEventDestroy(t.stop);
   }
   if (gof->upload_done) (void)hipEventDestroy(gof->upload_done);
+  if (gof->smooth_grid) (void)hipFree(gof->smooth_grid);
   if (gof->arena) (void)hipFree(gof->arena);
   if (gof->h_counts) (void)hipHostFree(gof->h_counts);
   delete gof;
@@ -558,6 +561,61 @@ extern "C" int vpcc_gof_algorithmic_bytes(vpcc_gof* g, uint32_t frame, uint64_t*
   const int st = fetch_counts(g);
   if (st) return st;
   *bytes_out = g->plans[frame].plane_bytes + 9ull * g->h_counts[frame];
+  return VPCC_OK;
+}
+
+// ------------------------------------------------------------------ smoothing
+extern "C" int vpcc_gof_smooth(vpcc_gof* g, uint32_t first, uint32_t count, const vpcc_smoothing_params* p,
+                               void* hip_stream) {
+  if (!g || !p) return VPCC_ERR_INVALID_ARG;
+  vpcc_ctx* ctx = g->ctx;
+  if (count == 0 || first >= g->n_frames || count > g->n_frames - first) return fail(ctx, VPCC_ERR_INVALID_ARG, "frame range");
+  if (!(g->flags & VPCC_GOF_WANT_PATCH_INDEX)) return fail(ctx, VPCC_ERR_STATE, "smoothing needs VPCC_GOF_WANT_PATCH_INDEX");
+  if (p->geometry_bitdepth_3d < 1 || p->geometry_bitdepth_3d > 16) return fail(ctx, VPCC_ERR_INVALID_ARG, "bit depth");
+  if ((p->flags & VPCC_SMOOTH_GEOMETRY) && p->grid_size < 2) return fail(ctx, VPCC_ERR_INVALID_ARG, "grid size");
+  if ((p->flags & VPCC_SMOOTH_COLOR) && p->color_grid_size < 2) return fail(ctx, VPCC_ERR_INVALID_ARG, "colour grid size");
+  HIP_TRY(ctx, hipSetDevice(ctx->device));
+  int st = fetch_counts(g);                               // synchronises: the point counts size the launches
+  if (st) return st;
+  hipStream_t s = hip_stream ? (hipStream_t)hip_stream : ctx->stream;
+  g->last_stream = s;
+  for (int pass = 0; pass < 2; ++pass) {
+    const bool geo = pass == 0;
+    if (!(p->flags & (geo ? VPCC_SMOOTH_GEOMETRY : VPCC_SMOOTH_COLOR))) continue;
+    if (!geo) {
+      bool any_attr = false;
+      for (uint32_t i = first; i < first + count; ++i) any_attr |= g->h_frames[i].has_attr != 0;
+      if (!any_attr) continue;
+      for (uint32_t i = first; i < first + count; ++i)
+        if (!g->h_frames[i].has_attr) return fail(ctx, VPCC_ERR_INVALID_ARG, "colour smoothing on a frame without attribute");
+    }
+    const uint32_t G = geo ? p->grid_size : p->color_grid_size;
+    const uint32_t w = ((1u << p->geometry_bitdepth_3d) + G - 1) / G;
+    const size_t cells = (size_t)w * w * w;
+    // the dense grids live in a scratch arena of at most ~1 GiB: frames are smoothed in chunks
+    const size_t per_frame = cells * sizeof(SmoothCell);
+    const uint32_t chunk = (uint32_t)std::max<size_t>(1, std::min<size_t>(count, (size_t(1) << 30) / per_frame));
+    if (g->smooth_bytes < per_frame * chunk) {
+      if (g->smooth_grid) HIP_TRY(ctx, hipFree(g->smooth_grid));
+      g->smooth_grid = nullptr;
+      g->smooth_bytes = 0;
+      HIP_TRY(ctx, hipMalloc(&g->smooth_grid, per_frame * chunk));
+      g->smooth_bytes = per_frame * chunk;
+    }
+    for (uint32_t c0 = first; c0 < first + count; c0 += chunk) {
+      const uint32_t c = std::min(chunk, first + count - c0);
+      uint32_t max_points = 0;
+      for (uint32_t i = c0; i < c0 + c; ++i) max_points = std::max(max_points, std::min<uint32_t>(g->h_counts[i], (uint32_t)g->capacity));
+      HIP_TRY(ctx, hipMemsetAsync(g->smooth_grid, 0, per_frame * c, s));
+      launch_smooth_stats(g->d_frames, c0, c, max_points, (SmoothCell*)g->smooth_grid, w, G, geo ? 0u : 1u, s);
+      if (geo)
+        launch_smooth_apply_geometry(g->d_frames, c0, c, max_points, (const SmoothCell*)g->smooth_grid, w, G, p->threshold, s);
+      else
+        launch_smooth_apply_color(g->d_frames, c0, c, max_points, (const SmoothCell*)g->smooth_grid, w, G,
+                                  p->color_threshold_smoothing, p->color_threshold_difference, s);
+      HIP_TRY(ctx, hipGetLastError());
+    }
+  }
   return VPCC_OK;
 }
 

@@ -1,0 +1,178 @@
+// vpcc_smooth.hip — grid-based geometry and colour smoothing on gfx950.
+//
+// The reference implements neither (every hook is unimplemented!(): src/decoder.rs:291-299, 630-658,
+// src/codec.rs:498-500); the behaviour is this repository's own integer specification "gs1"/"cs1",
+// written down in oracle/vpcc_smoothing_spec.h and tested bit for bit against its CPU form.
+//
+// Two kernels per filter, both one thread per point, HBM-bound scatter/gather:
+//   k_smooth_stats : per occupied grid cell {count, 3 sums, max(65535 - patch), max(patch)} with atomics into
+//                    a dense w^3 grid (zeroed by one memset per launch);
+//   k_smooth_apply : 2x2x2 cell neighbourhood with integer trilinear weights -> centroid / mean,
+//                    thresholded replacement in place (a thread reads only its own point and the grid).
+#include <hip/hip_runtime.h>
+
+#include "vpcc_device.hpp"
+#include "vpcc_devfn.hpp"
+
+namespace vpcc {
+
+namespace {
+
+__device__ __forceinline__ uint32_t cell_coord(uint32_t p, uint32_t G, uint32_t w) {
+  const uint32_t q = p / G;
+  return q < w ? q : w - 1u;
+}
+
+__device__ __forceinline__ void axis_setup(uint32_t p, uint32_t G, uint32_t w, int32_t& s, int64_t wt[2]) {
+  const int32_t q = (int32_t)cell_coord(p, G, w), r = (int32_t)p - q * (int32_t)G, h = (int32_t)(G / 2u);
+  s = (r < h) ? q - 1 : q;
+  const int32_t t = 2 * ((int32_t)p - (s * (int32_t)G + h)) + 1;
+  wt[0] = 2 * (int64_t)G - t;
+  wt[1] = t;
+}
+
+}  // namespace
+
+// mode 0: sums of coordinates (geometry); mode 1: sums of R,G,B (colour)
+__global__ __launch_bounds__(256) void k_smooth_stats(const DevFrame* __restrict__ frames, uint32_t first,
+                                                      SmoothCell* __restrict__ grids, uint32_t w, uint32_t G,
+                                                      uint32_t mode) {
+  const DevFrame& f = frames[first + blockIdx.y];
+  const uint32_t n = min(*gl(f.n_points), f.capacity);
+  const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+  if (i >= n) return;
+  const vpcc_point3 p = gload(f.out_xyz + i);
+  SmoothCell* c = grids + (size_t)blockIdx.y * w * w * w +
+                  ((size_t)cell_coord(p.z, G, w) * w + cell_coord(p.y, G, w)) * w + cell_coord(p.x, G, w);
+  uint32_t v[3] = {p.x, p.y, p.z};
+  if (mode) {
+    const vpcc_color3 col = gload(f.out_rgb + i);
+    v[0] = col.r; v[1] = col.g; v[2] = col.b;
+  }
+  const uint32_t patch = gl(f.out_patch)[i];
+  atomicAdd(&c->count, 1u);
+  atomicAdd(&c->s[0], v[0]);
+  atomicAdd(&c->s[1], v[1]);
+  atomicAdd(&c->s[2], v[2]);
+  atomicMax(&c->negminp, 65535u - patch);
+  atomicMax(&c->maxp, patch);
+}
+
+__global__ __launch_bounds__(256) void k_smooth_apply_geometry(const DevFrame* __restrict__ frames, uint32_t first,
+                                                               const SmoothCell* __restrict__ grids, uint32_t w,
+                                                               uint32_t G, uint32_t T) {
+  const DevFrame& f = frames[first + blockIdx.y];
+  const uint32_t n = min(*gl(f.n_points), f.capacity);
+  const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+  if (i >= n) return;
+  const vpcc_point3 pt = gload(f.out_xyz + i);
+  const uint32_t p[3] = {pt.x, pt.y, pt.z};
+  const SmoothCell* grid = grids + (size_t)blockIdx.y * w * w * w;
+  int32_t s[3];
+  int64_t wt[3][2];
+#pragma unroll
+  for (int a = 0; a < 3; ++a) axis_setup(p[a], G, w, s[a], wt[a]);
+  int64_t num[3] = {0, 0, 0}, den = 0;
+  bool mixed = false;
+#pragma unroll
+  for (int d = 0; d < 8; ++d) {
+    const int dx = d & 1, dy = (d >> 1) & 1, dz = d >> 2;
+    const int32_t cx = s[0] + dx, cy = s[1] + dy, cz = s[2] + dz;
+    if (cx < 0 || cy < 0 || cz < 0 || cx >= (int32_t)w || cy >= (int32_t)w || cz >= (int32_t)w) continue;
+    const SmoothCell c = gload(grid + ((size_t)cz * w + cy) * w + cx);
+    if (!c.count) continue;
+    const int64_t W = wt[0][dx] * wt[1][dy] * wt[2][dz];
+    num[0] += W * c.s[0]; num[1] += W * c.s[1]; num[2] += W * c.s[2];
+    den += W * c.count;
+    mixed |= (65535u - c.negminp) != c.maxp;
+  }
+  if (!mixed || den <= 0) return;
+  int64_t C[3], d2 = 0;
+#pragma unroll
+  for (int a = 0; a < 3; ++a) {
+    C[a] = (16 * num[a] + den / 2) / den;
+    const int64_t d = 16 * (int64_t)p[a] - C[a];
+    d2 += d * d;
+  }
+  if (d2 > 256 * (int64_t)T * T) {
+    vpcc_point3 o;
+    const int64_t x = (C[0] + 8) >> 4, y = (C[1] + 8) >> 4, z = (C[2] + 8) >> 4;
+    o.x = (uint16_t)(x > 65535 ? 65535 : x); o.y = (uint16_t)(y > 65535 ? 65535 : y); o.z = (uint16_t)(z > 65535 ? 65535 : z);
+    gstore(f.out_xyz + i, o);
+  }
+}
+
+__global__ __launch_bounds__(256) void k_smooth_apply_color(const DevFrame* __restrict__ frames, uint32_t first,
+                                                            const SmoothCell* __restrict__ grids, uint32_t w, uint32_t G,
+                                                            uint32_t Ts, uint32_t Td) {
+  const DevFrame& f = frames[first + blockIdx.y];
+  const uint32_t n = min(*gl(f.n_points), f.capacity);
+  const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+  if (i >= n) return;
+  const vpcc_point3 pt = gload(f.out_xyz + i);
+  const vpcc_color3 col = gload(f.out_rgb + i);
+  const uint32_t p[3] = {pt.x, pt.y, pt.z};
+  const int64_t cl[3] = {col.r, col.g, col.b};
+  const SmoothCell* grid = grids + (size_t)blockIdx.y * w * w * w;
+  int32_t s[3];
+  int64_t wt[3][2];
+#pragma unroll
+  for (int a = 0; a < 3; ++a) axis_setup(p[a], G, w, s[a], wt[a]);
+  const int32_t qx = (int32_t)cell_coord(p[0], G, w), qy = (int32_t)cell_coord(p[1], G, w), qz = (int32_t)cell_coord(p[2], G, w);
+  const SmoothCell cc = gload(grid + ((size_t)qz * w + qy) * w + qx);
+  const int64_t mc[3] = {cc.s[0] / cc.count, cc.s[1] / cc.count, cc.s[2] / cc.count};
+  int64_t num[3] = {0, 0, 0}, den = 0;
+  bool mixed = false;
+#pragma unroll
+  for (int d = 0; d < 8; ++d) {
+    const int dx = d & 1, dy = (d >> 1) & 1, dz = d >> 2;
+    const int32_t cx = s[0] + dx, cy = s[1] + dy, cz = s[2] + dz;
+    if (cx < 0 || cy < 0 || cz < 0 || cx >= (int32_t)w || cy >= (int32_t)w || cz >= (int32_t)w) continue;
+    const SmoothCell c = gload(grid + ((size_t)cz * w + cy) * w + cx);
+    if (!c.count) continue;
+    if (!(cx == qx && cy == qy && cz == qz)) {
+      int64_t diff = 0;
+#pragma unroll
+      for (int a = 0; a < 3; ++a) { const int64_t m = (int64_t)(c.s[a] / c.count) - mc[a]; diff += m < 0 ? -m : m; }
+      if (diff > (int64_t)Td) continue;
+    }
+    const int64_t W = wt[0][dx] * wt[1][dy] * wt[2][dz];
+    num[0] += W * c.s[0]; num[1] += W * c.s[1]; num[2] += W * c.s[2];
+    den += W * c.count;
+    mixed |= (65535u - c.negminp) != c.maxp;
+  }
+  if (!mixed || den <= 0) return;
+  int64_t m[3], dist = 0;
+#pragma unroll
+  for (int a = 0; a < 3; ++a) {
+    m[a] = (2 * num[a] + den) / (2 * den);
+    const int64_t d = cl[a] - m[a];
+    dist += d < 0 ? -d : d;
+  }
+  if (dist >= (int64_t)Ts) {
+    vpcc_color3 o;
+    o.r = (uint8_t)m[0]; o.g = (uint8_t)m[1]; o.b = (uint8_t)m[2];
+    gstore(f.out_rgb + i, o);
+  }
+}
+
+void launch_smooth_stats(const DevFrame* d_frames, uint32_t first, uint32_t count, uint32_t max_points, SmoothCell* grids,
+                         uint32_t w, uint32_t G, uint32_t mode, void* stream) {
+  if (!count || !max_points) return;
+  hipLaunchKernelGGL(k_smooth_stats, dim3((max_points + 255) / 256, count), dim3(256), 0, (hipStream_t)stream, d_frames,
+                     first, grids, w, G, mode);
+}
+void launch_smooth_apply_geometry(const DevFrame* d_frames, uint32_t first, uint32_t count, uint32_t max_points,
+                                  const SmoothCell* grids, uint32_t w, uint32_t G, uint32_t T, void* stream) {
+  if (!count || !max_points) return;
+  hipLaunchKernelGGL(k_smooth_apply_geometry, dim3((max_points + 255) / 256, count), dim3(256), 0, (hipStream_t)stream,
+                     d_frames, first, grids, w, G, T);
+}
+void launch_smooth_apply_color(const DevFrame* d_frames, uint32_t first, uint32_t count, uint32_t max_points,
+                               const SmoothCell* grids, uint32_t w, uint32_t G, uint32_t Ts, uint32_t Td, void* stream) {
+  if (!count || !max_points) return;
+  hipLaunchKernelGGL(k_smooth_apply_color, dim3((max_points + 255) / 256, count), dim3(256), 0, (hipStream_t)stream,
+                     d_frames, first, grids, w, G, Ts, Td);
+}
+
+}  // namespace vpcc

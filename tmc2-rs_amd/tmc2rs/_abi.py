@@ -86,6 +86,16 @@ class FrameDesc(C.Structure):
     ]
 
 
+class SmoothingParams(C.Structure):
+    _fields_ = [("geometry_bitdepth_3d", C.c_uint32), ("flags", C.c_uint32), ("grid_size", C.c_uint32),
+                ("threshold", C.c_uint32), ("color_grid_size", C.c_uint32),
+                ("color_threshold_smoothing", C.c_uint32), ("color_threshold_difference", C.c_uint32),
+                ("reserved", C.c_uint32)]
+
+
+VPCC_SMOOTH_GEOMETRY = 0x1
+VPCC_SMOOTH_COLOR = 0x2
+
 POINT3_DTYPE = np.dtype([("x", "<u2"), ("y", "<u2"), ("z", "<u2")])
 COLOR3_DTYPE = np.dtype([("r", "u1"), ("g", "u1"), ("b", "u1")])
 
@@ -183,6 +193,7 @@ def load_library():
     lib.vpcc_gof_frame_status.argtypes = [vp, u32]
     lib.vpcc_gof_kernel_times.argtypes = [vp, C.POINTER(C.c_char_p), C.POINTER(C.c_float), C.c_int]
     lib.vpcc_gof_algorithmic_bytes.argtypes = [vp, u32, C.POINTER(u64)]
+    lib.vpcc_gof_smooth.argtypes = [vp, u32, u32, C.POINTER(SmoothingParams), vp]
     lib.vpcc_decoder_open.argtypes = [C.c_char_p, C.POINTER(C.c_int), C.c_int, C.POINTER(vp)]
     lib.vpcc_decoder_start.argtypes = [vp]
     lib.vpcc_decoder_recv_frame.argtypes = [vp, C.POINTER(sz), C.POINTER(vp), C.POINTER(vp)]

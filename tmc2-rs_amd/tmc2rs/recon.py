@@ -160,6 +160,19 @@ class Gof:
             res["patch_index"] = pidx[:k.value].copy()
         return res
 
+    def smooth(self, bitdepth, grid_size=0, threshold=0, color_grid_size=0, color_threshold_smoothing=0,
+               color_threshold_difference=0, first=0, count=None, stream=None):
+        """vpcc_gof_smooth: geometry smoothing if grid_size > 0, colour smoothing if color_grid_size > 0."""
+        p = _abi.SmoothingParams()
+        p.geometry_bitdepth_3d = bitdepth
+        p.flags = (_abi.VPCC_SMOOTH_GEOMETRY if grid_size else 0) | (_abi.VPCC_SMOOTH_COLOR if color_grid_size else 0)
+        p.grid_size, p.threshold = grid_size, threshold
+        p.color_grid_size = color_grid_size
+        p.color_threshold_smoothing, p.color_threshold_difference = color_threshold_smoothing, color_threshold_difference
+        count = self.n_frames - first if count is None else count
+        self.ctx._check(self.lib.vpcc_gof_smooth(self.h, first, count, C.byref(p), C.c_void_p(stream) if stream else None),
+                        "vpcc_gof_smooth")
+
     def device_outputs(self, frame):
         p = [C.c_void_p() for _ in range(4)]
         self.ctx._check(self.lib.vpcc_gof_device_outputs(self.h, frame, *[C.byref(x) for x in p]),
