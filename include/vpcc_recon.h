@@ -143,6 +143,14 @@ int  vpcc_ctx_create(int device_id, vpcc_ctx** out);
 void vpcc_ctx_destroy(vpcc_ctx* ctx);
 const char* vpcc_last_error(const vpcc_ctx* ctx);
 
+/* Plane ingest (stand-in for LibavcodecDecoder::decode, src/decoder.rs:1089-1156, whose Vec<u8> planes
+ * are the H2D source): page-locks a host range so that uploads from it are true asynchronous DMA. */
+int  vpcc_host_pin(vpcc_ctx* ctx, const void* ptr, size_t bytes);
+int  vpcc_host_unpin(vpcc_ctx* ctx, const void* ptr);
+/* Page-locked host buffers for results (D2H straight into the memory the consumer keeps). */
+int  vpcc_host_alloc(vpcc_ctx* ctx, size_t bytes, void** out);
+int  vpcc_host_free(vpcc_ctx* ctx, void* ptr);   /* ctx may be NULL once the context is gone */
+
 /* Validates a frame descriptor on the host exactly as far as the reference's
  * asserts would fire while walking it (patch extents, plane sizes, supported
  * envelope).  Pure host function, no GPU needed. */
@@ -189,6 +197,11 @@ void vpcc_gof_destroy(vpcc_gof* gof);
 #define VPCC_GOF_WANT_PATCH_INDEX 0x1u  /* also emit per-point patch index (partition)          */
 #define VPCC_GOF_FORCE_GENERAL    0x2u  /* force the general (all-orientation) kernel sequence  */
 #define VPCC_GOF_PROFILE          0x4u  /* record per-kernel HIP-event timings                  */
+#define VPCC_GOF_ASYNC_UPLOAD     0x8u  /* VPCC_MEM_HOST only: vpcc_gof_create returns while the H2D copies
+                                           are still in flight on the context's copy stream (plane ingest
+                                           overlapping the previous GOF's kernels).  The planes must be pinned
+                                           (vpcc_host_pin) and stay valid until the first vpcc_gof_sync /
+                                           vpcc_gof_point_counts / vpcc_gof_download of this gof.          */
 
 /* Enqueues the reconstruction of frames [first, first+count) on `hip_stream`
  * (a hipStream_t passed as void*; NULL = the context's own stream).  Returns
@@ -259,6 +272,10 @@ int  vpcc_decoder_start(vpcc_decoder* dec);
  * failure in the worker, like the reference's consumer sees None after a worker panic. */
 int  vpcc_decoder_recv_frame(vpcc_decoder* dec, size_t* n_points, const vpcc_point3** xyz, const vpcc_color3** rgb);
 const char* vpcc_decoder_error(vpcc_decoder* dec);
+/* Consumes the rest of the stream inside the library (no per-frame copies into the caller) and reports
+ * frames, points and wall seconds since the call: the end-to-end, PCIe-inclusive rate of the ingest ->
+ * reconstruct -> D2H pipeline. */
+int  vpcc_decoder_drain(vpcc_decoder* dec, uint64_t* frames, uint64_t* points, double* seconds);
 void vpcc_decoder_close(vpcc_decoder* dec);
 
 /* writer::PlyWriter::write, ASCII (src/writer.rs:25-74); rgb may be NULL (no colour properties). */

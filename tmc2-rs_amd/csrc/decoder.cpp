@@ -2,6 +2,7 @@
 // reconstruction on one or several MI355X through the C ABI (include/vpcc_recon.h).
 #include "decoder.hpp"
 
+#include <chrono>
 #include <cstdio>
 #include <cstring>
 #include <fstream>
@@ -86,6 +87,42 @@ bool parse_container(const std::vector<unsigned char>& buf, std::vector<DecodedG
   return true;
 }
 
+// ------------------------------------------------------------------ PinnedPool
+PinnedPool::~PinnedPool() { detach(); }
+
+PinnedBlock PinnedPool::get(size_t bytes) {
+  if (bytes == 0) bytes = 1;
+  {
+    std::lock_guard<std::mutex> lk(m_);
+    for (size_t k = 0; k < free_.size(); ++k)
+      if (free_[k].second >= bytes) {
+        PinnedBlock b{free_[k].first, free_[k].second, shared_from_this()};
+        free_.erase(free_.begin() + (long)k);
+        return b;
+      }
+  }
+  PinnedBlock b;
+  const size_t cap = (bytes + (size_t(1) << 20) - 1) & ~((size_t(1) << 20) - 1);   // 1 MiB granules: blocks get reused
+  if (ctx_ && vpcc_host_alloc(ctx_, cap, &b.ptr) == VPCC_OK) {
+    b.bytes = cap;
+    b.pool = shared_from_this();
+  }
+  return b;
+}
+
+void PinnedPool::put(void* ptr, size_t bytes) {
+  std::lock_guard<std::mutex> lk(m_);
+  if (ctx_ && free_.size() < 8) free_.emplace_back(ptr, bytes);
+  else vpcc_host_free(ctx_, ptr);             // also after the context is gone (frames may outlive the decoder)
+}
+
+void PinnedPool::detach() {
+  std::lock_guard<std::mutex> lk(m_);
+  if (ctx_) for (auto& f : free_) vpcc_host_free(ctx_, f.first);
+  free_.clear();
+  ctx_ = nullptr;
+}
+
 // ------------------------------------------------------------------ Decoder
 Decoder::Decoder(Params params) : params_(std::move(params)) {}
 
@@ -118,6 +155,8 @@ struct GofDeleter { void operator()(vpcc_gof* g) const { vpcc_gof_destroy(g); } 
 void Decoder::worker() {
   // one context per GPU; frames of a GOF are dealt round-robin (frame f -> device f % G) and delivered in
   // presentation order — they are independent (src/decoder.rs:186), so no data moves between GPUs.
+  // Plane ingest: the container buffer is page-locked once, so every plane upload is an asynchronous
+  // DMA on the context's copy stream, and GOF k+1 is uploaded while GOF k is reconstructed and drained.
   const size_t G = params_.devices.empty() ? 1 : params_.devices.size();
   std::vector<std::unique_ptr<vpcc_ctx, CtxDeleter>> ctxs(G);
   for (size_t d = 0; d < G; ++d) {
@@ -126,73 +165,110 @@ void Decoder::worker() {
     if (st) { error_ = std::string("vpcc_ctx_create: ") + vpcc_status_string(st); chan_.close_tx(); return; }
     ctxs[d].reset(c);
   }
-  for (const DecodedGof& gof : gofs_) {       // while ssvu.get_v3c_unit_count() > 0, src/lib.rs:118
-    const size_t n = gof.frames.size();
-    std::vector<std::vector<vpcc_frame_desc>> part(G);
-    for (size_t f = 0; f < n; ++f) part[f % G].push_back(gof.frames[f]);
-    std::vector<std::unique_ptr<vpcc_gof, GofDeleter>> dg(G);
+  auto pool = std::make_shared<PinnedPool>(ctxs[0].get());
+  struct Detach {
+    std::shared_ptr<PinnedPool> p;
+    ~Detach() { p->detach(); }              // frames the consumer still holds outlive the context safely
+  } detach{pool};
+  const bool pinned = !file_.empty() && vpcc_host_pin(ctxs[0].get(), file_.data(), file_.size()) == VPCC_OK;
+  struct Unpin {
+    vpcc_ctx* c; const void* p; bool on;
+    ~Unpin() { if (on) vpcc_host_unpin(c, p); }
+  } unpin{ctxs[0].get(), file_.data(), pinned};
+
+  struct InFlight {                                   // one GOF, sharded over the devices
+    std::vector<std::vector<vpcc_frame_desc>> part;
+    std::vector<std::unique_ptr<vpcc_gof, GofDeleter>> dg;
+    bool ok = false;
+  };
+  auto launch = [&](const DecodedGof& gof, InFlight* f) -> bool {
+    f->part.assign(G, {});
+    f->dg.clear();
+    f->dg.resize(G);
+    for (size_t i = 0; i < gof.frames.size(); ++i) f->part[i % G].push_back(gof.frames[i]);
     for (size_t d = 0; d < G; ++d) {
-      if (part[d].empty()) continue;
+      if (f->part[d].empty()) continue;
       vpcc_gof* g = nullptr;
-      int st = vpcc_gof_create(ctxs[d].get(), part[d].data(), (uint32_t)part[d].size(), VPCC_MEM_HOST, 0, 0, &g);
+      int st = vpcc_gof_create(ctxs[d].get(), f->part[d].data(), (uint32_t)f->part[d].size(), VPCC_MEM_HOST, 0,
+                               pinned ? VPCC_GOF_ASYNC_UPLOAD : 0u, &g);
       if (st == VPCC_OK) {
-        dg[d].reset(g);
-        st = vpcc_gof_reconstruct(g, 0, (uint32_t)part[d].size(), nullptr);     // asynchronous: all GPUs run concurrently
+        f->dg[d].reset(g);
+        st = vpcc_gof_reconstruct(g, 0, (uint32_t)f->part[d].size(), nullptr);   // asynchronous: all GPUs run concurrently
       }
       if (st) {
         error_ = std::string(vpcc_status_string(st)) + ": " + vpcc_last_error(ctxs[d].get());
-        chan_.close_tx();                     // reference: panic in the worker -> consumer sees end-of-stream
-        return;
+        return false;                                 // reference: panic in the worker -> consumer sees end-of-stream
       }
     }
+    f->ok = true;
+    return true;
+  };
+
+  InFlight cur, next;
+  if (!gofs_.empty() && !launch(gofs_[0], &cur)) { chan_.close_tx(); return; }
+  for (size_t k = 0; k < gofs_.size(); ++k) {         // while ssvu.get_v3c_unit_count() > 0, src/lib.rs:118
+    const DecodedGof& gof = gofs_[k];
+    next = InFlight{};
+    bool next_failed = false;
+    if (k + 1 < gofs_.size()) next_failed = !launch(gofs_[k + 1], &next);   // its ingest overlaps this GOF's work
+    const size_t n = gof.frames.size();
     std::vector<std::vector<uint32_t>> counts(G);
     for (size_t d = 0; d < G; ++d) {
-      if (!dg[d]) continue;
-      counts[d].resize(part[d].size());
-      const int st = vpcc_gof_point_counts(dg[d].get(), counts[d].data());
+      if (!cur.dg[d]) continue;
+      counts[d].resize(cur.part[d].size());
+      const int st = vpcc_gof_point_counts(cur.dg[d].get(), counts[d].data());
       if (st) { error_ = vpcc_last_error(ctxs[d].get()); chan_.close_tx(); return; }
     }
-    for (size_t f = 0; f < n; ++f) {          // presentation order, src/decoder.rs:188
+    for (size_t f = 0; f < n; ++f) {                  // presentation order, src/decoder.rs:188
       const size_t d = f % G, local = f / G;
       PointSet3 ps;
       ps.with_colors = gof.frames[f].attribute_count > 0;
       const size_t np = counts[d][local];
-      ps.positions.resize(np);
-      if (ps.with_colors) ps.colors.resize(np);
+      PinnedBlock bx = pool->get(np * sizeof(vpcc_point3)), bc;
+      if (ps.with_colors) bc = pool->get(np * sizeof(vpcc_color3));
+      if (!bx.ptr || (ps.with_colors && !bc.ptr)) { error_ = "out of page-locked memory"; chan_.close_tx(); return; }
+      ps.positions.adopt(std::move(bx), np);
+      if (ps.with_colors) ps.colors.adopt(std::move(bc), np);
       size_t got = 0;
-      const int st = vpcc_gof_download(dg[d].get(), (uint32_t)local, ps.positions.data(),
+      const int st = vpcc_gof_download(cur.dg[d].get(), (uint32_t)local, ps.positions.data(),
                                        ps.with_colors ? ps.colors.data() : nullptr, nullptr, np ? np : 1, &got);
       if (st || got != np) { error_ = vpcc_last_error(ctxs[d].get()); chan_.close_tx(); return; }
       if (!chan_.send(std::move(ps))) { chan_.close_tx(); return; }            // receiver dropped, src/decoder.rs:311-313
     }
+    if (next_failed) { chan_.close_tx(); return; }    // the stream ends where the failing GOF would have started
+    cur = std::move(next);
   }
-  chan_.close_tx();                           // drop(tx), src/lib.rs:136
+  chan_.close_tx();                                   // drop(tx), src/lib.rs:136
 }
 
 // ------------------------------------------------------------------ PlyWriter (src/writer.rs:25-74)
-std::string PlyWriter::to_string() const {
+std::string PlyWriter::to_string(const vpcc_point3* xyz, const vpcc_color3* rgb, size_t n) {
   std::string s;
-  s.reserve(64 + pc_.len() * 24);
+  s.reserve(64 + n * 24);
   s += "ply\n";
   s += "format ascii 1.0\n";
-  s += "element vertex " + std::to_string(pc_.len()) + "\n";
+  s += "element vertex " + std::to_string(n) + "\n";
   s += "property uint x\nproperty uint y\nproperty uint z\n";
-  if (pc_.with_colors) s += "property uchar red\nproperty uchar green\nproperty uchar blue\n";
+  if (rgb) s += "property uchar red\nproperty uchar green\nproperty uchar blue\n";
   s += "element face 0\n";
   s += "property list uint8 int32 vertex_index\n";
   s += "end_header\n";
   char line[64];
-  for (size_t i = 0; i < pc_.len(); ++i) {
-    const vpcc_point3& p = pc_.positions[i];
-    int n = std::snprintf(line, sizeof line, "%u %u %u", (unsigned)p.x, (unsigned)p.y, (unsigned)p.z);
-    if (pc_.with_colors) {
-      const vpcc_color3& c = pc_.colors[i];
-      n += std::snprintf(line + n, sizeof line - n, " %u %u %u", (unsigned)c.r, (unsigned)c.g, (unsigned)c.b);
+  for (size_t i = 0; i < n; ++i) {
+    const vpcc_point3& p = xyz[i];
+    int k = std::snprintf(line, sizeof line, "%u %u %u", (unsigned)p.x, (unsigned)p.y, (unsigned)p.z);
+    if (rgb) {
+      const vpcc_color3& c = rgb[i];
+      k += std::snprintf(line + k, sizeof line - k, " %u %u %u", (unsigned)c.r, (unsigned)c.g, (unsigned)c.b);
     }
-    line[n++] = '\n';
-    s.append(line, (size_t)n);
+    line[k++] = '\n';
+    s.append(line, (size_t)k);
   }
   return s;
+}
+
+std::string PlyWriter::to_string() const {
+  return to_string(pc_.positions.data(), pc_.with_colors ? pc_.colors.data() : nullptr, pc_.len());
 }
 
 bool PlyWriter::write(const std::string& path) const {
@@ -251,13 +327,25 @@ extern "C" const char* vpcc_decoder_error(vpcc_decoder* d) {
   return d->dec.last_error().empty() ? d->err.c_str() : d->dec.last_error().c_str();   // the worker's error wins
 }
 
+extern "C" int vpcc_decoder_drain(vpcc_decoder* d, uint64_t* frames, uint64_t* points, double* seconds) {
+  if (!d) return VPCC_ERR_INVALID_ARG;
+  const auto t0 = std::chrono::steady_clock::now();
+  uint64_t nf = 0, np = 0;
+  while (auto fr = d->dec.recv_frame()) { ++nf; np += fr->len(); }
+  const double s = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+  if (frames) *frames = nf;
+  if (points) *points = np;
+  if (seconds) *seconds = s;
+  return d->dec.last_error().empty() ? VPCC_OK : VPCC_ERR_DEVICE;
+}
+
 extern "C" void vpcc_decoder_close(vpcc_decoder* d) { delete d; }
 
 extern "C" int vpcc_write_ply(const char* path, const vpcc_point3* xyz, const vpcc_color3* rgb, size_t n) {
   if (!path || (n && !xyz)) return VPCC_ERR_INVALID_ARG;
-  tmc2rs::PointSet3 ps;
-  ps.positions.assign(xyz, xyz + n);
-  ps.with_colors = rgb != nullptr;
-  if (rgb) ps.colors.assign(rgb, rgb + n);
-  return tmc2rs::PlyWriter(ps, tmc2rs::Format::Ascii).write(path) ? VPCC_OK : VPCC_ERR_INVALID_ARG;
+  std::ofstream out(path, std::ios::binary);
+  if (!out) return VPCC_ERR_INVALID_ARG;
+  const std::string s = tmc2rs::PlyWriter::to_string(xyz, rgb, n);
+  out.write(s.data(), (std::streamsize)s.size());
+  return out ? VPCC_OK : VPCC_ERR_INVALID_ARG;
 }

@@ -14,6 +14,7 @@
 
 #include <condition_variable>
 #include <deque>
+#include <memory>
 #include <mutex>
 #include <optional>
 #include <string>
@@ -31,12 +32,74 @@ struct Params {                       // src/lib.rs:23-57
   explicit Params(std::string path = {}) : compressed_stream_path(std::move(path)) {}
 };
 
+// Pool of page-locked host blocks: a frame's storage is DMA'd into directly and returns to the pool when
+// the consumer drops the frame (the reference moves owned Vecs through its channel, src/decoder.rs:311).
+class PinnedPool;
+struct PinnedBlock {
+  void* ptr = nullptr;
+  size_t bytes = 0;
+  std::shared_ptr<PinnedPool> pool;   // null: plain heap memory (no GPU context, tests)
+};
+
+// Contiguous array with Vec-like read access, backed by a pooled pinned block.
+template <class T>
+class PinnedVec {
+ public:
+  PinnedVec() = default;
+  PinnedVec(PinnedVec&& o) noexcept { *this = std::move(o); }
+  PinnedVec& operator=(PinnedVec&& o) noexcept {
+    if (this != &o) { release(); blk_ = o.blk_; n_ = o.n_; o.blk_ = PinnedBlock{}; o.n_ = 0; }
+    return *this;
+  }
+  PinnedVec(const PinnedVec&) = delete;
+  PinnedVec& operator=(const PinnedVec&) = delete;
+  ~PinnedVec() { release(); }
+  void adopt(PinnedBlock b, size_t n) { release(); blk_ = std::move(b); n_ = n; }
+  size_t size() const { return n_; }
+  bool empty() const { return n_ == 0; }
+  T* data() { return static_cast<T*>(blk_.ptr); }
+  const T* data() const { return static_cast<const T*>(blk_.ptr); }
+  const T& operator[](size_t i) const { return data()[i]; }
+  T& operator[](size_t i) { return data()[i]; }
+  const T* begin() const { return data(); }
+  const T* end() const { return data() + n_; }
+
+ private:
+  void release();
+  PinnedBlock blk_;
+  size_t n_ = 0;
+};
+
 struct PointSet3 {                    // src/codec.rs:20-36 (public part)
-  std::vector<vpcc_point3> positions;
-  std::vector<vpcc_color3> colors;
+  PinnedVec<vpcc_point3> positions;
+  PinnedVec<vpcc_color3> colors;
   bool with_colors = false;
   size_t len() const { return positions.size(); }
 };
+
+class PinnedPool : public std::enable_shared_from_this<PinnedPool> {
+ public:
+  explicit PinnedPool(vpcc_ctx* ctx) : ctx_(ctx) {}
+  ~PinnedPool();
+  PinnedBlock get(size_t bytes);      // a block of at least `bytes` (empty ptr on failure)
+  void put(void* ptr, size_t bytes);
+  void detach();                      // the context is going away: free what is pooled, stop pooling
+
+ private:
+  std::mutex m_;
+  vpcc_ctx* ctx_;
+  std::vector<std::pair<void*, size_t>> free_;
+};
+
+template <class T>
+void PinnedVec<T>::release() {
+  if (blk_.ptr) {
+    if (blk_.pool) blk_.pool->put(blk_.ptr, blk_.bytes);
+    else ::operator delete(blk_.ptr);
+  }
+  blk_ = PinnedBlock{};
+  n_ = 0;
+}
 
 // Capacity-bounded single-producer/single-consumer channel with close(), like crossbeam bounded(n).
 template <class T>
@@ -116,6 +179,8 @@ enum class Format { Ascii };                  // src/writer.rs:8-12
 class PlyWriter {                             // src/writer.rs:14-74
  public:
   PlyWriter(const PointSet3& pc, Format format) : pc_(pc), format_(format) {}
+  // plain arrays (C ABI entry point)
+  static std::string to_string(const vpcc_point3* xyz, const vpcc_color3* rgb, size_t n);
   bool write(const std::string& path) const;
   std::string to_string() const;
 

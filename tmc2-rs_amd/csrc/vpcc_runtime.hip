@@ -20,8 +20,12 @@ using namespace vpcc;
 // ----------------------------------------------------------------- objects
 struct vpcc_ctx {
   int device = 0;
-  hipStream_t stream = nullptr;
+  hipStream_t stream = nullptr;        // kernels and D2H
+  hipStream_t copy_stream = nullptr;   // H2D plane ingest: overlaps the kernels of the previous GOF
   std::string last_error;
+  // Arenas of destroyed GOFs are kept for the next GOF of the same shape: hipMalloc/hipFree cost
+  // milliseconds and hipFree synchronises the whole device, which would stall a GOF pipeline.
+  std::vector<std::pair<void*, size_t>> arena_cache;
 };
 
 struct KernelTiming {
@@ -118,7 +122,8 @@ extern "C" int vpcc_ctx_create(int device_id, vpcc_ctx** out) {
   if (hipSetDevice(device_id) != hipSuccess) return VPCC_ERR_NO_DEVICE;
   vpcc_ctx* ctx = new vpcc_ctx();
   ctx->device = device_id;
-  if (hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) != hipSuccess) {
+  if (hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) != hipSuccess ||
+      hipStreamCreateWithFlags(&ctx->copy_stream, hipStreamNonBlocking) != hipSuccess) {
     delete ctx;
     return VPCC_ERR_DEVICE;
   }
@@ -129,11 +134,40 @@ extern "C" int vpcc_ctx_create(int device_id, vpcc_ctx** out) {
 extern "C" void vpcc_ctx_destroy(vpcc_ctx* ctx) {
   if (!ctx) return;
   (void)hipSetDevice(ctx->device);
+  for (auto& a : ctx->arena_cache) (void)hipFree(a.first);
   if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
+  if (ctx->copy_stream) (void)hipStreamDestroy(ctx->copy_stream);
   delete ctx;
 }
 
 extern "C" const char* vpcc_last_error(const vpcc_ctx* ctx) { return ctx ? ctx->last_error.c_str() : ""; }
+
+extern "C" int vpcc_host_pin(vpcc_ctx* ctx, const void* ptr, size_t bytes) {
+  if (!ctx || !ptr || !bytes) return VPCC_ERR_INVALID_ARG;
+  HIP_TRY(ctx, hipSetDevice(ctx->device));
+  HIP_TRY(ctx, hipHostRegister(const_cast<void*>(ptr), bytes, hipHostRegisterDefault));
+  return VPCC_OK;
+}
+
+extern "C" int vpcc_host_unpin(vpcc_ctx* ctx, const void* ptr) {
+  if (!ctx || !ptr) return VPCC_ERR_INVALID_ARG;
+  HIP_TRY(ctx, hipSetDevice(ctx->device));
+  HIP_TRY(ctx, hipHostUnregister(const_cast<void*>(ptr)));
+  return VPCC_OK;
+}
+
+extern "C" int vpcc_host_alloc(vpcc_ctx* ctx, size_t bytes, void** out) {
+  if (!ctx || !out || !bytes) return VPCC_ERR_INVALID_ARG;
+  HIP_TRY(ctx, hipSetDevice(ctx->device));
+  HIP_TRY(ctx, hipHostMalloc(out, bytes, hipHostMallocDefault));
+  return VPCC_OK;
+}
+
+extern "C" int vpcc_host_free(vpcc_ctx* ctx, void* ptr) {     // ctx may be NULL (context already destroyed)
+  if (!ptr) return VPCC_ERR_INVALID_ARG;
+  if (ctx) HIP_TRY(ctx, hipSetDevice(ctx->device));
+  return hipHostFree(ptr) == hipSuccess ? VPCC_OK : VPCC_ERR_DEVICE;
+}
 
 extern "C" int vpcc_frame_validate(const vpcc_frame_desc* frame) { return validate_frame(frame); }
 
@@ -148,13 +182,18 @@ extern "C" void vpcc_gof_destroy(vpcc_gof* gof) {
   (void)hipSetDevice(gof->ctx->device);
   if (gof->last_stream) (void)hipStreamSynchronize(gof->last_stream);
   (void)hipStreamSynchronize(gof->ctx->stream);
+  (void)hipStreamSynchronize(gof->ctx->copy_stream);
   for (auto& t : gof->timings) {
     (void)hipEventDestroy(t.start);
     (void)hipEventDestroy(t.stop);
   }
   if (gof->upload_done) (void)hipEventDestroy(gof->upload_done);
   if (gof->smooth_grid) (void)hipFree(gof->smooth_grid);
-  if (gof->arena) (void)hipFree(gof->arena);
+  if (gof->arena) {                                   // all work on it is complete (streams synchronised above)
+    auto& cache = gof->ctx->arena_cache;
+    if (cache.size() < 4) cache.emplace_back(gof->arena, gof->arena_bytes);
+    else (void)hipFree(gof->arena);
+  }
   if (gof->h_counts) (void)hipHostFree(gof->h_counts);
   delete gof;
 }
@@ -259,7 +298,16 @@ int gof_create_impl(vpcc_ctx* ctx, const vpcc_frame_desc* frames, uint32_t n_fra
     }
   }
   g->arena_bytes = L.total;
-  HIP_TRY(ctx, hipMalloc(&g->arena, g->arena_bytes));
+  for (size_t k = 0; k < ctx->arena_cache.size(); ++k) {          // smallest cached arena that fits
+    auto& a = ctx->arena_cache[k];
+    if (a.second >= L.total && a.second <= L.total + L.total / 4) {
+      g->arena = a.first;
+      g->arena_bytes = a.second;
+      ctx->arena_cache.erase(ctx->arena_cache.begin() + k);
+      break;
+    }
+  }
+  if (!g->arena) HIP_TRY(ctx, hipMalloc(&g->arena, g->arena_bytes));
   char* base = (char*)g->arena;
   g->d_frames = (DevFrame*)(base + off_frames);
   g->d_counts = (uint32_t*)(base + off_counts);
@@ -270,8 +318,8 @@ int gof_create_impl(vpcc_ctx* ctx, const vpcc_frame_desc* frames, uint32_t n_fra
   HIP_TRY(ctx, hipHostMalloc((void**)&g->h_counts, sizeof(uint32_t) * 2 * n_frames, hipHostMallocDefault));
   HIP_TRY(ctx, hipEventCreateWithFlags(&g->upload_done, hipEventDisableTiming));
 
-  // 3. fill descriptors and upload
-  hipStream_t s = ctx->stream;
+  // 3. fill descriptors and upload (plane ingest on the copy stream)
+  hipStream_t s = ctx->copy_stream;
   for (uint32_t i = 0; i < n_frames; ++i) {
     const vpcc_frame_desc& F = frames[i];
     const FramePlan& P = g->plans[i];
@@ -352,8 +400,9 @@ int gof_create_impl(vpcc_ctx* ctx, const vpcc_frame_desc* frames, uint32_t n_fra
   HIP_TRY(ctx, hipMemsetAsync(g->d_counts, 0, sizeof(uint32_t) * n_frames, s));
   HIP_TRY(ctx, hipMemsetAsync(base + ctrl_begin, 0, g->ctrl_bytes, s));
   HIP_TRY(ctx, hipEventRecord(g->upload_done, s));
-  // the host staging vectors (plans) must stay alive until the copies are done
-  HIP_TRY(ctx, hipStreamSynchronize(s));
+  // descriptor staging (plans, h_frames) lives in the gof; the caller's planes must outlive the copies,
+  // so creation is synchronous unless the caller asked for overlapping ingest
+  if (!(gof_flags & VPCC_GOF_ASYNC_UPLOAD) || kind != VPCC_MEM_HOST) HIP_TRY(ctx, hipStreamSynchronize(s));
   return VPCC_OK;
 }
 
@@ -410,6 +459,7 @@ extern "C" int vpcc_gof_reconstruct(vpcc_gof* g, uint32_t first, uint32_t count,
     return fail(ctx, VPCC_ERR_INVALID_ARG, "frame range");
   HIP_TRY(ctx, hipSetDevice(ctx->device));
   hipStream_t s = hip_stream ? (hipStream_t)hip_stream : ctx->stream;
+  HIP_TRY(ctx, hipStreamWaitEvent(s, g->upload_done, 0));        // the planes' H2D copies (copy stream) come first
   g->last_stream = s;
   g->counts_valid = false;
   g->n_timed = 0;

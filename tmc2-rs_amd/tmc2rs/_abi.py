@@ -199,6 +199,9 @@ def load_library():
     lib.vpcc_decoder_recv_frame.argtypes = [vp, C.POINTER(sz), C.POINTER(vp), C.POINTER(vp)]
     lib.vpcc_decoder_error.argtypes = [vp]
     lib.vpcc_decoder_error.restype = C.c_char_p
+    lib.vpcc_decoder_drain.argtypes = [vp, C.POINTER(u64), C.POINTER(u64), C.POINTER(C.c_double)]
+    lib.vpcc_host_pin.argtypes = [vp, vp, sz]
+    lib.vpcc_host_unpin.argtypes = [vp, vp]
     lib.vpcc_decoder_close.argtypes = [vp]
     lib.vpcc_decoder_close.restype = None
     lib.vpcc_write_ply.argtypes = [C.c_char_p, vp, vp, sz]

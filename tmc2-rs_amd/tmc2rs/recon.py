@@ -224,6 +224,14 @@ class Decoder:
                 C.memmove(rgb.ctypes.data, pc.value, k * 3)
         return {"n": k, "xyz": xyz, "rgb": rgb if pc.value else None}
 
+    def drain(self):
+        """Consumes the rest of the stream inside the library; returns (frames, points, seconds)."""
+        nf, npts, sec = C.c_uint64(0), C.c_uint64(0), C.c_double(0)
+        st = self.lib.vpcc_decoder_drain(self.h, C.byref(nf), C.byref(npts), C.byref(sec))
+        if st:
+            raise VpccError(st, "vpcc_decoder_drain", self.error())
+        return nf.value, npts.value, sec.value
+
     def __iter__(self):
         return self
 
