@@ -281,6 +281,44 @@ void vpcc_decoder_close(vpcc_decoder* dec);
 /* writer::PlyWriter::write, ASCII (src/writer.rs:25-74); rgb may be NULL (no colour properties). */
 int  vpcc_write_ply(const char* path, const vpcc_point3* xyz, const vpcc_color3* rgb, size_t n_points);
 
+/* -------------------------------------------- syntax side (host only) */
+/* V3C bit reader (src/bitstream.rs:53-190): read/peek MSB-first, Exp-Golomb, byte_align, copy_from. */
+typedef struct vpcc_bitstream vpcc_bitstream;
+vpcc_bitstream* vpcc_bs_new(const uint8_t* data, size_t n);
+void  vpcc_bs_free(vpcc_bitstream* bs);
+int   vpcc_bs_read(vpcc_bitstream* bs, unsigned bits, uint32_t* out);
+int   vpcc_bs_peek(vpcc_bitstream* bs, unsigned bits, uint32_t* out);
+int   vpcc_bs_read_uvlc(vpcc_bitstream* bs, uint32_t* out);
+int   vpcc_bs_read_svlc(vpcc_bitstream* bs, int32_t* out);
+int   vpcc_bs_byte_align(vpcc_bitstream* bs);
+void  vpcc_bs_reset(vpcc_bitstream* bs);
+int   vpcc_bs_copy_from(vpcc_bitstream* dst, vpcc_bitstream* src, size_t start_byte, size_t size);
+size_t vpcc_bs_data(const vpcc_bitstream* bs, const uint8_t** data);
+void  vpcc_bs_position(const vpcc_bitstream* bs, size_t* bytes, unsigned* bits);
+/* SampleStreamV3CUnit::from_bitstream (src/bitstream/reader.rs:623-670): unit types (data[0] >> 3),
+ * payload offsets and sizes of a V3C sample stream. */
+int   vpcc_v3c_split(const uint8_t* data, size_t n, uint32_t max_units, uint8_t* types, size_t* offsets,
+                     size_t* sizes, uint32_t* n_units, size_t* header_size);
+/* VideoBitstream::sample_stream_to_bytestream (src/bitstream.rs:216-289): 4-byte NAL length prefixes ->
+ * Annex-B start codes (codec_id 0 H264, 1 H265, 2 H266), for an external video decoder. */
+int   vpcc_sample_stream_to_bytestream(const uint8_t* data, size_t n, int codec_id, uint8_t* out,
+                                       size_t out_capacity, size_t* out_size);
+/* Patch-table builder: one Intra patch data unit -> vpcc_patch (create_patch_frame, src/decoder.rs:415-486). */
+typedef struct vpcc_patch_frame_params {
+  uint32_t log2_patch_packing_block_size;   /* asps                                               */
+  uint32_t geometry_3d_bitdepth;            /* asps.geometry_3d_bitdepth_minus1 + 1               */
+  uint32_t pos_min_d_quantizer;             /* ath                                                */
+  uint32_t patch_size_quantizer_present_flag, patch_size_info_quantizer_x, patch_size_info_quantizer_y;
+  uint32_t plr_enabled_flag;
+  uint32_t reserved;
+} vpcc_patch_frame_params;
+typedef struct vpcc_intra_pdu {
+  uint32_t pos_2d_x, pos_2d_y, size_2d_x_minus1, size_2d_y_minus1;
+  uint32_t pos_3d_offset_u, pos_3d_offset_v, pos_3d_offset_d, pos_3d_range_d;
+  uint32_t projection_id, orientation_index, lod_enabled_flag, reserved;
+} vpcc_intra_pdu;
+int   vpcc_patch_from_intra_pdu(const vpcc_patch_frame_params* fp, const vpcc_intra_pdu* pdu, vpcc_patch* out);
+
 #ifdef __cplusplus
 }
 #endif
