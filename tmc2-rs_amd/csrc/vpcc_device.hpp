@@ -108,7 +108,8 @@ void launch_block_owner(const DevFrame* d_frames, uint32_t first, uint32_t count
 void launch_count(const DevFrame* d_frames, uint32_t first, uint32_t count, uint32_t max_vb, void* stream);
 void launch_scan(const DevFrame* d_frames, uint32_t first, uint32_t count, void* stream);
 void launch_emit(const DevFrame* d_frames, uint32_t first, uint32_t count, uint32_t max_vb, void* stream);
-void launch_tiles(const DevFrame* d_frames, uint32_t first, uint32_t count, uint32_t max_groups, void* stream);
+void launch_tiles(const DevFrame* d_frames, uint32_t first, uint32_t count, uint32_t max_groups, uint32_t gen,
+                  void* stream);
 void launch_upsample_occupancy(const DevFrame* d_frames, uint32_t frame, uint8_t* d_out, uint32_t width,
                                uint32_t height, void* stream);
 

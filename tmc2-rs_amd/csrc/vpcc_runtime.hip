@@ -62,6 +62,7 @@ struct vpcc_gof {
   hipStream_t last_stream = nullptr;
   std::vector<KernelTiming> timings;
   uint32_t n_timed = 0;
+  uint32_t generation = 0;             // launch counter of the tile kernel (tags look-back words)
   void* smooth_grid = nullptr;         // dense cell grids of the smoothing filters (scratch, on demand)
   size_t smooth_bytes = 0;
 };
@@ -470,17 +471,12 @@ extern "C" int vpcc_gof_reconstruct(vpcc_gof* g, uint32_t first, uint32_t count,
     uint32_t max_groups = 0;
     for (uint32_t i = first; i < first + count; ++i)
       max_groups = std::max(max_groups, (uint32_t)(g->scan_off[i + 1] - g->scan_off[i]));
-    HIP_TRY(ctx, hipMemsetAsync(g->d_counts + first, 0, sizeof(uint32_t) * count, s));
-    if (first == 0 && count == g->n_frames) {
-      HIP_TRY(ctx, hipMemsetAsync(g->d_tickets, 0, g->ctrl_bytes, s));
-    } else {
-      HIP_TRY(ctx, hipMemsetAsync(g->d_tickets + 64 * (size_t)first, 0, 256 * (size_t)count, s));
-      HIP_TRY(ctx, hipMemsetAsync(g->d_errors + first, 0, sizeof(uint32_t) * count, s));
-      const size_t w0 = g->scan_off[first], w1 = g->scan_off[first + count];
-      if (w1 > w0) HIP_TRY(ctx, hipMemsetAsync(g->d_scan + w0, 0, sizeof(uint64_t) * (w1 - w0), s));
-    }
+    // Nothing to clear: look-back words carry the launch generation, every ticket counter is re-armed by
+    // the last workgroup that draws from it, and a frame's point count is rewritten by its last group
+    // (a frame without tiles keeps the zero written at creation).
+    g->generation = (g->generation % 0x3FFFFFFFu) + 1u;
     T.begin("k_recon_tiles");
-    launch_tiles(g->d_frames, first, count, max_groups, s);
+    launch_tiles(g->d_frames, first, count, max_groups, g->generation, s);
     T.end();
     HIP_TRY(ctx, hipGetLastError());
     g->launched = true;

@@ -45,7 +45,10 @@ namespace vpcc {
 
 namespace {
 
-constexpr uint64_t kStatusShift = 62;
+// Look-back word: {generation:30 | status:2 | value:32}.  The generation is the launch counter of the
+// gof: words written by earlier launches read as EMPTY, so nothing has to be cleared between launches.
+constexpr uint64_t kStatusShift = 32;
+constexpr uint64_t kGenShift = 34;
 constexpr uint64_t kAggregate = 1ull << kStatusShift;
 constexpr uint64_t kPrefix = 2ull << kStatusShift;
 constexpr uint32_t kSpinLimit = 1u << 22;
@@ -58,27 +61,31 @@ __device__ __forceinline__ void st_store(uint64_t* p, uint64_t v) {
 }
 
 // Exclusive prefix of group `g` within its frame.  One full wave; same result in every lane.
-__device__ uint32_t look_back_groups(const DevFrame& f, uint32_t g) {
+__device__ __forceinline__ uint32_t status_of(uint64_t s, uint32_t gen) {
+  return (uint32_t)(s >> kGenShift) == gen ? (uint32_t)(s >> kStatusShift) & 3u : 0u;
+}
+
+__device__ uint32_t look_back_groups(const DevFrame& f, uint32_t g, uint32_t gen) {
   uint32_t excl = 0;
   int32_t idx = (int32_t)g - 1;
   const uint32_t lane = lane_id();
   while (idx >= 0) {
     const int32_t my = idx - (int32_t)lane;
-    uint64_t s = kPrefix;
+    uint64_t s = ((uint64_t)gen << kGenShift) | kPrefix;
     if (my >= 0) {
       uint32_t spins = 0;
       s = st_load(f.scan_state + my);
-      while ((s >> kStatusShift) == 0) {
+      while (status_of(s, gen) == 0) {
         __builtin_amdgcn_s_sleep(8);
         if (++spins > kSpinLimit) {               // never reached in a healthy run; reported by the host
           atomicOr(f.error_flag, 1u);
-          s = kPrefix;
+          s = ((uint64_t)gen << kGenShift) | kPrefix;
           break;
         }
         s = st_load(f.scan_state + my);
       }
     }
-    const uint64_t pm = __ballot((s >> kStatusShift) == 2);
+    const uint64_t pm = __ballot(status_of(s, gen) == 2);
     const uint32_t firstp = pm ? (uint32_t)__builtin_ctzll(pm) : 64u;
     uint32_t v = lane <= firstp ? (uint32_t)s : 0u;
     for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
@@ -421,7 +428,8 @@ __device__ __forceinline__ void store_rgb(VPCC_GLOBAL unsigned char* base, uint3
 // 8 skip colour conversion, 16 skip global stores, 64 in-kernel stamps (diagnostic build path).
 template <bool kStamps>
 __global__ __launch_bounds__(256) void k_recon_tiles(const DevFrame* __restrict__ frames, uint32_t first,
-                                                     uint32_t count, uint32_t groups_stride, uint32_t variant) {
+                                                     uint32_t count, uint32_t groups_stride, uint32_t gen,
+                                                     uint32_t variant) {
   // XCD-aware placement (speed only): ids equal mod 8 share an XCD/L2; a frame stays on one label.
   // The frames of one label are interleaved: consecutive groups of ONE frame then start a few
   // workgroup slots apart, which gives a group's predecessors a head start and shortens its look-back
@@ -440,7 +448,12 @@ __global__ __launch_bounds__(256) void k_recon_tiles(const DevFrame* __restrict_
 
   [[maybe_unused]] unsigned long long t_prev = kStamps ? stamp() : 0ull;
   [[maybe_unused]] unsigned long long t_acc[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
-  if (threadIdx.x == 0) s_group = __hip_atomic_fetch_add(glw(f.ticket), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  if (threadIdx.x == 0) {
+    const uint32_t t = __hip_atomic_fetch_add(glw(f.ticket), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    // exactly groups_stride workgroups of this launch draw from this counter: the last one re-arms it
+    if (t + 1u == groups_stride) __hip_atomic_store(glw(f.ticket), 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    s_group = t;
+  }
   __syncthreads();
   const uint32_t g = __builtin_amdgcn_readfirstlane(s_group);
   const uint32_t n_groups = (f.n_tiles + kTileItemsPerGroup - 1u) / kTileItemsPerGroup;
@@ -455,27 +468,27 @@ __global__ __launch_bounds__(256) void k_recon_tiles(const DevFrame* __restrict_
   // what IS kept is what the loop's loads would otherwise have to wait for: the four occupancy
   // nibbles (one register) and the item descriptors (LDS).  On CDNA4 vmcnt retires in order and counts
   // stores, so any dependent load inside the loop would also drain the previous item's stores.
-  uint32_t occ_all = 0;
-  {
-    Item it4[K];
-    Samples s4[K];
+  uint64_t occ_all = 0, dup_all = 0;                   // one occupancy / duplicate nibble per item of this wave
+  for (uint32_t c0 = 0; c0 < K; c0 += 4u) {            // four items' loads in flight at a time
+    Item it4[4];
+    Samples s4[4];
 #pragma unroll
-    for (int i = 0; i < (int)K; ++i) {
-      const bool valid = item0 + i < f.n_tiles;
-      it4[i] = load_item(f.tiles + (valid ? item0 + i : 0u));
-      if (lane == 0) store_item(s_items[wave * K + i], it4[i]);
+    for (int i = 0; i < 4; ++i) {
+      const bool valid = item0 + c0 + i < f.n_tiles;
+      it4[i] = load_item(f.tiles + (valid ? item0 + c0 + i : 0u));
+      if (lane == 0) store_item(s_items[wave * K + c0 + i], it4[i]);
       s4[i].occ = load_occupancy(f, it4[i], valid, lane);
-      occ_all |= s4[i].occ << (4 * i);
+      occ_all |= (uint64_t)s4[i].occ << (4u * (c0 + i));
     }
 #pragma unroll
-    for (int i = 0; i < (int)K; ++i) load_geometry(f, it4[i], lane, s4[i]);
+    for (int i = 0; i < 4; ++i) load_geometry(f, it4[i], lane, s4[i]);
 #pragma unroll
-    for (int i = 0; i < (int)K; ++i) {
+    for (int i = 0; i < 4; ++i) {
       uint32_t dup, cnt;
       classify(f, it4[i], s4[i], dup, cnt);
-      occ_all |= (dup & s4[i].occ) << (16 + 4 * i);     // the per-item loop reuses the duplicate mask
+      dup_all |= (uint64_t)(dup & s4[i].occ) << (4u * (c0 + i));       // the per-item loop reuses the duplicate mask
       for (int off = 32; off > 0; off >>= 1) cnt += __shfl_xor(cnt, off, 64);
-      if (lane == 0) s_tot[wave * K + i] = cnt;
+      if (lane == 0) s_tot[wave * K + c0 + i] = cnt;
     }
   }
   VPCC_STAMP(1)                                         // occupancy + geometry of 4 items, counted
@@ -485,19 +498,19 @@ __global__ __launch_bounds__(256) void k_recon_tiles(const DevFrame* __restrict_
   // ---- 2. publish the group total and look back (wave 0); every wave prefetches its first item ----
   Item it = fetch_item(s_items[wave * K]);
   Samples cur;
-  cur.occ = occ_all & 0xFu;
+  cur.occ = (uint32_t)occ_all & 0xFu;
   load_geometry(f, it, lane, cur);
   load_attributes(f, it, lane, cur);
 
   if (wave == 0) {
     uint32_t total = lane < kTileItemsPerGroup ? s_tot[lane] : 0u;
-    for (int off = 16; off > 0; off >>= 1) total += __shfl_xor(total, off, 64);
+    for (int off = 32; off > 0; off >>= 1) total += __shfl_xor(total, off, 64);
     total = __shfl(total, 0, 64);
-    if (lane == 0) st_store(f.scan_state + g, (g == 0 ? kPrefix : kAggregate) | total);
+    if (lane == 0) st_store(f.scan_state + g, ((uint64_t)gen << kGenShift) | (g == 0 ? kPrefix : kAggregate) | total);
     uint32_t excl = 0;
     if (g != 0 && !(variant & 1u)) {
-      excl = look_back_groups(f, g);
-      if (lane == 0) st_store(f.scan_state + g, kPrefix | (uint64_t)(excl + total));
+      excl = look_back_groups(f, g, gen);
+      if (lane == 0) st_store(f.scan_state + g, ((uint64_t)gen << kGenShift) | kPrefix | (uint64_t)(excl + total));
     }
     if (lane == 0) {
       s_base = excl;
@@ -523,14 +536,14 @@ __global__ __launch_bounds__(256) void k_recon_tiles(const DevFrame* __restrict_
     nxt.occ = 0;
     if (i + 1u < K) {
       nit = fetch_item(s_items[wave * K + i + 1u]);
-      nxt.occ = (occ_all >> (4u * (i + 1u))) & 0xFu;
+      nxt.occ = (uint32_t)(occ_all >> (4u * (i + 1u))) & 0xFu;
     }
     load_geometry(f, nit, lane, nxt);
     load_attributes(f, nit, lane, nxt);
 
     if (n != 0) {                                       // wave-uniform
       uint32_t rk[4];
-      const uint32_t dup = (occ_all >> (16u + 4u * i)) & 0xFu;          // from the count phase
+      const uint32_t dup = (uint32_t)(dup_all >> (4u * i)) & 0xFu;       // from the count phase
       const uint32_t cnt = 2u * (uint32_t)__builtin_popcount(cur.occ) - (uint32_t)__builtin_popcount(dup);
       pixel_ranks(it, cur, dup, cnt, lane, reinterpret_cast<unsigned char*>(slots), rk);
       // patch-local offsets of the lane's pixels: Default (du, dv) = (4q + j, r); Swap (du, dv) = (r, 4q + j)
@@ -618,7 +631,8 @@ extern "C" int vpcc_debug_read_stamps(unsigned long long* out16, int reset) {
 
 namespace vpcc {
 
-void launch_tiles(const DevFrame* d_frames, uint32_t first, uint32_t count, uint32_t max_groups, void* stream) {
+void launch_tiles(const DevFrame* d_frames, uint32_t first, uint32_t count, uint32_t max_groups, uint32_t gen,
+                  void* stream) {
   if (!count || !max_groups) return;
   static const uint32_t variant = [] {
     const char* e = getenv("VPCC_TILES_VARIANT");
@@ -628,10 +642,10 @@ void launch_tiles(const DevFrame* d_frames, uint32_t first, uint32_t count, uint
   const uint32_t grid = 8u * frame_groups * max_groups;
   if (variant & 64u)
     hipLaunchKernelGGL(k_recon_tiles<true>, dim3(grid), dim3(256), 0, (hipStream_t)stream, d_frames, first, count,
-                       max_groups, variant);
+                       max_groups, gen, variant);
   else
     hipLaunchKernelGGL(k_recon_tiles<false>, dim3(grid), dim3(256), 0, (hipStream_t)stream, d_frames, first, count,
-                       max_groups, variant);
+                       max_groups, gen, variant);
 }
 
 }  // namespace vpcc
