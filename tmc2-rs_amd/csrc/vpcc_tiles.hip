@@ -15,20 +15,20 @@
 //   group  = one 256-thread workgroup = 4 waves = 16 consecutive items = one ticket and one
 //            look-back word.
 //
-// Per group
-//   1. count: occupancy + both geometry layers of the 16 items; a D1 point is dropped when it equals
-//      the D0 point (src/codec.rs:422-427); the group total is published;
-//   2. wave 0 obtains the group's output offset by decoupled look-back over the earlier groups of
-//      the frame, while every wave already fetches its first item's samples again (L2-hot);
-//   3. per item (rolled loop, next item's samples prefetched): every lane writes one 8-B record
-//      {depth, pixel, layer | Y, U, V} per point into the wave's LDS slots at the point's rank
+// Per workgroup: a short pipeline over groups of ONE frame (tickets drawn dynamically)
+//   1. count the NEXT group: occupancy + both geometry layers of its 16 items; a D1 point is dropped
+//      when it equals the D0 point (src/codec.rs:422-427); the group total is published;
+//   2. wave 0 obtains the CURRENT group's output offset by decoupled look-back over the earlier groups
+//      of the frame (its total was published one step ago), while every wave already fetches its
+//      first item's samples again (L2-hot);
+//   3. per item (rolled loop, next item's samples prefetched): colour conversion of the lane's 8
+//      samples (src/codec.rs:661-687; vpcc_colour.h), then every lane writes one 8-B record
+//      {depth, du, dv, layer | r, g, b} per point into the wave's LDS slots at the point's rank
 //      (= compaction in emission order); then lane <-> point: back-projection
-//      (src/decoder.rs:871-888), colour conversion (src/codec.rs:661-687) and contiguous stores
-//      (6 + 3 bytes per lane: the pattern that streams best on gfx950, tools/micro/store_bw.hip).
-//   PMC counters and in-kernel stamps (tools/pmc.sh, tools/stamps.py) show wave lifetime — the
-//   chain of dependent memory round trips — and instruction issue bounding this kernel, not HBM:
-//   hence the dense lane<->point loop with one colour site, the exact INTEGER colour path, the
-//   axes-specialised packing and the small code footprint.
+//      (src/decoder.rs:871-888) and contiguous stores (12 + 6 bytes per lane for two points).
+//   PMC counters, in-kernel stamps and ablations (tools/pmc.sh, tools/stamps.py, tools/variants.sh)
+//   show instruction issue and wave lifetime bounding this kernel, not HBM: hence the division-free
+//   colour path, the byte-permute point assembly, DPP scans and unconditional record writes.
 //
 // Cross-workgroup ordering is placement-independent (cdna_hip_programming.md §6 Guideline 16):
 // groups are drawn from a per-frame TICKET counter, so a look-back only waits for tickets that
@@ -39,6 +39,7 @@
 #include <cstdlib>
 
 #include "vpcc_device.hpp"
+#include "vpcc_colour.h"
 #include "vpcc_devfn.hpp"
 
 namespace vpcc {
@@ -245,24 +246,37 @@ __device__ __forceinline__ void classify(const DevFrame& f, const Item& it, cons
 }
 
 // {x | y << 16, z} of a point as the reference builds it (src/decoder.rs:871-888): assignment order
-// normal, tangent, bitangent, `as u16` truncation.  The three axis tables of set_view_id
-// (src/decoder.rs:790-796) get straight-line code; anything else takes the generic selects.
-__device__ __forceinline__ uint2 pack_point(const Item& it, uint32_t n, uint32_t t, uint32_t b) {
-  n &= 0xFFFFu; t &= 0xFFFFu; b &= 0xFFFFu;
-  if (it.axes == (0u | (2u << 2) | (1u << 4))) return make_uint2(n | (b << 16), t);   // axes (0,2,1)
-  if (it.axes == (1u | (2u << 2) | (0u << 4))) return make_uint2(b | (n << 16), t);   // axes (1,2,0)
-  if (it.axes == (2u | (0u << 2) | (1u << 4))) return make_uint2(t | (b << 16), n);   // axes (2,0,1)
+// normal, tangent, bitangent, `as u16` truncation.  The axes are wave-uniform per item, so the
+// assignment becomes two byte permutes with per-item selectors: coordinate a takes bitangent if
+// bitangent_axis == a, else tangent if tangent_axis == a, else normal if normal_axis == a, else 0.
+struct PointSel { uint32_t xy, z; uint32_t nmin; int32_t nsign; };
+
+__device__ __forceinline__ PointSel point_selectors(const Item& it) {
   const uint32_t na = it.axes & 3u, ta = (it.axes >> 2) & 3u, ba = (it.axes >> 4) & 3u;
   uint32_t c[3];
 #pragma unroll
   for (uint32_t a = 0; a < 3; ++a) {
-    uint32_t v = 0;
-    if (na == a) v = n;
-    if (ta == a) v = t;
-    if (ba == a) v = b;
+    uint32_t v = 0x0C0Cu;                       // constant 0
+    if (na == a) v = 0x0100u;                   // bytes 0,1 of {n | t << 16}
+    if (ta == a) v = 0x0302u;                   // bytes 2,3
+    if (ba == a) v = 0x0504u;                   // bytes 0,1 of b
     c[a] = v;
   }
-  return make_uint2(c[0] | (c[1] << 16), c[2]);
+  PointSel s;
+  s.xy = c[0] | (c[1] << 16);
+  s.z = c[2] | 0x0C0C0000u;
+  // normal coordinate (decoder.rs:881-888): mode 0: depth + d1; mode 1: max(d1, depth) - depth = d1 - min(depth, d1)
+  s.nmin = (it.flags & kTileMode1) ? it.d1 : 0xFFFFFFFFu;
+  s.nsign = (it.flags & kTileMode1) ? -1 : 1;
+  return s;
+}
+
+__device__ __forceinline__ uint2 pack_point(const Item& it, const PointSel& s, uint32_t depth, uint32_t du, uint32_t dv) {
+  const uint32_t m = depth < s.nmin ? depth : s.nmin;                       // depth < 2^14
+  const uint32_t n = (uint32_t)((int32_t)m * s.nsign) + it.d1;
+  const uint32_t t = it.tb + du * it.lod_x, b = it.bb + dv * it.lod_y;
+  const uint32_t nt = __builtin_amdgcn_perm(t, n, 0x05040100u);             // n (low half) | t << 16
+  return make_uint2(__builtin_amdgcn_perm(b, nt, s.xy), __builtin_amdgcn_perm(b, nt, s.z));
 }
 
 // D1 point in relative mode (src/codec.rs:551-559): point0 with +-d1 on coordinate index normal_axis.
@@ -275,69 +289,64 @@ __device__ __forceinline__ uint2 relative_point(const Item& it, uint2 p0, uint32
   return make_uint2(c[0] | (c[1] << 16), c[2]);
 }
 
-// ---- convert_yuv10_to_rgb8 (src/codec.rs:661-687), exact integer form --------------------------
-// With T = c*255/1023 the reference's result is clamp(floor(p)), p = fl(fl(c/1023)*255), |p - T| < 2e-13
-// for 10-bit samples (two roundings of the division/multiplication plus the roundings inside c).
-// Using the decimal coefficients, T is the rational
-//     R: 17*(2500*Y + 3937*dv) / 170500        G: 17*(100000*Y - 18733*du - 46813*dv) / 6820000
-//     B: 17*(100000*Y + 185563*du) / 6820000   (du = U-512, dv = V-512; the double constants differ
-// from the decimals by < 1.2e-16, i.e. by < 3e-14 in T).  A non-integer T is at least 1/6820000 away
-// from every integer, far more than those errors, so floor(p) == floor(T) == integer quotient; when
-// the division is exact (10 364 of the 2^30 triplets, e.g. grey with luma a multiple of 341) the lane
-// takes the IEEE f64 path.  Verified against the f64 formula on all 2^30 10-bit triplets
-// (tests/colour_exhaustive.c).  Samples above 1023 also take the f64 path.
-__device__ __forceinline__ int colour_channel(int32_t n, uint32_t d) {
-  if (n <= 0) return 0;
-  const uint32_t x = 17u * (uint32_t)n;
-  const uint32_t q = x / d;
-  if (q * d == x) return -1;
-  return q > 255u ? 255 : (int)q;
+// ---- convert_yuv10_to_rgb8 (src/codec.rs:661-687) for the lane's 4 pixels of one layer ------------
+// vpcc_colour.h: f64 FMAs on a 2^-20 grid whose low dword is the fixed-point result — no division, no
+// floor, no float compare.  Pixels 0,1 and 2,3 share a chroma sample (src/decoder.rs:977), so the
+// chroma part of each channel is evaluated once per pair.  When a fraction pattern could hide an exact
+// integer (2.4e-5 of all triplets; checked on the whole 10-bit cube by tests/colour_exhaustive.c) or a
+// sample exceeds 10 bits, the lane evaluates the reference formula itself.
+__device__ __forceinline__ uint32_t colour_exact(uint32_t Y, uint32_t U, uint32_t V) {
+  const vpcc_color3 c = yuv10_to_rgb8((uint16_t)Y, (uint16_t)U, (uint16_t)V);
+  return (uint32_t)c.r | ((uint32_t)c.g << 8) | ((uint32_t)c.b << 16);
 }
 
-__device__ __forceinline__ uint32_t yuv10_to_rgb8_int(uint32_t Y, uint32_t U, uint32_t V) {
-  const int32_t y = (int32_t)Y, du = (int32_t)U - 512, dv = (int32_t)V - 512;
-  const int r = colour_channel(2500 * y + 3937 * dv, 170500u);
-  const int g = colour_channel(100000 * y - 18733 * du - 46813 * dv, 6820000u);
-  const int b = colour_channel(100000 * y + 185563 * du, 6820000u);
-  uint32_t rgb = (uint32_t)r | ((uint32_t)g << 8) | ((uint32_t)b << 16);
-  if ((Y | U | V) > 1023u || (r | g | b) < 0) {       // rare: exact IEEE division path
-    const vpcc_color3 c = yuv10_to_rgb8((uint16_t)Y, (uint16_t)U, (uint16_t)V);
-    rgb = (uint32_t)c.r | ((uint32_t)c.g << 8) | ((uint32_t)c.b << 16);
+__device__ __forceinline__ void colours4(const Px4& y, uint32_t u, uint32_t v, uint32_t rgb[4]) {
+  const vpcc_chroma_part c01 = vpcc_colour_chroma(u & 0xFFFFu, v & 0xFFFFu);
+  const vpcc_chroma_part c23 = vpcc_colour_chroma(u >> 16, v >> 16);
+  uint32_t amb = (y.lo | y.hi | u | v) & 0xFC00FC00u;             // a sample wider than 10 bits
+  rgb[0] = vpcc_colour_luma(px<0>(y), c01, &amb);
+  rgb[1] = vpcc_colour_luma(px<1>(y), c01, &amb);
+  rgb[2] = vpcc_colour_luma(px<2>(y), c23, &amb);
+  rgb[3] = vpcc_colour_luma(px<3>(y), c23, &amb);
+  if (amb) {                                                       // rare
+    rgb[0] = colour_exact(px<0>(y), u & 0xFFFFu, v & 0xFFFFu);
+    rgb[1] = colour_exact(px<1>(y), u & 0xFFFFu, v & 0xFFFFu);
+    rgb[2] = colour_exact(px<2>(y), u >> 16, v >> 16);
+    rgb[3] = colour_exact(px<3>(y), u >> 16, v >> 16);
   }
-  return rgb;
 }
 
 // 8-B point record:
-//   x: depth | pixel << 16 | layer << 24      (pixel = 4*lane + j: du = pixel & 15, dv = pixel >> 4)
-//   y: Y | U << 10 | V << 20 | wide << 30     (wide: some sample exceeds 10 bits; the consumer then
-//                                              re-reads the three samples from the planes)
+//   x: depth | du << 16 | dv << 20 | layer << 24     (du, dv: the pixel's patch-local offsets in the block)
+//   y: r | g << 8 | b << 16
 // A D1 record always directly follows the D0 record of its pixel (relative D1 reads its depth there).
-__device__ __forceinline__ uint32_t pack_yuv(uint32_t y, uint32_t u, uint32_t v) {
-  const uint32_t wide = (y | u | v) > 1023u ? 1u : 0u;
-  return (y & 1023u) | ((u & 1023u) << 10) | ((v & 1023u) << 20) | (wide << 30);
-}
+// Writes are unconditional: an absent point goes to the lane's dump slot behind the 512 record slots.
+constexpr uint32_t kSlotsPerWave = 512u + 64u;
 
-// Writes the records of the lane's pixel J at rank `rank` (and rank + 1 for a distinct D1 point).
-// `pixel` = dv * 16 + du, the pixel's patch-local offsets inside the block.
 template <int J>
 __device__ __forceinline__ void put_records(const Samples& s, uint32_t dup, uint32_t pixel, uint32_t rank,
-                                            uint2* slots) {
-  if (!((s.occ >> J) & 1u)) return;
-  const uint32_t u0 = J < 2 ? (s.u0 & 0xFFFFu) : (s.u0 >> 16), v0 = J < 2 ? (s.v0 & 0xFFFFu) : (s.v0 >> 16);
-  slots[rank] = make_uint2((px<J>(s.g0) >> 2) | (pixel << 16), pack_yuv(px<J>(s.y0), u0, v0));
-  if (!((dup >> J) & 1u)) {
-    const uint32_t u1 = J < 2 ? (s.u1 & 0xFFFFu) : (s.u1 >> 16), v1 = J < 2 ? (s.v1 & 0xFFFFu) : (s.v1 >> 16);
-    slots[rank + 1u] = make_uint2((px<J>(s.g1) >> 2) | (pixel << 16) | (1u << 24), pack_yuv(px<J>(s.y1), u1, v1));
-  }
+                                            uint32_t dump, const uint32_t rgb0[4], const uint32_t rgb1[4], uint2* slots) {
+  const bool occ = (s.occ >> J) & 1u, second = occ && !((dup >> J) & 1u);
+  slots[occ ? rank : dump] = make_uint2((px<J>(s.g0) >> 2) | (pixel << 16), rgb0[J]);
+  slots[second ? rank + 1u : dump] = make_uint2((px<J>(s.g1) >> 2) | (pixel << 16) | (1u << 24), rgb1[J]);
 }
 
-// Inclusive scan over the 64 lanes.
-__device__ __forceinline__ uint32_t wave_inclusive_scan(uint32_t v, uint32_t lane) {
-  for (int off = 1; off < 64; off <<= 1) {
-    const uint32_t t = __shfl_up(v, off, 64);
-    if ((int)lane >= off) v += t;
-  }
+// Wave-wide inclusive scan / sum with DPP row shifts and row broadcasts (gfx9 DPP controls; no LDS).
+template <int kCtrl, int kRowMask>
+__device__ __forceinline__ uint32_t dpp_add(uint32_t v) {
+  return v + (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, kCtrl, kRowMask, 0xF, kRowMask == 0xF);
+}
+__device__ __forceinline__ uint32_t wave_inclusive_scan(uint32_t v) {
+  v = dpp_add<0x111, 0xF>(v);        // row_shr:1   (lanes shifted in from outside the row read 0)
+  v = dpp_add<0x112, 0xF>(v);        // row_shr:2
+  v = dpp_add<0x114, 0xF>(v);        // row_shr:4
+  v = dpp_add<0x118, 0xF>(v);        // row_shr:8   -> scan inside each row of 16
+  v = dpp_add<0x142, 0xA>(v);        // row_bcast:15 into rows 1 and 3
+  v = dpp_add<0x143, 0xC>(v);        // row_bcast:31 into rows 2 and 3
   return v;
+}
+__device__ __forceinline__ uint32_t wave_sum(uint32_t v) {
+  return (uint32_t)__builtin_amdgcn_readlane((int)wave_inclusive_scan(v), 63);
 }
 
 // Ranks of the lane's 4 pixels inside the item, emission order (src/codec.rs:382-385: v1 outer, u1 inner).
@@ -352,7 +361,7 @@ __device__ __forceinline__ void pixel_ranks(const Item& it, const Samples& s, ui
 #pragma unroll
   for (int j = 0; j < 4; ++j) c[j] = ((s.occ >> j) & 1u) ? (((dup >> j) & 1u) ? 1u : 2u) : 0u;
   if (!(it.flags & kTileSwap)) {
-    const uint32_t first = wave_inclusive_scan(cnt, lane) - cnt;
+    const uint32_t first = wave_inclusive_scan(cnt) - cnt;
     rk[0] = first; rk[1] = rk[0] + c[0]; rk[2] = rk[1] + c[1]; rk[3] = rk[2] + c[2];
     return;
   }
@@ -365,7 +374,7 @@ __device__ __forceinline__ void pixel_ranks(const Item& it, const Samples& s, ui
 #pragma unroll
   for (int j = 0; j < 4; ++j) t[j] = scratch[(yq + j) * 16u + x];
   const uint32_t sum = t[0] + t[1] + t[2] + t[3];
-  uint32_t r = wave_inclusive_scan(sum, lane) - sum;
+  uint32_t r = wave_inclusive_scan(sum) - sum;
 #pragma unroll
   for (int j = 0; j < 4; ++j) {
     r16[(yq + j) * 16u + x] = (uint16_t)r;
@@ -389,7 +398,7 @@ __device__ __forceinline__ unsigned long long stamp() {
 #define VPCC_STAMP(slot)                                                                  \
   if constexpr (kStamps) {                                                                  \
     const unsigned long long now_ = stamp();                                                \
-    t_acc[slot] = now_ - t_prev;                                                            \
+    t_acc[slot] += now_ - t_prev;                                                            \
     t_prev = now_;                                                                          \
   }
 #define VPCC_STAMP_FLUSH()                                                                \
@@ -425,15 +434,20 @@ __device__ __forceinline__ void store_rgb(VPCC_GLOBAL unsigned char* base, uint3
 }  // namespace
 
 // `variant`: 0 in production; timing-only ablation bits (VPCC_TILES_VARIANT): 1 skip look-back wait,
-// 8 skip colour conversion, 16 skip global stores, 64 in-kernel stamps (diagnostic build path).
+// 8 skip colour conversion, 16 skip the lane<->point loop, 32 skip only its stores, 64 in-kernel stamps (diagnostic build path).
+//
+// Every workgroup is a short pipeline over the groups of ONE frame: it draws a ticket, counts that
+// group and publishes the group total BEFORE it looks back for and emits the group it counted one
+// step earlier.  A group's look-back therefore happens a whole count phase (or a whole step) after
+// its total was published, when the totals of the earlier tickets have long arrived: the wait that
+// cost a quarter of the kernel in the count -> look back -> emit form is gone, and the plane loads
+// of the next group overlap the stores of the current one across the waves of a CU.
 template <bool kStamps>
 __global__ __launch_bounds__(256) void k_recon_tiles(const DevFrame* __restrict__ frames, uint32_t first,
                                                      uint32_t count, uint32_t groups_stride, uint32_t gen,
                                                      uint32_t variant) {
   // XCD-aware placement (speed only): ids equal mod 8 share an XCD/L2; a frame stays on one label.
-  // The frames of one label are interleaved: consecutive groups of ONE frame then start a few
-  // workgroup slots apart, which gives a group's predecessors a head start and shortens its look-back
-  // wait (measured: 0.05 -> 0.02 ms per 32-frame batch against one-frame-at-a-time).
+  // The frames of one label are interleaved, so the workgroups of ONE frame start a few slots apart.
   const uint32_t xcd = blockIdx.x & 7u, slot = blockIdx.x >> 3;
   const uint32_t frame_groups = (count + 7u) / 8u;
   const uint32_t fi = xcd + 8u * (slot % frame_groups);
@@ -442,43 +456,47 @@ __global__ __launch_bounds__(256) void k_recon_tiles(const DevFrame* __restrict_
 
   __shared__ uint32_t s_group;
   __shared__ uint32_t s_base;
-  __shared__ uint32_t s_tot[kTileItemsPerGroup];
-  __shared__ uint32_t s_items[kTileItemsPerGroup][6];                   // the 16 item descriptors (scalar-loaded once)
-  __shared__ __attribute__((aligned(16))) uint2 s_slots[4][512];
+  __shared__ uint32_t s_tot[2][kTileItemsPerGroup];
+  __shared__ uint32_t s_items[2][kTileItemsPerGroup][6];                // item descriptors of the two groups in flight
+  __shared__ __attribute__((aligned(16))) uint2 s_slots[4][kSlotsPerWave];
 
   [[maybe_unused]] unsigned long long t_prev = kStamps ? stamp() : 0ull;
   [[maybe_unused]] unsigned long long t_acc[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
-  if (threadIdx.x == 0) {
-    const uint32_t t = __hip_atomic_fetch_add(glw(f.ticket), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    // exactly groups_stride workgroups of this launch draw from this counter: the last one re-arms it
-    if (t + 1u == groups_stride) __hip_atomic_store(glw(f.ticket), 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    s_group = t;
-  }
-  __syncthreads();
-  const uint32_t g = __builtin_amdgcn_readfirstlane(s_group);
   const uint32_t n_groups = (f.n_tiles + kTileItemsPerGroup - 1u) / kTileItemsPerGroup;
-  if (g >= n_groups) return;                            // surplus workgroups of this frame
-
   const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = lane_id();
   constexpr uint32_t K = kTileItemsPerWave;
-  const uint32_t item0 = g * kTileItemsPerGroup + wave * K;
-  VPCC_STAMP(0)                                         // ticket + first barrier
+  static_assert(K == 4, "one occupancy / duplicate nibble per item in a 16-bit half");
 
-  // ---- 1. count.  Geometry registers are transient (the per-item loop re-reads its samples, L2-hot);
-  // what IS kept is what the loop's loads would otherwise have to wait for: the four occupancy
-  // nibbles (one register) and the item descriptors (LDS).  On CDNA4 vmcnt retires in order and counts
-  // stores, so any dependent load inside the loop would also drain the previous item's stores.
-  uint64_t occ_all = 0, dup_all = 0;                   // one occupancy / duplicate nibble per item of this wave
-  for (uint32_t c0 = 0; c0 < K; c0 += 4u) {            // four items' loads in flight at a time
+  // Draws the next group of this frame.  Every workgroup of the frame stops at its first ticket past
+  // the end, so exactly n_groups + groups_stride tickets are drawn per launch: the last re-arms the counter.
+  auto claim = [&]() -> uint32_t {
+    if (threadIdx.x == 0) {
+      const uint32_t t = __hip_atomic_fetch_add(glw(f.ticket), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if (t + 1u == n_groups + groups_stride)
+        __hip_atomic_store(glw(f.ticket), 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      s_group = t;
+    }
+    __syncthreads();
+    return __builtin_amdgcn_readfirstlane(s_group);
+  };
+
+  // ---- count: occupancy + geometry of the wave's 4 items of group g; returns occupancy nibbles in the
+  // low half and duplicate nibbles in the high half.  Geometry registers are transient (the per-item
+  // loop re-reads its samples, L2-hot); what IS kept is what the loop's loads would otherwise have to
+  // wait for.  On CDNA4 vmcnt retires in order and counts stores, so any dependent load inside the
+  // loop would also drain the previous item's stores.
+  auto count_group = [&](uint32_t g, uint32_t buf) -> uint32_t {
+    const uint32_t item0 = g * kTileItemsPerGroup + wave * K;
+    uint32_t masks = 0;
     Item it4[4];
     Samples s4[4];
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-      const bool valid = item0 + c0 + i < f.n_tiles;
-      it4[i] = load_item(f.tiles + (valid ? item0 + c0 + i : 0u));
-      if (lane == 0) store_item(s_items[wave * K + c0 + i], it4[i]);
+      const bool valid = item0 + i < f.n_tiles;
+      it4[i] = load_item(f.tiles + (valid ? item0 + i : 0u));
+      if (lane == 0) store_item(s_items[buf][wave * K + i], it4[i]);
       s4[i].occ = load_occupancy(f, it4[i], valid, lane);
-      occ_all |= (uint64_t)s4[i].occ << (4u * (c0 + i));
+      masks |= s4[i].occ << (4u * i);
     }
 #pragma unroll
     for (int i = 0; i < 4; ++i) load_geometry(f, it4[i], lane, s4[i]);
@@ -486,135 +504,164 @@ __global__ __launch_bounds__(256) void k_recon_tiles(const DevFrame* __restrict_
     for (int i = 0; i < 4; ++i) {
       uint32_t dup, cnt;
       classify(f, it4[i], s4[i], dup, cnt);
-      dup_all |= (uint64_t)(dup & s4[i].occ) << (4u * (c0 + i));       // the per-item loop reuses the duplicate mask
-      for (int off = 32; off > 0; off >>= 1) cnt += __shfl_xor(cnt, off, 64);
-      if (lane == 0) s_tot[wave * K + c0 + i] = cnt;
+      masks |= (dup & s4[i].occ) << (16u + 4u * i);
+      cnt = wave_sum(cnt);
+      if (lane == 0) s_tot[buf][wave * K + i] = cnt;
     }
-  }
-  VPCC_STAMP(1)                                         // occupancy + geometry of 4 items, counted
-  __syncthreads();
-  VPCC_STAMP(2)                                         // barrier: all 16 counts
+    return masks;
+  };
 
-  // ---- 2. publish the group total and look back (wave 0); every wave prefetches its first item ----
-  Item it = fetch_item(s_items[wave * K]);
-  Samples cur;
-  cur.occ = (uint32_t)occ_all & 0xFu;
-  load_geometry(f, it, lane, cur);
-  load_attributes(f, it, lane, cur);
-
-  if (wave == 0) {
-    uint32_t total = lane < kTileItemsPerGroup ? s_tot[lane] : 0u;
+  uint32_t g_cur = claim();
+  VPCC_STAMP(0)
+  if (g_cur >= n_groups) return;                          // surplus workgroup of this frame
+  uint32_t m_cur = count_group(g_cur, 0);
+  uint32_t cb = 0;
+  // Wave 0: the group's total from s_tot[buf] (after a barrier), published as AGGREGATE (PREFIX for group 0).
+  auto publish = [&](uint32_t g, uint32_t buf) -> uint32_t {
+    uint32_t total = lane < kTileItemsPerGroup ? s_tot[buf][lane] : 0u;
     for (int off = 32; off > 0; off >>= 1) total += __shfl_xor(total, off, 64);
-    total = __shfl(total, 0, 64);
-    if (lane == 0) st_store(f.scan_state + g, ((uint64_t)gen << kGenShift) | (g == 0 ? kPrefix : kAggregate) | total);
-    uint32_t excl = 0;
-    if (g != 0 && !(variant & 1u)) {
-      excl = look_back_groups(f, g, gen);
-      if (lane == 0) st_store(f.scan_state + g, ((uint64_t)gen << kGenShift) | kPrefix | (uint64_t)(excl + total));
-    }
-    if (lane == 0) {
-      s_base = excl;
-      if (g + 1u == n_groups) *glw(f.n_points) = excl + total;         // tile.total_number_of_regular_points
-    }
-    VPCC_STAMP(3)                                       // look-back (wave 0 only)
-  }
+    if (lane == 0)
+      st_store(f.scan_state + g, ((uint64_t)gen << kGenShift) | (g == 0 ? kPrefix : kAggregate) | total);
+    return total;
+  };
   __syncthreads();
-  VPCC_STAMP(4)                                         // barrier: offset known
-  uint32_t base = s_base;
-  for (uint32_t k = 0; k < wave * K; ++k) base += s_tot[k];
+  uint32_t total_cur = 0;
+  if (wave == 0) total_cur = publish(g_cur, 0);
+  VPCC_STAMP(1)
 
-  // ---- 3. per item: compact records through LDS, then lane <-> point ------------------------------
   uint2* slots = s_slots[wave];
   VPCC_GLOBAL unsigned char* const gx = (VPCC_GLOBAL unsigned char*)f.out_xyz;
   VPCC_GLOBAL unsigned char* const gc = (VPCC_GLOBAL unsigned char*)f.out_rgb;
   VPCC_GLOBAL uint16_t* const gp = glw(f.out_patch);
-  for (uint32_t i = 0; i < K; ++i) {
-    const uint32_t n = s_tot[wave * K + i];
-    // prefetch the next item's samples; nothing here depends on an outstanding global load
-    Item nit = it;
-    Samples nxt;
-    nxt.occ = 0;
-    if (i + 1u < K) {
-      nit = fetch_item(s_items[wave * K + i + 1u]);
-      nxt.occ = (uint32_t)(occ_all >> (4u * (i + 1u))) & 0xFu;
-    }
-    load_geometry(f, nit, lane, nxt);
-    load_attributes(f, nit, lane, nxt);
 
-    if (n != 0) {                                       // wave-uniform
-      uint32_t rk[4];
-      const uint32_t dup = (uint32_t)(dup_all >> (4u * i)) & 0xFu;       // from the count phase
-      const uint32_t cnt = 2u * (uint32_t)__builtin_popcount(cur.occ) - (uint32_t)__builtin_popcount(dup);
-      pixel_ranks(it, cur, dup, cnt, lane, reinterpret_cast<unsigned char*>(slots), rk);
-      // patch-local offsets of the lane's pixels: Default (du, dv) = (4q + j, r); Swap (du, dv) = (r, 4q + j)
-      const uint32_t q4 = 4u * (lane & 3u), r = lane >> 2;
-      const bool swap = it.flags & kTileSwap;
-      const uint32_t pix0 = swap ? q4 * 16u + r : r * 16u + q4, pstep = swap ? 16u : 1u;
-      put_records<0>(cur, dup, pix0, rk[0], slots);
-      put_records<1>(cur, dup, pix0 + pstep, rk[1], slots);
-      put_records<2>(cur, dup, pix0 + 2u * pstep, rk[2], slots);
-      put_records<3>(cur, dup, pix0 + 3u * pstep, rk[3], slots);
-      wave_sync();                                      // records written by other lanes are read below
-      // Take delivery of the prefetched samples NOW, before this item's stores are issued: waited for
-      // later, the in-order vmcnt would make that wait cover the stores as well.
-      asm volatile("" : "+v"(nxt.g0.lo), "+v"(nxt.g0.hi), "+v"(nxt.g1.lo), "+v"(nxt.g1.hi), "+v"(nxt.y0.lo),
-                   "+v"(nxt.y0.hi), "+v"(nxt.y1.lo), "+v"(nxt.y1.hi));
-      asm volatile("" : "+v"(nxt.u0), "+v"(nxt.v0), "+v"(nxt.u1), "+v"(nxt.v1));
+  for (;;) {
+    // ---- 1. draw and count the NEXT group (s_tot[cb] of the current one becomes visible at the barriers)
+    const uint32_t g_next = claim();
+    const bool have_next = g_next < n_groups;
+    uint32_t m_next = 0;
+    if (have_next) m_next = count_group(g_next, cb ^ 1u);
+    VPCC_STAMP(2)
+    __syncthreads();
+    VPCC_STAMP(3)
 
-      const uint32_t room = base < f.capacity ? f.capacity - base : 0u;   // never write past the caller's arrays
-      const uint32_t nw = (variant & 16u) ? 0u : (n < room ? n : room);
-      // Two consecutive points per lane: one 16-B record read, one 12-B xyz store and one 6-B rgb store
-      // per lane and step — half the loop trips and less than half the store instructions of a
-      // point-per-lane loop (the CU issues a vector-memory instruction only every few cycles).
-      for (uint32_t k = 2u * lane; k < nw; k += 128u) {
-        const uint4 rr = *reinterpret_cast<const uint4*>(slots + k);       // records k and k+1
-        const bool two = k + 1u < nw;
-        uint2 p[2];
-        uint32_t rgb[2];
-#pragma unroll
-        for (int h = 0; h < 2; ++h) {
-          // an odd tail has no second record: reuse the first (never a stale slot — its fields index planes)
-          const uint32_t rx = (h && two) ? rr.z : rr.x, ry = (h && two) ? rr.w : rr.y;
-          const uint32_t depth = rx & 0xFFFFu, pixel = (rx >> 16) & 0xFFu, layer = rx >> 24;
-          const uint32_t tg = it.tb + (pixel & 15u) * it.lod_x, bt = it.bb + (pixel >> 4) * it.lod_y;
-          if (f.absolute_d1 || layer == 0) {
-            p[h] = pack_point(it, normal_of(it, depth), tg, bt);
-          } else {                                      // relative D1: the D0 record of this pixel precedes it
-            const uint32_t d0 = h ? (rr.x & 0xFFFFu) : (slots[k - 1u].x & 0xFFFFu);
-            p[h] = relative_point(it, pack_point(it, normal_of(it, d0), tg, bt), depth);
-          }
-          rgb[h] = 0;
-          if (f.has_attr) {
-            uint32_t Y = ry & 1023u, U = (ry >> 10) & 1023u, V = (ry >> 20) & 1023u;
-            if (ry >> 30) {                             // rare: samples wider than 10 bits, fetch them again
-              const uint32_t du = pixel & 15u, dv = pixel >> 4;
-              const uint32_t x = it.x0 + (swap ? dv : du), y = it.y0 + (swap ? du : dv);
-              const uint32_t ci = (y >> 1) * f.attr_cstride[layer] + (x >> 1);
-              Y = gl(f.attr_y[layer])[y * f.attr_stride[layer] + x];
-              U = gl(f.attr_u[layer])[ci];
-              V = gl(f.attr_v[layer])[ci];
-            }
-            rgb[h] = (variant & 8u) ? ry : yuv10_to_rgb8_int(Y, U, V);
-          }
-        }
-        if (two) {
-          store_xyz2(gx, (base + k) * 6u, p[0], p[1]);
-          if (f.has_attr) store_rgb2(gc, (base + k) * 3u, rgb[0], rgb[1]);
-          if (gp) { gp[base + k] = (uint16_t)it.patch; gp[base + k + 1u] = (uint16_t)it.patch; }   // partition, codec.rs:452
-        } else {
-          store_xyz(gx, (base + k) * 6u, p[0]);
-          if (f.has_attr) store_rgb(gc, (base + k) * 3u, rgb[0]);
-          if (gp) gp[base + k] = (uint16_t)it.patch;
-        }
+    // ---- 2. wave 0: publish the totals not yet published, then look back for the current group ------
+    Item it = fetch_item(s_items[cb][wave * K]);
+    Samples cur;
+    cur.occ = m_cur & 0xFu;
+    load_geometry(f, it, lane, cur);
+    load_attributes(f, it, lane, cur);
+
+    uint32_t total_next = 0;
+    if (wave == 0) {
+      if (have_next) total_next = publish(g_next, cb ^ 1u);
+      uint32_t excl = (variant & 1u) ? g_cur * 7000u : 0u;   // ablation: no wait, outputs still spread over the frame
+      if (g_cur != 0 && !(variant & 1u)) {
+        excl = look_back_groups(f, g_cur, gen);
+        if (lane == 0)
+          st_store(f.scan_state + g_cur, ((uint64_t)gen << kGenShift) | kPrefix | (uint64_t)(excl + total_cur));
       }
-      wave_sync();                                      // the next item overwrites the slots
+      if (lane == 0) {
+        s_base = excl;
+        if (g_cur + 1u == n_groups)                                        // tile.total_number_of_regular_points
+          *glw(f.n_points) = (variant & 1u) ? (excl + total_cur < f.capacity ? excl + total_cur : f.capacity) : excl + total_cur;
+      }
     }
-    base += n;
-    it = nit;
-    cur = nxt;
+    VPCC_STAMP(4)
+    __syncthreads();
+    VPCC_STAMP(5)
+    uint32_t base = s_base;
+    for (uint32_t k = 0; k < wave * K; ++k) base += s_tot[cb][k];
+
+    // ---- 3. per item: compact records through LDS, then lane <-> point ----------------------------
+    for (uint32_t i = 0; i < K; ++i) {
+      const uint32_t n = s_tot[cb][wave * K + i];
+      // prefetch the next item's samples; nothing here depends on an outstanding global load
+      Item nit = it;
+      Samples nxt;
+      nxt.occ = 0;
+      if (i + 1u < K) {
+        nit = fetch_item(s_items[cb][wave * K + i + 1u]);
+        nxt.occ = (m_cur >> (4u * (i + 1u))) & 0xFu;
+      }
+      load_geometry(f, nit, lane, nxt);
+      load_attributes(f, nit, lane, nxt);
+
+      if (n != 0) {                                       // wave-uniform
+        uint32_t rk[4];
+        const uint32_t dup = (m_cur >> (16u + 4u * i)) & 0xFu;             // from the count phase
+        const uint32_t cnt = 2u * (uint32_t)__builtin_popcount(cur.occ) - (uint32_t)__builtin_popcount(dup);
+        pixel_ranks(it, cur, dup, cnt, lane, reinterpret_cast<unsigned char*>(slots), rk);
+        uint32_t rgb0[4] = {0, 0, 0, 0}, rgb1[4] = {0, 0, 0, 0};
+        if (f.has_attr && !(variant & 8u)) {
+          colours4(cur.y0, cur.u0, cur.v0, rgb0);
+          if (f.map_count > 1) colours4(cur.y1, cur.u1, cur.v1, rgb1);
+        }
+        // patch-local offsets of the lane's pixels: Default (du, dv) = (4q + j, r); Swap (du, dv) = (r, 4q + j)
+        const uint32_t q4 = 4u * (lane & 3u), r = lane >> 2;
+        const bool swap = it.flags & kTileSwap;
+        const uint32_t pix0 = swap ? q4 * 16u + r : r * 16u + q4, pstep = swap ? 16u : 1u;
+        const uint32_t dump = 512u + lane;
+        put_records<0>(cur, dup, pix0, rk[0], dump, rgb0, rgb1, slots);
+        put_records<1>(cur, dup, pix0 + pstep, rk[1], dump, rgb0, rgb1, slots);
+        put_records<2>(cur, dup, pix0 + 2u * pstep, rk[2], dump, rgb0, rgb1, slots);
+        put_records<3>(cur, dup, pix0 + 3u * pstep, rk[3], dump, rgb0, rgb1, slots);
+        wave_sync();                                      // records written by other lanes are read below
+        // Take delivery of the prefetched samples NOW, before this item's stores are issued: waited for
+        // later, the in-order vmcnt would make that wait cover the stores as well.
+        asm volatile("" : "+v"(nxt.g0.lo), "+v"(nxt.g0.hi), "+v"(nxt.g1.lo), "+v"(nxt.g1.hi), "+v"(nxt.y0.lo),
+                     "+v"(nxt.y0.hi), "+v"(nxt.y1.lo), "+v"(nxt.y1.hi));
+        asm volatile("" : "+v"(nxt.u0), "+v"(nxt.v0), "+v"(nxt.u1), "+v"(nxt.v1));
+
+        const uint32_t room = base < f.capacity ? f.capacity - base : 0u;   // never write past the caller's arrays
+        const uint32_t nw = (variant & 16u) ? 0u : (n < room ? n : room);
+        const PointSel sel = point_selectors(it);
+        // Two consecutive points per lane: one 16-B record read, one 12-B xyz store and one 6-B rgb store
+        // per lane and step — half the loop trips and less than half the store instructions of a
+        // point-per-lane loop (the CU issues a vector-memory instruction only every few cycles).
+        for (uint32_t k = 2u * lane; k < nw; k += 128u) {
+          const uint4 rr = *reinterpret_cast<const uint4*>(slots + k);       // records k and k+1
+          const bool two = k + 1u < nw;
+          uint2 p[2];
+          uint32_t rgb[2];
+#pragma unroll
+          for (int h = 0; h < 2; ++h) {
+            // an odd tail has no second record: reuse the first (a stale slot could hold anything)
+            const uint32_t rx = (h && two) ? rr.z : rr.x, ry = (h && two) ? rr.w : rr.y;
+            const uint32_t depth = rx & 0xFFFFu, du = (rx >> 16) & 15u, dv = (rx >> 20) & 15u;
+            if (f.absolute_d1 || (rx >> 24) == 0) {
+              p[h] = pack_point(it, sel, depth, du, dv);
+            } else {                                      // relative D1: the D0 record of this pixel precedes it
+              const uint32_t d0 = h ? (rr.x & 0xFFFFu) : (slots[k - 1u].x & 0xFFFFu);
+              p[h] = relative_point(it, pack_point(it, sel, d0, du, dv), depth);
+            }
+            rgb[h] = ry;
+          }
+          if ((variant & 32u) && p[0].x != 0xFFFFFFFEu) continue;           // ablation: all the arithmetic, no stores
+          if (two) {
+            store_xyz2(gx, (base + k) * 6u, p[0], p[1]);
+            if (f.has_attr) store_rgb2(gc, (base + k) * 3u, rgb[0], rgb[1]);
+            if (gp) { gp[base + k] = (uint16_t)it.patch; gp[base + k + 1u] = (uint16_t)it.patch; }   // partition, codec.rs:452
+          } else {
+            store_xyz(gx, (base + k) * 6u, p[0]);
+            if (f.has_attr) store_rgb(gc, (base + k) * 3u, rgb[0]);
+            if (gp) gp[base + k] = (uint16_t)it.patch;
+          }
+        }
+        wave_sync();                                      // the next item overwrites the slots
+      }
+      base += n;
+      it = nit;
+      cur = nxt;
+    }
+    VPCC_STAMP(6)
+    if (!have_next) break;
+    g_cur = g_next;
+    m_cur = m_next;
+    cb ^= 1u;
+    total_cur = total_next;
   }
   if constexpr (kStamps) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  VPCC_STAMP(5)                                         // the four items incl. store drain
+  VPCC_STAMP(7)
   VPCC_STAMP_FLUSH()
 }
 
@@ -638,14 +685,21 @@ void launch_tiles(const DevFrame* d_frames, uint32_t first, uint32_t count, uint
     const char* e = getenv("VPCC_TILES_VARIANT");
     return e ? (uint32_t)atoi(e) : 0u;
   }();
+  // groups each workgroup is expected to pipeline (tickets are drawn dynamically; this only sizes the grid)
+  static const uint32_t depth = [] {
+    const char* e = getenv("VPCC_TILES_DEPTH");
+    const int v = e ? atoi(e) : 3;
+    return (uint32_t)(v < 1 ? 1 : v);
+  }();
   const uint32_t frame_groups = (count + 7u) / 8u;
-  const uint32_t grid = 8u * frame_groups * max_groups;
+  const uint32_t wgs = (max_groups + depth - 1u) / depth;     // workgroups per frame
+  const uint32_t grid = 8u * frame_groups * wgs;
   if (variant & 64u)
     hipLaunchKernelGGL(k_recon_tiles<true>, dim3(grid), dim3(256), 0, (hipStream_t)stream, d_frames, first, count,
-                       max_groups, gen, variant);
+                       wgs, gen, variant);
   else
     hipLaunchKernelGGL(k_recon_tiles<false>, dim3(grid), dim3(256), 0, (hipStream_t)stream, d_frames, first, count,
-                       max_groups, gen, variant);
+                       wgs, gen, variant);
 }
 
 }  // namespace vpcc
