@@ -11,7 +11,7 @@ PROJ       := tmc2-rs_amd
 CSRC       := $(PROJ)/csrc
 
 HIPFLAGS   := --offload-arch=$(ARCH) -O3 -std=c++17 -fPIC -ffp-contract=off -Wall -Wno-unused-function \
-              -Iinclude -I$(CSRC)
+              -Iinclude -I$(CSRC) $(EXTRA)
 PRODUCT_SO := $(PROJ)/libvpcc_recon.so
 PRODUCT_SRC := $(wildcard $(CSRC)/*.hip) $(wildcard $(CSRC)/*.cpp)
 PRODUCT_HDR := $(wildcard $(CSRC)/*.hpp) $(wildcard $(CSRC)/*.h) include/vpcc_recon.h

@@ -13,7 +13,7 @@ int main(){ uint64_t bad=0, slow=0, total=0, exact_unflagged=0;
   for (int u=0;u<1024;++u) for (int v=0;v<1024;++v){ const vpcc_chroma_part c = vpcc_colour_chroma(u, v);
     const int du=u-512, dv=v-512;
     for (int y=0;y<1024;++y){
-      uint32_t amb=0; const uint32_t rgb=vpcc_colour_luma(y,c,&amb); uint8_t o[3]; ref(y,u,v,o); total++;
+      uint32_t fmin=0xFFFFFFFFu; const uint32_t rgb=vpcc_colour_luma(y,c,&fmin); const int amb = fmin==0; uint8_t o[3]; ref(y,u,v,o); total++;
       const int64_t nr=17ll*(2500ll*y+3937ll*dv), ng=17ll*(100000ll*y-18733ll*du-46813ll*dv), nb=17ll*(100000ll*y+185563ll*du);
       const int exact = (nr>0&&nr%170500==0)||(ng>0&&ng%6820000==0)||(nb>0&&nb%6820000==0);
       if (amb){ slow++; continue; }

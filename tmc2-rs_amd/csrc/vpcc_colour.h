@@ -60,15 +60,16 @@ VPCC_COLOUR_FN int32_t vpcc_colour_lo(double x) {
 
 VPCC_COLOUR_FN int32_t vpcc_colour_clamp(int32_t q) { return q < 0 ? 0 : (q > 255 ? 255 : q); }
 
-/* r | g << 8 | b << 16; *ambiguous is OR-ed with non-zero when the caller must use the reference formula */
-VPCC_COLOUR_FN uint32_t vpcc_colour_luma(uint32_t Y, vpcc_chroma_part c, uint32_t* ambiguous) {
+/* r | g << 8 | b << 16.  *fraction_min is lowered to the smallest masked fraction field seen: the caller
+ * must use the reference formula for every pixel that contributed when it ends up 0. */
+VPCC_COLOUR_FN uint32_t vpcc_colour_luma(uint32_t Y, vpcc_chroma_part c, uint32_t* fraction_min) {
   const double y = (double)Y;
   const int32_t ir = vpcc_colour_lo(fma(y, VPCC_C_AY, c.r));
   const int32_t ig = vpcc_colour_lo(fma(y, VPCC_C_AY, c.g));
   const int32_t ib = vpcc_colour_lo(fma(y, VPCC_C_AY, c.b));
   const uint32_t fr = (uint32_t)ir & 0xFFFF8u, fg = (uint32_t)ig & 0xFFFF8u, fb = (uint32_t)ib & 0xFFFF8u;
   const uint32_t m = fr < fg ? (fr < fb ? fr : fb) : (fg < fb ? fg : fb);
-  *ambiguous |= (m == 0u) ? 1u : 0u;
+  if (m < *fraction_min) *fraction_min = m;
   return (uint32_t)vpcc_colour_clamp(ir >> 20) | ((uint32_t)vpcc_colour_clamp(ig >> 20) << 8) |
          ((uint32_t)vpcc_colour_clamp(ib >> 20) << 16);
 }

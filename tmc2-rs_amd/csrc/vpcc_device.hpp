@@ -46,7 +46,8 @@ struct TileItem {
                           //   u0*R*lod_x + u1 ,  v0*R*lod_y + v1     (src/decoder.rs:875-876)
   uint32_t d1;
   uint16_t lod_x, lod_y;
-  uint32_t pad[2];
+  uint32_t sel_xy, sel_z; // v_perm_b32 selectors that assemble {x | y << 16} and {z} from {normal | tangent << 16}
+                          //   (bytes 0-3) and {bitangent} (bytes 4-5): the axis assignment of src/decoder.rs:871-888
 };
 static_assert(sizeof(TileItem) == 32, "TileItem is 32 B");
 constexpr uint8_t kTileSwap = 1, kTileMode1 = 2;
@@ -82,8 +83,8 @@ struct DevFrame {
   uint32_t n_patches, n_vblocks;
   uint32_t map_count, absolute_d1, has_attr;
   uint32_t capacity;
-  uint32_t n_tiles;           // number of tile items
-  uint32_t pad[1];
+  uint32_t n_tiles;           // number of tile items (the array is padded to a multiple of 16 readable items)
+  uint32_t prec_shift;        // log2(prec) when prec is a power of two (tile kernel)
 };
 
 // One grid cell of the smoothing filters (oracle/vpcc_smoothing_spec.h): all-zero = empty.

@@ -142,7 +142,7 @@ void plan_frame(const vpcc_frame_desc& f, FramePlan* out) {
   // in emission order, each carrying the patch fields its points need.
   out->tiles.clear();
   const uint32_t prec = f.occupancy_precision;
-  out->tile_eligible = out->simple_orientations && f.occupancy_resolution == 16 && (prec < 4 || prec % 4 == 0);
+  out->tile_eligible = out->simple_orientations && f.occupancy_resolution == 16 && prec <= 16 && (prec & (prec - 1)) == 0;
   if (out->tile_eligible) {
     std::vector<int32_t> cover((size_t)out->bw * out->bh, -1);
     for (const VBlock& b : out->vblocks) cover[b.canvas_block] = std::max(cover[b.canvas_block], (int32_t)b.patch);
@@ -160,6 +160,18 @@ void plan_frame(const vpcc_frame_desc& f, FramePlan* out) {
       t.d1 = p.d1;
       t.lod_x = (uint16_t)p.lod_x;
       t.lod_y = (uint16_t)p.lod_y;
+      // coordinate a takes bitangent if bitangent_axis == a, else tangent, else normal, else 0: the
+      // reference assigns normal, tangent, bitangent in this order (src/decoder.rs:874-876)
+      uint32_t sel[3];
+      for (uint32_t a = 0; a < 3; ++a) {
+        uint32_t v = 0x0C0Cu;
+        if (p.normal_axis == a) v = 0x0100u;
+        if (p.tangent_axis == a) v = 0x0302u;
+        if (p.bitangent_axis == a) v = 0x0504u;
+        sel[a] = v;
+      }
+      t.sel_xy = sel[0] | (sel[1] << 16);
+      t.sel_z = sel[2] | 0x0C0C0000u;
       if (p.lod_x > 65535u || p.lod_y > 65535u) out->tile_eligible = false;
       out->tiles.push_back(t);
     }
@@ -178,7 +190,16 @@ void plan_frame(const vpcc_frame_desc& f, FramePlan* out) {
 
 bool tile_planes_aligned(const DevFrame& d) {
   auto al = [](const void* p, uintptr_t a) { return ((uintptr_t)p % a) == 0; };
+  // the lane's occupancy bytes (4 / 2 / 1 for precision 1 / 2 / >= 4) must lie inside one aligned dword
+  if (d.prec_shift == 0 && (!al(d.occ, 4) || d.occ_stride % 4)) return false;
+  if (d.prec_shift == 1 && (!al(d.occ, 2) || d.occ_stride % 2)) return false;
+  // the kernel addresses every plane with 32-bit byte offsets
+  const uint64_t lim = 1ull << 32;
+  if ((uint64_t)d.occ_h * d.occ_stride >= lim) return false;
   for (uint32_t m = 0; m < d.map_count; ++m) {
+    if ((uint64_t)d.height * d.geo_stride[m] * 2 >= lim) return false;
+    if (d.has_attr && ((uint64_t)d.height * d.attr_stride[m] * 2 >= lim || (uint64_t)d.height * d.attr_cstride[m] >= lim))
+      return false;
     if (!al(d.geo[m], 8) || d.geo_stride[m] % 4) return false;
     if (d.has_attr) {
       if (!al(d.attr_y[m], 8) || d.attr_stride[m] % 4) return false;

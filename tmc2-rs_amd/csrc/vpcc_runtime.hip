@@ -280,7 +280,7 @@ int gof_create_impl(vpcc_ctx* ctx, const vpcc_frame_desc* frames, uint32_t n_fra
     Off& o = offs[i];
     o.patches = L.take(sizeof(DevPatch) * std::max<size_t>(P.patches.size(), 1));
     o.vblocks = L.take(sizeof(VBlock) * std::max<size_t>(P.vblocks.size(), 1));
-    o.items = L.take(sizeof(TileItem) * std::max<size_t>(P.tiles.size(), 1));
+    o.items = L.take(sizeof(TileItem) * (((P.tiles.size() + kTileItemsPerGroup - 1) / kTileItemsPerGroup) * kTileItemsPerGroup + kTileItemsPerGroup));
     o.vb_count = L.take(sizeof(uint32_t) * std::max<size_t>(P.vblocks.size(), 1));
     o.vb_offset = L.take(sizeof(uint32_t) * std::max<size_t>(P.vblocks.size(), 1));
     o.xyz = L.take(sizeof(vpcc_point3) * cap);
@@ -342,6 +342,8 @@ int gof_create_impl(vpcc_ctx* ctx, const vpcc_frame_desc* frames, uint32_t n_fra
     D.ticket = g->d_tickets + 64 * (size_t)i;
     D.error_flag = g->d_errors + i;
     D.width = F.width; D.height = F.height; D.R = F.occupancy_resolution; D.prec = F.occupancy_precision;
+    D.prec_shift = 0;
+    while ((1u << D.prec_shift) < D.prec && D.prec_shift < 31) ++D.prec_shift;
     D.bw = P.bw; D.bh = P.bh;
     D.n_patches = (uint32_t)P.patches.size();
     D.n_vblocks = (uint32_t)P.vblocks.size();
@@ -383,6 +385,18 @@ int gof_create_impl(vpcc_ctx* ctx, const vpcc_frame_desc* frames, uint32_t n_fra
         }
       }
     }
+    // The tile kernel loads both layers and the attribute planes unconditionally (branch-free loads keep
+    // several items in flight): absent planes alias present ones; their samples are never used.
+    if (F.map_count == 1) {
+      D.geo[1] = D.geo[0]; D.geo_stride[1] = D.geo_stride[0];
+      D.attr_y[1] = D.attr_y[0]; D.attr_u[1] = D.attr_u[0]; D.attr_v[1] = D.attr_v[0];
+      D.attr_stride[1] = D.attr_stride[0]; D.attr_cstride[1] = D.attr_cstride[0];
+    }
+    if (!F.attribute_count)
+      for (uint32_t m = 0; m < 2; ++m) {
+        D.attr_y[m] = D.attr_u[m] = D.attr_v[m] = D.geo[m];
+        D.attr_stride[m] = D.attr_cstride[m] = D.geo_stride[m];
+      }
     if (!P.patches.empty())
       HIP_TRY(ctx, hipMemcpyAsync(base + o.patches, P.patches.data(), sizeof(DevPatch) * P.patches.size(),
                                   hipMemcpyHostToDevice, s));

@@ -113,21 +113,26 @@ __device__ __forceinline__ uint32_t px(const Px4& v) {
   return J == 0 ? (v.lo & 0xFFFFu) : J == 1 ? (v.lo >> 16) : J == 2 ? (v.hi & 0xFFFFu) : (v.hi >> 16);
 }
 
-// Scalar (wave-uniform) view of one work item.
+// Scalar (wave-uniform) view of one work item: the eight descriptor dwords live in SGPRs.
 struct Item {
-  uint32_t x0, y0, patch, flags, axes, tb, bb, d1, lod_x, lod_y;
+  uint32_t x0, y0, patch, flags, axes, tb, bb, d1, lod_x, lod_y, sel_xy, sel_z;
 };
 
+// The item tables are written by the host before the launch and never by a kernel: with a
+// wave-uniform address the constant address space makes this ONE s_load_dwordx8 — no vector load, no
+// readfirstlane, and (unlike a vector load) it does not queue behind the wave's outstanding stores.
+#define VPCC_CONSTANT __attribute__((address_space(4)))
 __device__ __forceinline__ Item load_item(const TileItem* p) {
-  uint32_t w[6];
-  __builtin_memcpy(w, (const VPCC_GLOBAL void*)p, 24);
+  const VPCC_CONSTANT uint32_t* q = (const VPCC_CONSTANT uint32_t*)p;
+  uint32_t w[8];
 #pragma unroll
-  for (int k = 0; k < 6; ++k) w[k] = __builtin_amdgcn_readfirstlane(w[k]);
+  for (int k = 0; k < 8; ++k) w[k] = q[k];
   Item it;
   it.x0 = w[0] & 0xFFFFu; it.y0 = w[0] >> 16;
   it.patch = w[1] & 0xFFFFu; it.flags = (w[1] >> 16) & 0xFFu; it.axes = w[1] >> 24;
   it.tb = w[2]; it.bb = w[3]; it.d1 = w[4];
   it.lod_x = w[5] & 0xFFFFu; it.lod_y = w[5] >> 16;
+  it.sel_xy = w[6]; it.sel_z = w[7];
   return it;
 }
 
@@ -138,13 +143,15 @@ struct Samples {       // one item's samples of the lane's 4 pixels
   uint32_t occ;        // bit j: pixel j occupied
 };
 
-__device__ __forceinline__ Px4 load4_row(const VPCC_GLOBAL uint16_t* p) {   // 8-B aligned by construction
+// Plane loads take a wave-uniform base and a 32-bit BYTE offset per lane (saddr + voffset addressing:
+// no 64-bit address arithmetic in vector registers); tile_planes_aligned keeps planes below 4 GiB.
+__device__ __forceinline__ Px4 load4_row(const uint16_t* base, uint32_t byte_off) {   // 8-B aligned by construction
   Px4 v;
-  __builtin_memcpy(&v, p, 8);
+  __builtin_memcpy(&v, (const VPCC_GLOBAL unsigned char*)base + byte_off, 8);
   return v;
 }
-__device__ __forceinline__ uint32_t load2(const VPCC_GLOBAL uint16_t* p) {   // 4-B aligned by construction
-  return *reinterpret_cast<const VPCC_GLOBAL uint32_t*>(p);
+__device__ __forceinline__ uint32_t load2(const uint16_t* base, uint32_t byte_off) {   // 4-B aligned by construction
+  return *reinterpret_cast<const VPCC_GLOBAL uint32_t*>((const VPCC_GLOBAL unsigned char*)base + byte_off);
 }
 // Lane l always reads the 4 CANVAS pixels x0 + 4*(l&3) .. +3 of canvas row y0 + (l>>2): 8 contiguous
 // bytes per plane, whatever the patch orientation.  For Default patches this is already the
@@ -155,137 +162,108 @@ __device__ __forceinline__ void lane_origin(const Item& it, uint32_t lane, uint3
   py0 = it.y0 + (lane >> 2);
 }
 
-// Item descriptor kept in LDS for the per-item loop (read back with lgkmcnt, not vmcnt).
-__device__ __forceinline__ void store_item(uint32_t* w, const Item& it) {
-  w[0] = it.x0 | (it.y0 << 16);
-  w[1] = it.patch | (it.flags << 16) | (it.axes << 24);
-  w[2] = it.tb; w[3] = it.bb; w[4] = it.d1;
-  w[5] = it.lod_x | (it.lod_y << 16);
-}
-__device__ __forceinline__ Item fetch_item(const uint32_t* w6) {
-  uint32_t w[6];
-#pragma unroll
-  for (int k = 0; k < 6; ++k) w[k] = __builtin_amdgcn_readfirstlane(w6[k]);
-  Item it;
-  it.x0 = w[0] & 0xFFFFu; it.y0 = w[0] >> 16;
-  it.patch = w[1] & 0xFFFFu; it.flags = (w[1] >> 16) & 0xFFu; it.axes = w[1] >> 24;
-  it.tb = w[2]; it.bb = w[3]; it.d1 = w[4];
-  it.lod_x = w[5] & 0xFFFFu; it.lod_y = w[5] >> 16;
-  return it;
-}
-
-// Occupancy bits of the lane's 4 pixels, through the low-resolution plane (src/codec.rs:288-301, 393).
-__device__ __forceinline__ uint32_t load_occupancy(const DevFrame& f, const Item& it, bool valid, uint32_t lane) {
-  if (!valid) return 0;
+// Occupancy of the lane's 4 pixels through the low-resolution plane (src/codec.rs:288-301, 393).  The
+// lane needs 4 / 2 / 1 consecutive bytes for occupancy_precision 1 / 2 / >= 4 (a power of two); they
+// lie inside one aligned dword (tile_planes_aligned), which is what is loaded — an aligned dword
+// that contains a valid byte never leaves the allocation's pages.
+__device__ __forceinline__ uint32_t load_occupancy_raw(const DevFrame& f, const Item& it, uint32_t lane) {
   uint32_t px0, py0;
   lane_origin(it, lane, px0, py0);
-  if (f.prec >= 4)                                    // the 4 pixels share one occupancy sample
-    return gl(f.occ)[(py0 / f.prec) * f.occ_stride + px0 / f.prec] ? 0xFu : 0u;
-  uint32_t occ = 0;
+  const uint32_t off = __umul24(py0 >> f.prec_shift, f.occ_stride) + (px0 >> f.prec_shift);
+  const uint32_t mis = ((uint32_t)(uintptr_t)f.occ + off) & 3u;            // position inside the aligned dword
+  const uint32_t w = *reinterpret_cast<const VPCC_GLOBAL uint32_t*>((const VPCC_GLOBAL unsigned char*)f.occ + (off - mis));
+  return w >> (8u * mis);
+}
+// bit j: pixel j of the lane is occupied; pixel j reads byte j >> prec_shift (byte 0 for precision >= 4)
+__device__ __forceinline__ uint32_t occupancy_bits(const DevFrame& f, uint32_t raw) {
+  const uint32_t sh = f.prec_shift < 2u ? f.prec_shift : 2u;
+  uint32_t bits = 0;
 #pragma unroll
-  for (uint32_t j = 0; j < 4; ++j)
-    occ |= (gl(f.occ)[(py0 / f.prec) * f.occ_stride + (px0 + j) / f.prec] ? 1u : 0u) << j;
-  return occ;
+  for (uint32_t j = 0; j < 4; ++j) bits |= (((raw >> (8u * (j >> sh))) & 0xFFu) ? 1u : 0u) << j;
+  return bits;
 }
 
+// Plane loads are UNCONDITIONAL (no exec-masked region, so loads of several items stay in flight
+// together): a lane without an occupied pixel reads the block's first pixels instead — a line the
+// wave touches anyway — and its samples are never used.
 __device__ __forceinline__ void load_geometry(const DevFrame& f, const Item& it, uint32_t lane, Samples& s) {
-  s.g0 = Px4{0, 0}; s.g1 = Px4{0, 0};
-  if (s.occ == 0) return;
   uint32_t px0, py0;
   lane_origin(it, lane, px0, py0);
-  s.g0 = load4_row(gl(f.geo[0]) + py0 * f.geo_stride[0] + px0);
-  if (f.map_count > 1) s.g1 = load4_row(gl(f.geo[1]) + py0 * f.geo_stride[1] + px0);
+  if (s.occ == 0) { px0 = it.x0; py0 = it.y0; }
+  s.g0 = load4_row(f.geo[0], (__umul24(py0, f.geo_stride[0]) + px0) * 2u);
+  s.g1 = load4_row(f.geo[1], (__umul24(py0, f.geo_stride[1]) + px0) * 2u);      // single map: an alias of layer 0
 }
 
-// Attribute samples of the occupied lanes; chroma is nearest-neighbour (src/decoder.rs:977): pixels
-// 0,1 of the lane use chroma sample px0/2, pixels 2,3 the next one.
+// Attribute samples; chroma is nearest-neighbour (src/decoder.rs:977): pixels 0,1 of the lane use
+// chroma sample px0/2, pixels 2,3 the next one.
 __device__ __forceinline__ void load_attributes(const DevFrame& f, const Item& it, uint32_t lane, Samples& s) {
-  s.y0 = Px4{0, 0}; s.y1 = Px4{0, 0};
-  s.u0 = s.v0 = s.u1 = s.v1 = 0;
-  if (s.occ == 0 || !f.has_attr) return;
   uint32_t px0, py0;
   lane_origin(it, lane, px0, py0);
-  const uint32_t c0 = (py0 >> 1) * f.attr_cstride[0] + (px0 >> 1);
-  s.y0 = load4_row(gl(f.attr_y[0]) + py0 * f.attr_stride[0] + px0);
-  s.u0 = load2(gl(f.attr_u[0]) + c0);
-  s.v0 = load2(gl(f.attr_v[0]) + c0);
-  if (f.map_count > 1) {
-    const uint32_t c1 = (py0 >> 1) * f.attr_cstride[1] + (px0 >> 1);
-    s.y1 = load4_row(gl(f.attr_y[1]) + py0 * f.attr_stride[1] + px0);
-    s.u1 = load2(gl(f.attr_u[1]) + c1);
-    s.v1 = load2(gl(f.attr_v[1]) + c1);
-  }
+  if (s.occ == 0) { px0 = it.x0; py0 = it.y0; }
+  const uint32_t c0 = (__umul24(py0 >> 1, f.attr_cstride[0]) + (px0 >> 1)) * 2u;
+  const uint32_t c1 = (__umul24(py0 >> 1, f.attr_cstride[1]) + (px0 >> 1)) * 2u;
+  s.y0 = load4_row(f.attr_y[0], (__umul24(py0, f.attr_stride[0]) + px0) * 2u);   // absent planes alias present ones
+  s.u0 = load2(f.attr_u[0], c0);
+  s.v0 = load2(f.attr_v[0], c0);
+  s.y1 = load4_row(f.attr_y[1], (__umul24(py0, f.attr_stride[1]) + px0) * 2u);
+  s.u1 = load2(f.attr_u[1], c1);
+  s.v1 = load2(f.attr_v[1], c1);
 }
 
-__device__ __forceinline__ uint32_t normal_of(const Item& it, uint32_t depth) {          // decoder.rs:881-888
-  return (it.flags & kTileMode1) ? (it.d1 > depth ? it.d1 : depth) - depth : depth + it.d1;
-}
-
-// Which D1 points duplicate their D0 point (src/codec.rs:422-427), and the lane's point count.
-//   absolute D1: the two points differ only in the normal coordinate — unless a later assignment
-//     overwrites it (degenerate axes), then they are always equal;
+// Which D1 points duplicate their D0 point (src/codec.rs:422-427), one bit per pixel of the lane.
+//   absolute D1: the two points differ only in the normal coordinate (src/decoder.rs:881-888),
+//     depth + d1 (mode 0) or max(d1, depth) - depth = d1 - min(depth, d1) (mode 1): equal exactly when
+//     min(depth0, D) == min(depth1, D) with D = d1 in mode 1 and "infinity" in mode 0 (depths are
+//     < 2^14, so `as u16` cannot fold two different values) — unless a later assignment overwrites
+//     the normal coordinate (degenerate axes, sel never picks the normal), then they are always equal;
 //   relative D1: point0[normal_axis] +- d1 as u16 leaves the point unchanged only for d1 == 0.
-__device__ __forceinline__ void classify(const DevFrame& f, const Item& it, const Samples& s, uint32_t& dup,
-                                         uint32_t& cnt) {
-  dup = 0xFu;                                         // single map: D0 only
-  if (f.map_count > 1) {
-    dup = 0;
-    const uint32_t na = it.axes & 3u;
-    const bool normal_visible = na != ((it.axes >> 2) & 3u) && na != ((it.axes >> 4) & 3u);
-    const uint32_t a0[4] = {px<0>(s.g0) >> 2, px<1>(s.g0) >> 2, px<2>(s.g0) >> 2, px<3>(s.g0) >> 2};   // depth / 4
-    const uint32_t a1[4] = {px<0>(s.g1) >> 2, px<1>(s.g1) >> 2, px<2>(s.g1) >> 2, px<3>(s.g1) >> 2};
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      bool d;
-      if (f.absolute_d1) d = !normal_visible || ((normal_of(it, a0[j]) ^ normal_of(it, a1[j])) & 0xFFFFu) == 0;
-      else d = a1[j] == 0;
-      dup |= (d ? 1u : 0u) << j;
-    }
+// Both depths of a dword are handled at once with packed 16-bit operations.
+typedef uint16_t u16x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ uint32_t pk_depth_min(uint32_t v, uint32_t dd) {
+  u16x2 a = __builtin_bit_cast(u16x2, v);
+  a = a >> (u16x2)(2);                                     // depth = sample / 4 (src/codec.rs:534, 548)
+  a = __builtin_elementwise_min(a, __builtin_bit_cast(u16x2, dd));
+  return __builtin_bit_cast(uint32_t, a);
+}
+__device__ __forceinline__ uint32_t zero_halves(uint32_t x) {   // bit 0: low half zero, bit 1: high half zero
+  return ((x & 0xFFFFu) ? 0u : 1u) | ((x >> 16) ? 0u : 2u);
+}
+__device__ __forceinline__ bool normal_visible(const Item& it) {
+  const uint32_t na = it.axes & 3u;
+  return na != ((it.axes >> 2) & 3u) && na != ((it.axes >> 4) & 3u);
+}
+__device__ __forceinline__ uint32_t classify(const DevFrame& f, const Item& it, const Samples& s) {
+  if (f.map_count < 2) return 0xFu;                      // single map: D0 only
+  if (f.absolute_d1) {
+    if (!normal_visible(it)) return 0xFu;
+    const uint32_t D = (it.flags & kTileMode1) ? (it.d1 < 0xFFFFu ? it.d1 : 0xFFFFu) : 0xFFFFu;
+    const uint32_t dd = D | (D << 16);
+    return zero_halves(pk_depth_min(s.g0.lo, dd) ^ pk_depth_min(s.g1.lo, dd)) |
+           (zero_halves(pk_depth_min(s.g0.hi, dd) ^ pk_depth_min(s.g1.hi, dd)) << 2);
   }
-  cnt = 2u * (uint32_t)__builtin_popcount(s.occ) - (uint32_t)__builtin_popcount(s.occ & dup);
+  return zero_halves(pk_depth_min(s.g1.lo, 0xFFFFFFFFu)) | (zero_halves(pk_depth_min(s.g1.hi, 0xFFFFFFFFu)) << 2);
 }
 
 // {x | y << 16, z} of a point as the reference builds it (src/decoder.rs:871-888): assignment order
 // normal, tangent, bitangent, `as u16` truncation.  The axes are wave-uniform per item, so the
-// assignment becomes two byte permutes with per-item selectors: coordinate a takes bitangent if
-// bitangent_axis == a, else tangent if tangent_axis == a, else normal if normal_axis == a, else 0.
-struct PointSel { uint32_t xy, z; uint32_t nmin; int32_t nsign; };
-
-__device__ __forceinline__ PointSel point_selectors(const Item& it) {
-  const uint32_t na = it.axes & 3u, ta = (it.axes >> 2) & 3u, ba = (it.axes >> 4) & 3u;
-  uint32_t c[3];
-#pragma unroll
-  for (uint32_t a = 0; a < 3; ++a) {
-    uint32_t v = 0x0C0Cu;                       // constant 0
-    if (na == a) v = 0x0100u;                   // bytes 0,1 of {n | t << 16}
-    if (ta == a) v = 0x0302u;                   // bytes 2,3
-    if (ba == a) v = 0x0504u;                   // bytes 0,1 of b
-    c[a] = v;
-  }
-  PointSel s;
-  s.xy = c[0] | (c[1] << 16);
-  s.z = c[2] | 0x0C0C0000u;
-  // normal coordinate (decoder.rs:881-888): mode 0: depth + d1; mode 1: max(d1, depth) - depth = d1 - min(depth, d1)
-  s.nmin = (it.flags & kTileMode1) ? it.d1 : 0xFFFFFFFFu;
-  s.nsign = (it.flags & kTileMode1) ? -1 : 1;
-  return s;
-}
-
-__device__ __forceinline__ uint2 pack_point(const Item& it, const PointSel& s, uint32_t depth, uint32_t du, uint32_t dv) {
-  const uint32_t m = depth < s.nmin ? depth : s.nmin;                       // depth < 2^14
-  const uint32_t n = (uint32_t)((int32_t)m * s.nsign) + it.d1;
-  const uint32_t t = it.tb + du * it.lod_x, b = it.bb + dv * it.lod_y;
+// assignment is two byte permutes with the item's selectors (vpcc_host.cpp).
+__device__ __forceinline__ uint2 pack_point(const Item& it, uint32_t depth, uint32_t du, uint32_t dv) {
+  // normal coordinate: mode 0: depth + d1; mode 1: max(d1, depth) - depth = d1 - min(depth, d1)
+  const uint32_t nmin = (it.flags & kTileMode1) ? it.d1 : 0xFFFFFFFFu;
+  const int32_t nsign = (it.flags & kTileMode1) ? -1 : 1;
+  const uint32_t m = depth < nmin ? depth : nmin;                           // depth < 2^14
+  const uint32_t n = (uint32_t)((int32_t)m * nsign) + it.d1;
+  const uint32_t t = it.tb + __umul24(du, it.lod_x), b = it.bb + __umul24(dv, it.lod_y);
   const uint32_t nt = __builtin_amdgcn_perm(t, n, 0x05040100u);             // n (low half) | t << 16
-  return make_uint2(__builtin_amdgcn_perm(b, nt, s.xy), __builtin_amdgcn_perm(b, nt, s.z));
+  return make_uint2(__builtin_amdgcn_perm(b, nt, it.sel_xy), __builtin_amdgcn_perm(b, nt, it.sel_z));
 }
 
 // D1 point in relative mode (src/codec.rs:551-559): point0 with +-d1 on coordinate index normal_axis.
-__device__ __forceinline__ uint2 relative_point(const Item& it, uint2 p0, uint32_t d1) {
-  const uint32_t na = it.axes & 3u;
+__device__ __forceinline__ uint2 relative_point(uint32_t na, bool mode1, uint2 p0, uint32_t d1) {
   uint32_t c[3] = {p0.x & 0xFFFFu, p0.x >> 16, p0.y & 0xFFFFu};
 #pragma unroll
   for (uint32_t a = 0; a < 3; ++a)
-    if (na == a) c[a] = ((it.flags & kTileMode1) ? c[a] - d1 : c[a] + d1) & 0xFFFFu;
+    if (na == a) c[a] = (mode1 ? c[a] - d1 : c[a] + d1) & 0xFFFFu;
   return make_uint2(c[0] | (c[1] << 16), c[2]);
 }
 
@@ -303,11 +281,12 @@ __device__ __forceinline__ uint32_t colour_exact(uint32_t Y, uint32_t U, uint32_
 __device__ __forceinline__ void colours4(const Px4& y, uint32_t u, uint32_t v, uint32_t rgb[4]) {
   const vpcc_chroma_part c01 = vpcc_colour_chroma(u & 0xFFFFu, v & 0xFFFFu);
   const vpcc_chroma_part c23 = vpcc_colour_chroma(u >> 16, v >> 16);
-  uint32_t amb = (y.lo | y.hi | u | v) & 0xFC00FC00u;             // a sample wider than 10 bits
-  rgb[0] = vpcc_colour_luma(px<0>(y), c01, &amb);
-  rgb[1] = vpcc_colour_luma(px<1>(y), c01, &amb);
-  rgb[2] = vpcc_colour_luma(px<2>(y), c23, &amb);
-  rgb[3] = vpcc_colour_luma(px<3>(y), c23, &amb);
+  uint32_t fmin = ((y.lo | y.hi | u | v) & 0xFC00FC00u) ? 0u : 0xFFFFFFFFu;   // a sample wider than 10 bits
+  rgb[0] = vpcc_colour_luma(px<0>(y), c01, &fmin);
+  rgb[1] = vpcc_colour_luma(px<1>(y), c01, &fmin);
+  rgb[2] = vpcc_colour_luma(px<2>(y), c23, &fmin);
+  rgb[3] = vpcc_colour_luma(px<3>(y), c23, &fmin);
+  const bool amb = fmin == 0u;
   if (amb) {                                                       // rare
     rgb[0] = colour_exact(px<0>(y), u & 0xFFFFu, v & 0xFFFFu);
     rgb[1] = colour_exact(px<1>(y), u & 0xFFFFu, v & 0xFFFFu);
@@ -442,8 +421,12 @@ __device__ __forceinline__ void store_rgb(VPCC_GLOBAL unsigned char* base, uint3
 // its total was published, when the totals of the earlier tickets have long arrived: the wait that
 // cost a quarter of the kernel in the count -> look back -> emit form is gone, and the plane loads
 // of the next group overlap the stores of the current one across the waves of a CU.
+#ifndef VPCC_TILES_WAVES_PER_EU
+#define VPCC_TILES_WAVES_PER_EU 5
+#endif
 template <bool kStamps>
-__global__ __launch_bounds__(256) void k_recon_tiles(const DevFrame* __restrict__ frames, uint32_t first,
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(VPCC_TILES_WAVES_PER_EU, VPCC_TILES_WAVES_PER_EU)))
+void k_recon_tiles(const DevFrame* __restrict__ frames, uint32_t first,
                                                      uint32_t count, uint32_t groups_stride, uint32_t gen,
                                                      uint32_t variant) {
   // XCD-aware placement (speed only): ids equal mod 8 share an XCD/L2; a frame stays on one label.
@@ -456,8 +439,7 @@ __global__ __launch_bounds__(256) void k_recon_tiles(const DevFrame* __restrict_
 
   __shared__ uint32_t s_group;
   __shared__ uint32_t s_base;
-  __shared__ uint32_t s_tot[2][kTileItemsPerGroup];
-  __shared__ uint32_t s_items[2][kTileItemsPerGroup][6];                // item descriptors of the two groups in flight
+  __shared__ uint32_t s_tot[2][kTileItemsPerGroup];                     // point counts of the two groups in flight
   __shared__ __attribute__((aligned(16))) uint2 s_slots[4][kSlotsPerWave];
 
   [[maybe_unused]] unsigned long long t_prev = kStamps ? stamp() : 0ull;
@@ -467,9 +449,17 @@ __global__ __launch_bounds__(256) void k_recon_tiles(const DevFrame* __restrict_
   constexpr uint32_t K = kTileItemsPerWave;
   static_assert(K == 4, "one occupancy / duplicate nibble per item in a 16-bit half");
 
-  // Draws the next group of this frame.  Every workgroup of the frame stops at its first ticket past
-  // the end, so exactly n_groups + groups_stride tickets are drawn per launch: the last re-arms the counter.
-  auto claim = [&]() -> uint32_t {
+  uint2* slots = s_slots[wave];
+  VPCC_GLOBAL unsigned char* const gx = (VPCC_GLOBAL unsigned char*)f.out_xyz;
+  VPCC_GLOBAL unsigned char* const gc = (VPCC_GLOBAL unsigned char*)f.out_rgb;
+  VPCC_GLOBAL uint16_t* const gp = glw(f.out_patch);
+
+  uint32_t g_cur = 0, m_cur = 0, total_cur = 0, cb = 0;
+  bool have_cur = false;
+  for (;;) {
+    // ---- 1. draw the NEXT group of this frame.  Every workgroup of the frame stops at its first ticket
+    // past the end, so exactly n_groups + groups_stride tickets are drawn per launch: the last re-arms
+    // the counter (nothing to clear between launches).
     if (threadIdx.x == 0) {
       const uint32_t t = __hip_atomic_fetch_add(glw(f.ticket), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       if (t + 1u == n_groups + groups_stride)
@@ -477,191 +467,170 @@ __global__ __launch_bounds__(256) void k_recon_tiles(const DevFrame* __restrict_
       s_group = t;
     }
     __syncthreads();
-    return __builtin_amdgcn_readfirstlane(s_group);
-  };
-
-  // ---- count: occupancy + geometry of the wave's 4 items of group g; returns occupancy nibbles in the
-  // low half and duplicate nibbles in the high half.  Geometry registers are transient (the per-item
-  // loop re-reads its samples, L2-hot); what IS kept is what the loop's loads would otherwise have to
-  // wait for.  On CDNA4 vmcnt retires in order and counts stores, so any dependent load inside the
-  // loop would also drain the previous item's stores.
-  auto count_group = [&](uint32_t g, uint32_t buf) -> uint32_t {
-    const uint32_t item0 = g * kTileItemsPerGroup + wave * K;
-    uint32_t masks = 0;
-    Item it4[4];
-    Samples s4[4];
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      const bool valid = item0 + i < f.n_tiles;
-      it4[i] = load_item(f.tiles + (valid ? item0 + i : 0u));
-      if (lane == 0) store_item(s_items[buf][wave * K + i], it4[i]);
-      s4[i].occ = load_occupancy(f, it4[i], valid, lane);
-      masks |= s4[i].occ << (4u * i);
-    }
-#pragma unroll
-    for (int i = 0; i < 4; ++i) load_geometry(f, it4[i], lane, s4[i]);
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      uint32_t dup, cnt;
-      classify(f, it4[i], s4[i], dup, cnt);
-      masks |= (dup & s4[i].occ) << (16u + 4u * i);
-      cnt = wave_sum(cnt);
-      if (lane == 0) s_tot[buf][wave * K + i] = cnt;
-    }
-    return masks;
-  };
-
-  uint32_t g_cur = claim();
-  VPCC_STAMP(0)
-  if (g_cur >= n_groups) return;                          // surplus workgroup of this frame
-  uint32_t m_cur = count_group(g_cur, 0);
-  uint32_t cb = 0;
-  // Wave 0: the group's total from s_tot[buf] (after a barrier), published as AGGREGATE (PREFIX for group 0).
-  auto publish = [&](uint32_t g, uint32_t buf) -> uint32_t {
-    uint32_t total = lane < kTileItemsPerGroup ? s_tot[buf][lane] : 0u;
-    for (int off = 32; off > 0; off >>= 1) total += __shfl_xor(total, off, 64);
-    if (lane == 0)
-      st_store(f.scan_state + g, ((uint64_t)gen << kGenShift) | (g == 0 ? kPrefix : kAggregate) | total);
-    return total;
-  };
-  __syncthreads();
-  uint32_t total_cur = 0;
-  if (wave == 0) total_cur = publish(g_cur, 0);
-  VPCC_STAMP(1)
-
-  uint2* slots = s_slots[wave];
-  VPCC_GLOBAL unsigned char* const gx = (VPCC_GLOBAL unsigned char*)f.out_xyz;
-  VPCC_GLOBAL unsigned char* const gc = (VPCC_GLOBAL unsigned char*)f.out_rgb;
-  VPCC_GLOBAL uint16_t* const gp = glw(f.out_patch);
-
-  for (;;) {
-    // ---- 1. draw and count the NEXT group (s_tot[cb] of the current one becomes visible at the barriers)
-    const uint32_t g_next = claim();
+    const uint32_t g_next = __builtin_amdgcn_readfirstlane(s_group);
     const bool have_next = g_next < n_groups;
+    VPCC_STAMP(0)
+
+    // ---- 2. count it: occupancy + geometry of the wave's 4 items, all loads of a kind issued together.
+    // Geometry registers are transient (the per-item loop re-reads its samples, L2-hot); kept are the
+    // occupancy nibbles (low half of m_next) and the duplicate nibbles (high half).
     uint32_t m_next = 0;
-    if (have_next) m_next = count_group(g_next, cb ^ 1u);
-    VPCC_STAMP(2)
+    if (have_next) {
+      const uint32_t item0 = g_next * kTileItemsPerGroup + wave * K;
+      Item it4[4];
+      Samples s4[4];
+      uint32_t raw[4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) it4[i] = load_item(f.tiles + (item0 + i < f.n_tiles ? item0 + i : 0u));
+#pragma unroll
+      for (int i = 0; i < 4; ++i) raw[i] = load_occupancy_raw(f, it4[i], lane);
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        s4[i].occ = item0 + i < f.n_tiles ? occupancy_bits(f, raw[i]) : 0u;   // past the end: an empty copy of item 0
+        load_geometry(f, it4[i], lane, s4[i]);
+      }
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const uint32_t dup = classify(f, it4[i], s4[i]) & s4[i].occ;
+        m_next |= (s4[i].occ << (4u * i)) | (dup << (16u + 4u * i));
+        const uint32_t cnt = wave_sum(2u * (uint32_t)__builtin_popcount(s4[i].occ) - (uint32_t)__builtin_popcount(dup));
+        if (lane == 0) s_tot[cb ^ 1u][wave * K + i] = cnt;
+      }
+    }
+    VPCC_STAMP(1)
     __syncthreads();
-    VPCC_STAMP(3)
+    VPCC_STAMP(2)
 
-    // ---- 2. wave 0: publish the totals not yet published, then look back for the current group ------
-    Item it = fetch_item(s_items[cb][wave * K]);
+    // ---- 3. wave 0 publishes the next group's total, THEN looks back for the current group, whose total
+    // has been public for a whole step; the other waves already fetch their first item's samples.
+    Item it;
     Samples cur;
-    cur.occ = m_cur & 0xFu;
-    load_geometry(f, it, lane, cur);
-    load_attributes(f, it, lane, cur);
-
+    if (have_cur) {
+      const uint32_t first_item = g_cur * kTileItemsPerGroup + wave * K;
+      it = load_item(f.tiles + (first_item < f.n_tiles ? first_item : 0u));
+      cur.occ = m_cur & 0xFu;
+      load_geometry(f, it, lane, cur);
+      load_attributes(f, it, lane, cur);
+    }
     uint32_t total_next = 0;
     if (wave == 0) {
-      if (have_next) total_next = publish(g_next, cb ^ 1u);
-      uint32_t excl = (variant & 1u) ? g_cur * 7000u : 0u;   // ablation: no wait, outputs still spread over the frame
-      if (g_cur != 0 && !(variant & 1u)) {
-        excl = look_back_groups(f, g_cur, gen);
+      if (have_next) {
+        total_next = lane < kTileItemsPerGroup ? s_tot[cb ^ 1u][lane] : 0u;
+        total_next = wave_sum(total_next);
         if (lane == 0)
-          st_store(f.scan_state + g_cur, ((uint64_t)gen << kGenShift) | kPrefix | (uint64_t)(excl + total_cur));
+          st_store(f.scan_state + g_next, ((uint64_t)gen << kGenShift) | (g_next == 0 ? kPrefix : kAggregate) | total_next);
       }
-      if (lane == 0) {
-        s_base = excl;
-        if (g_cur + 1u == n_groups)                                        // tile.total_number_of_regular_points
-          *glw(f.n_points) = (variant & 1u) ? (excl + total_cur < f.capacity ? excl + total_cur : f.capacity) : excl + total_cur;
+      if (have_cur) {
+        uint32_t excl = (variant & 1u) ? g_cur * 7000u : 0u;   // ablation: no wait, outputs still spread over the frame
+        if (g_cur != 0 && !(variant & 1u)) {
+          excl = look_back_groups(f, g_cur, gen);
+          if (lane == 0)
+            st_store(f.scan_state + g_cur, ((uint64_t)gen << kGenShift) | kPrefix | (uint64_t)(excl + total_cur));
+        }
+        if (lane == 0) {
+          s_base = excl;
+          if (g_cur + 1u == n_groups)                                        // tile.total_number_of_regular_points
+            *glw(f.n_points) = (variant & 1u) ? (excl + total_cur < f.capacity ? excl + total_cur : f.capacity) : excl + total_cur;
+        }
       }
     }
-    VPCC_STAMP(4)
-    __syncthreads();
-    VPCC_STAMP(5)
-    uint32_t base = s_base;
-    for (uint32_t k = 0; k < wave * K; ++k) base += s_tot[cb][k];
+    VPCC_STAMP(3)
 
-    // ---- 3. per item: compact records through LDS, then lane <-> point ----------------------------
-    for (uint32_t i = 0; i < K; ++i) {
-      const uint32_t n = s_tot[cb][wave * K + i];
-      // prefetch the next item's samples; nothing here depends on an outstanding global load
-      Item nit = it;
-      Samples nxt;
-      nxt.occ = 0;
-      if (i + 1u < K) {
-        nit = fetch_item(s_items[cb][wave * K + i + 1u]);
-        nxt.occ = (m_cur >> (4u * (i + 1u))) & 0xFu;
-      }
-      load_geometry(f, nit, lane, nxt);
-      load_attributes(f, nit, lane, nxt);
+    if (have_cur) {
+      __syncthreads();
+      VPCC_STAMP(4)
+      uint32_t base = s_base;
+      for (uint32_t k = 0; k < wave * K; ++k) base += s_tot[cb][k];
 
-      if (n != 0) {                                       // wave-uniform
-        uint32_t rk[4];
-        const uint32_t dup = (m_cur >> (16u + 4u * i)) & 0xFu;             // from the count phase
-        const uint32_t cnt = 2u * (uint32_t)__builtin_popcount(cur.occ) - (uint32_t)__builtin_popcount(dup);
-        pixel_ranks(it, cur, dup, cnt, lane, reinterpret_cast<unsigned char*>(slots), rk);
-        uint32_t rgb0[4] = {0, 0, 0, 0}, rgb1[4] = {0, 0, 0, 0};
-        if (f.has_attr && !(variant & 8u)) {
-          colours4(cur.y0, cur.u0, cur.v0, rgb0);
-          if (f.map_count > 1) colours4(cur.y1, cur.u1, cur.v1, rgb1);
+      // ---- 4. per item: colours, compaction of the records through LDS, then lane <-> point ---------
+      for (uint32_t i = 0; i < K; ++i) {
+        const uint32_t n = s_tot[cb][wave * K + i];
+        // prefetch the next item's samples; nothing here depends on an outstanding vector load
+        Item nit = it;
+        Samples nxt = {};
+        if (i + 1u < K) {
+          const uint32_t next_item = g_cur * kTileItemsPerGroup + wave * K + i + 1u;
+          nit = load_item(f.tiles + (next_item < f.n_tiles ? next_item : 0u));
+          nxt.occ = (m_cur >> (4u * (i + 1u))) & 0xFu;
+          load_geometry(f, nit, lane, nxt);
+          load_attributes(f, nit, lane, nxt);
         }
-        // patch-local offsets of the lane's pixels: Default (du, dv) = (4q + j, r); Swap (du, dv) = (r, 4q + j)
-        const uint32_t q4 = 4u * (lane & 3u), r = lane >> 2;
-        const bool swap = it.flags & kTileSwap;
-        const uint32_t pix0 = swap ? q4 * 16u + r : r * 16u + q4, pstep = swap ? 16u : 1u;
-        const uint32_t dump = 512u + lane;
-        put_records<0>(cur, dup, pix0, rk[0], dump, rgb0, rgb1, slots);
-        put_records<1>(cur, dup, pix0 + pstep, rk[1], dump, rgb0, rgb1, slots);
-        put_records<2>(cur, dup, pix0 + 2u * pstep, rk[2], dump, rgb0, rgb1, slots);
-        put_records<3>(cur, dup, pix0 + 3u * pstep, rk[3], dump, rgb0, rgb1, slots);
-        wave_sync();                                      // records written by other lanes are read below
-        // Take delivery of the prefetched samples NOW, before this item's stores are issued: waited for
-        // later, the in-order vmcnt would make that wait cover the stores as well.
-        asm volatile("" : "+v"(nxt.g0.lo), "+v"(nxt.g0.hi), "+v"(nxt.g1.lo), "+v"(nxt.g1.hi), "+v"(nxt.y0.lo),
-                     "+v"(nxt.y0.hi), "+v"(nxt.y1.lo), "+v"(nxt.y1.hi));
-        asm volatile("" : "+v"(nxt.u0), "+v"(nxt.v0), "+v"(nxt.u1), "+v"(nxt.v1));
 
-        const uint32_t room = base < f.capacity ? f.capacity - base : 0u;   // never write past the caller's arrays
-        const uint32_t nw = (variant & 16u) ? 0u : (n < room ? n : room);
-        const PointSel sel = point_selectors(it);
-        // Two consecutive points per lane: one 16-B record read, one 12-B xyz store and one 6-B rgb store
-        // per lane and step — half the loop trips and less than half the store instructions of a
-        // point-per-lane loop (the CU issues a vector-memory instruction only every few cycles).
-        for (uint32_t k = 2u * lane; k < nw; k += 128u) {
-          const uint4 rr = *reinterpret_cast<const uint4*>(slots + k);       // records k and k+1
-          const bool two = k + 1u < nw;
-          uint2 p[2];
-          uint32_t rgb[2];
+        if (n != 0) {                                       // wave-uniform
+          uint32_t rk[4];
+          const uint32_t dup = (m_cur >> (16u + 4u * i)) & 0xFu;             // from the count phase
+          const uint32_t cnt = 2u * (uint32_t)__builtin_popcount(cur.occ) - (uint32_t)__builtin_popcount(dup);
+          pixel_ranks(it, cur, dup, cnt, lane, reinterpret_cast<unsigned char*>(slots), rk);
+          uint32_t rgb0[4] = {0, 0, 0, 0}, rgb1[4] = {0, 0, 0, 0};
+          if (f.has_attr && !(variant & 8u)) {
+            colours4(cur.y0, cur.u0, cur.v0, rgb0);
+            if (f.map_count > 1) colours4(cur.y1, cur.u1, cur.v1, rgb1);
+          }
+          // patch-local offsets of the lane's pixels: Default (du, dv) = (4q + j, r); Swap (du, dv) = (r, 4q + j)
+          const uint32_t q4 = 4u * (lane & 3u), r = lane >> 2;
+          const bool swap = it.flags & kTileSwap;
+          const uint32_t pix0 = swap ? q4 * 16u + r : r * 16u + q4, pstep = swap ? 16u : 1u;
+          const uint32_t dump = 512u + lane;
+          put_records<0>(cur, dup, pix0, rk[0], dump, rgb0, rgb1, slots);
+          put_records<1>(cur, dup, pix0 + pstep, rk[1], dump, rgb0, rgb1, slots);
+          put_records<2>(cur, dup, pix0 + 2u * pstep, rk[2], dump, rgb0, rgb1, slots);
+          put_records<3>(cur, dup, pix0 + 3u * pstep, rk[3], dump, rgb0, rgb1, slots);
+          wave_sync();                                      // records written by other lanes are read below
+          // Take delivery of the prefetched samples NOW, before this item's stores are issued: waited for
+          // later, the in-order vmcnt would make that wait cover the stores as well.
+          asm volatile("" : "+v"(nxt.g0.lo), "+v"(nxt.g0.hi), "+v"(nxt.g1.lo), "+v"(nxt.g1.hi), "+v"(nxt.y0.lo),
+                       "+v"(nxt.y0.hi), "+v"(nxt.y1.lo), "+v"(nxt.y1.hi));
+          asm volatile("" : "+v"(nxt.u0), "+v"(nxt.v0), "+v"(nxt.u1), "+v"(nxt.v1));
+
+          const uint32_t room = base < f.capacity ? f.capacity - base : 0u;   // never write past the caller's arrays
+          const uint32_t nw = (variant & 16u) ? 0u : (n < room ? n : room);
+          // Two consecutive points per lane: one 16-B record read, one 12-B xyz store and one 6-B rgb store
+          // per lane and step (the CU issues a vector-memory instruction only every few cycles).
+          for (uint32_t k = 2u * lane; k < nw; k += 128u) {
+            const uint4 rr = *reinterpret_cast<const uint4*>(slots + k);       // records k and k+1
+            const bool two = k + 1u < nw;
+            uint2 p[2];
+            uint32_t rgb[2];
 #pragma unroll
-          for (int h = 0; h < 2; ++h) {
-            // an odd tail has no second record: reuse the first (a stale slot could hold anything)
-            const uint32_t rx = (h && two) ? rr.z : rr.x, ry = (h && two) ? rr.w : rr.y;
-            const uint32_t depth = rx & 0xFFFFu, du = (rx >> 16) & 15u, dv = (rx >> 20) & 15u;
-            if (f.absolute_d1 || (rx >> 24) == 0) {
-              p[h] = pack_point(it, sel, depth, du, dv);
-            } else {                                      // relative D1: the D0 record of this pixel precedes it
-              const uint32_t d0 = h ? (rr.x & 0xFFFFu) : (slots[k - 1u].x & 0xFFFFu);
-              p[h] = relative_point(it, pack_point(it, sel, d0, du, dv), depth);
+            for (int h = 0; h < 2; ++h) {
+              // an odd tail has no second record: reuse the first (a stale slot could hold anything)
+              const uint32_t rx = (h && two) ? rr.z : rr.x, ry = (h && two) ? rr.w : rr.y;
+              const uint32_t depth = rx & 0xFFFFu, du = (rx >> 16) & 15u, dv = (rx >> 20) & 15u;
+              p[h] = pack_point(it, depth, du, dv);
+              if (!f.absolute_d1 && (rx >> 24) != 0) {      // relative D1: the D0 record of this pixel precedes it
+                const uint32_t d0 = h ? (rr.x & 0xFFFFu) : (slots[k - 1u].x & 0xFFFFu);
+                p[h] = relative_point(it.axes & 3u, it.flags & kTileMode1, pack_point(it, d0, du, dv), depth);
+              }
+              rgb[h] = ry;
             }
-            rgb[h] = ry;
+            if ((variant & 32u) && p[0].x != 0xFFFFFFFEu) continue;           // ablation: all the arithmetic, no stores
+            if (two) {
+              store_xyz2(gx, (base + k) * 6u, p[0], p[1]);
+              if (f.has_attr) store_rgb2(gc, (base + k) * 3u, rgb[0], rgb[1]);
+              if (gp) { gp[base + k] = (uint16_t)it.patch; gp[base + k + 1u] = (uint16_t)it.patch; }   // partition, codec.rs:452
+            } else {
+              store_xyz(gx, (base + k) * 6u, p[0]);
+              if (f.has_attr) store_rgb(gc, (base + k) * 3u, rgb[0]);
+              if (gp) gp[base + k] = (uint16_t)it.patch;
+            }
           }
-          if ((variant & 32u) && p[0].x != 0xFFFFFFFEu) continue;           // ablation: all the arithmetic, no stores
-          if (two) {
-            store_xyz2(gx, (base + k) * 6u, p[0], p[1]);
-            if (f.has_attr) store_rgb2(gc, (base + k) * 3u, rgb[0], rgb[1]);
-            if (gp) { gp[base + k] = (uint16_t)it.patch; gp[base + k + 1u] = (uint16_t)it.patch; }   // partition, codec.rs:452
-          } else {
-            store_xyz(gx, (base + k) * 6u, p[0]);
-            if (f.has_attr) store_rgb(gc, (base + k) * 3u, rgb[0]);
-            if (gp) gp[base + k] = (uint16_t)it.patch;
-          }
+          wave_sync();                                      // the next item overwrites the slots
         }
-        wave_sync();                                      // the next item overwrites the slots
+        base += n;
+        it = nit;
+        cur = nxt;
       }
-      base += n;
-      it = nit;
-      cur = nxt;
+      VPCC_STAMP(5)
     }
-    VPCC_STAMP(6)
     if (!have_next) break;
     g_cur = g_next;
     m_cur = m_next;
-    cb ^= 1u;
     total_cur = total_next;
+    cb ^= 1u;
+    have_cur = true;
   }
   if constexpr (kStamps) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  VPCC_STAMP(7)
+  VPCC_STAMP(6)
   VPCC_STAMP_FLUSH()
 }
 
