@@ -51,7 +51,10 @@ struct TileItem {
 };
 static_assert(sizeof(TileItem) == 32, "TileItem is 32 B");
 constexpr uint8_t kTileSwap = 1, kTileMode1 = 2;
-constexpr uint32_t kTileItemsPerWave = 4;
+#ifndef VPCC_TILE_ITEMS_PER_WAVE
+#define VPCC_TILE_ITEMS_PER_WAVE 4
+#endif
+constexpr uint32_t kTileItemsPerWave = VPCC_TILE_ITEMS_PER_WAVE;
 constexpr uint32_t kTileItemsPerGroup = 4 * kTileItemsPerWave;   // 4 waves: one ticket / one look-back word per group
 
 // Per-frame descriptor, resident in HBM, read by every kernel.

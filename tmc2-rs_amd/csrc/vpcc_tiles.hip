@@ -143,15 +143,27 @@ struct Samples {       // one item's samples of the lane's 4 pixels
   uint32_t occ;        // bit j: pixel j occupied
 };
 
+// Cache policy of the streaming accesses: bit 1 = output stores, bit 2 = attribute loads, bit 4 = the
+// per-item geometry re-read are issued non-temporal.  Measured on MI355X (S-longdress, 32 frames):
+// non-temporal STORES keep the 230 MB of output from evicting the geometry lines a group reads twice
+// (count, then emit one pipeline step later) out of the XCD's 4 MB L2 — 0.180 -> 0.150 ms and 70 MB
+// less L2-miss traffic; non-temporal LOADS make things worse (0.19 ms), so only bit 1 is on.
+#ifndef VPCC_TILES_NT
+#define VPCC_TILES_NT 1
+#endif
 // Plane loads take a wave-uniform base and a 32-bit BYTE offset per lane (saddr + voffset addressing:
 // no 64-bit address arithmetic in vector registers); tile_planes_aligned keeps planes below 4 GiB.
+template <bool kStream>
 __device__ __forceinline__ Px4 load4_row(const uint16_t* base, uint32_t byte_off) {   // 8-B aligned by construction
-  Px4 v;
-  __builtin_memcpy(&v, (const VPCC_GLOBAL unsigned char*)base + byte_off, 8);
-  return v;
+  typedef uint32_t v2 __attribute__((ext_vector_type(2)));
+  const VPCC_GLOBAL v2* p = (const VPCC_GLOBAL v2*)((const VPCC_GLOBAL unsigned char*)base + byte_off);
+  const v2 v = kStream ? __builtin_nontemporal_load(p) : *p;
+  return Px4{v.x, v.y};
 }
+template <bool kStream>
 __device__ __forceinline__ uint32_t load2(const uint16_t* base, uint32_t byte_off) {   // 4-B aligned by construction
-  return *reinterpret_cast<const VPCC_GLOBAL uint32_t*>((const VPCC_GLOBAL unsigned char*)base + byte_off);
+  const VPCC_GLOBAL uint32_t* p = (const VPCC_GLOBAL uint32_t*)((const VPCC_GLOBAL unsigned char*)base + byte_off);
+  return kStream ? __builtin_nontemporal_load(p) : *p;
 }
 // Lane l always reads the 4 CANVAS pixels x0 + 4*(l&3) .. +3 of canvas row y0 + (l>>2): 8 contiguous
 // bytes per plane, whatever the patch orientation.  For Default patches this is already the
@@ -186,12 +198,14 @@ __device__ __forceinline__ uint32_t occupancy_bits(const DevFrame& f, uint32_t r
 // Plane loads are UNCONDITIONAL (no exec-masked region, so loads of several items stay in flight
 // together): a lane without an occupied pixel reads the block's first pixels instead — a line the
 // wave touches anyway — and its samples are never used.
+template <bool kLastUse>
 __device__ __forceinline__ void load_geometry(const DevFrame& f, const Item& it, uint32_t lane, Samples& s) {
+  constexpr bool kS = kLastUse && (VPCC_TILES_NT & 4);
   uint32_t px0, py0;
   lane_origin(it, lane, px0, py0);
   if (s.occ == 0) { px0 = it.x0; py0 = it.y0; }
-  s.g0 = load4_row(f.geo[0], (__umul24(py0, f.geo_stride[0]) + px0) * 2u);
-  s.g1 = load4_row(f.geo[1], (__umul24(py0, f.geo_stride[1]) + px0) * 2u);      // single map: an alias of layer 0
+  s.g0 = load4_row<kS>(f.geo[0], (__umul24(py0, f.geo_stride[0]) + px0) * 2u);
+  s.g1 = load4_row<kS>(f.geo[1], (__umul24(py0, f.geo_stride[1]) + px0) * 2u);      // single map: an alias of layer 0
 }
 
 // Attribute samples; chroma is nearest-neighbour (src/decoder.rs:977): pixels 0,1 of the lane use
@@ -202,12 +216,13 @@ __device__ __forceinline__ void load_attributes(const DevFrame& f, const Item& i
   if (s.occ == 0) { px0 = it.x0; py0 = it.y0; }
   const uint32_t c0 = (__umul24(py0 >> 1, f.attr_cstride[0]) + (px0 >> 1)) * 2u;
   const uint32_t c1 = (__umul24(py0 >> 1, f.attr_cstride[1]) + (px0 >> 1)) * 2u;
-  s.y0 = load4_row(f.attr_y[0], (__umul24(py0, f.attr_stride[0]) + px0) * 2u);   // absent planes alias present ones
-  s.u0 = load2(f.attr_u[0], c0);
-  s.v0 = load2(f.attr_v[0], c0);
-  s.y1 = load4_row(f.attr_y[1], (__umul24(py0, f.attr_stride[1]) + px0) * 2u);
-  s.u1 = load2(f.attr_u[1], c1);
-  s.v1 = load2(f.attr_v[1], c1);
+  constexpr bool kS = VPCC_TILES_NT & 2;
+  s.y0 = load4_row<kS>(f.attr_y[0], (__umul24(py0, f.attr_stride[0]) + px0) * 2u);   // absent planes alias present ones
+  s.u0 = load2<kS>(f.attr_u[0], c0);
+  s.v0 = load2<kS>(f.attr_v[0], c0);
+  s.y1 = load4_row<kS>(f.attr_y[1], (__umul24(py0, f.attr_stride[1]) + px0) * 2u);
+  s.u1 = load2<kS>(f.attr_u[1], c1);
+  s.v1 = load2<kS>(f.attr_v[1], c1);
 }
 
 // Which D1 points duplicate their D0 point (src/codec.rs:422-427), one bit per pixel of the lane.
@@ -386,28 +401,36 @@ __device__ __forceinline__ unsigned long long stamp() {
     atomicAdd(&g_stamps[15], 1ull);                                                         \
   }
 
-struct __attribute__((packed)) Out6 { uint32_t xy; uint16_t z; };
-struct Out3 { uint8_t r, g, b; };
+typedef uint32_t u32x3 __attribute__((ext_vector_type(3)));
+typedef u32x3 u32x3_a4 __attribute__((aligned(4)));
+typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
+typedef uint32_t u32_a2 __attribute__((aligned(2)));
+typedef uint16_t u16_a2 __attribute__((aligned(2)));
+
+template <class T>
+__device__ __forceinline__ void out_store(VPCC_GLOBAL unsigned char* p, T v) {
+  if (VPCC_TILES_NT & 1) __builtin_nontemporal_store(v, (VPCC_GLOBAL T*)p);
+  else *(VPCC_GLOBAL T*)p = v;
+}
 
 // One point's 6 B (dword + short) / one colour's 3 B at a 32-bit byte offset from a uniform base:
 // consecutive lanes write consecutive points, so a wave covers 384 / 192 contiguous bytes.
 __device__ __forceinline__ void store_xyz(VPCC_GLOBAL unsigned char* base, uint32_t byte_off, uint2 p) {
-  const Out6 o6{p.x, (uint16_t)p.y};
-  __builtin_memcpy(base + byte_off, &o6, 6);
+  out_store<u32_a2>(base + byte_off, p.x);
+  out_store<u16_a2>(base + byte_off + 4, (uint16_t)p.y);
 }
-struct Out12 { uint32_t a, b, c; };
-struct __attribute__((packed)) Out6c { uint32_t a; uint16_t b; };
 __device__ __forceinline__ void store_xyz2(VPCC_GLOBAL unsigned char* base, uint32_t byte_off, uint2 p, uint2 q) {
-  const Out12 o{p.x, (p.y & 0xFFFFu) | (q.x << 16), (q.x >> 16) | (q.y << 16)};
-  __builtin_memcpy(base + byte_off, &o, 12);            // one unaligned dwordx3
+  u32x3 o;
+  o.x = p.x; o.y = (p.y & 0xFFFFu) | (q.x << 16); o.z = (q.x >> 16) | (q.y << 16);
+  out_store<u32x3_a4>(base + byte_off, o);               // one unaligned dwordx3
 }
 __device__ __forceinline__ void store_rgb2(VPCC_GLOBAL unsigned char* base, uint32_t byte_off, uint32_t c0, uint32_t c1) {
-  const Out6c o{(c0 & 0xFFFFFFu) | (c1 << 24), (uint16_t)(c1 >> 8)};
-  __builtin_memcpy(base + byte_off, &o, 6);
+  out_store<u32_a2>(base + byte_off, (c0 & 0xFFFFFFu) | (c1 << 24));
+  out_store<u16_a2>(base + byte_off + 4, (uint16_t)(c1 >> 8));
 }
 __device__ __forceinline__ void store_rgb(VPCC_GLOBAL unsigned char* base, uint32_t byte_off, uint32_t rgb) {
-  const Out3 o3{(uint8_t)rgb, (uint8_t)(rgb >> 8), (uint8_t)(rgb >> 16)};
-  __builtin_memcpy(base + byte_off, &o3, 3);
+  out_store<u16_a2>(base + byte_off, (uint16_t)rgb);
+  out_store<uint8_t>(base + byte_off + 2, (uint8_t)(rgb >> 16));
 }
 
 }  // namespace
@@ -447,14 +470,14 @@ void k_recon_tiles(const DevFrame* __restrict__ frames, uint32_t first,
   const uint32_t n_groups = (f.n_tiles + kTileItemsPerGroup - 1u) / kTileItemsPerGroup;
   const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = lane_id();
   constexpr uint32_t K = kTileItemsPerWave;
-  static_assert(K == 4, "one occupancy / duplicate nibble per item in a 16-bit half");
+  static_assert(K % 4 == 0 && K <= 8, "one occupancy / duplicate nibble per item in a 32-bit register");
 
   uint2* slots = s_slots[wave];
   VPCC_GLOBAL unsigned char* const gx = (VPCC_GLOBAL unsigned char*)f.out_xyz;
   VPCC_GLOBAL unsigned char* const gc = (VPCC_GLOBAL unsigned char*)f.out_rgb;
   VPCC_GLOBAL uint16_t* const gp = glw(f.out_patch);
 
-  uint32_t g_cur = 0, m_cur = 0, total_cur = 0, cb = 0;
+  uint32_t g_cur = 0, occ_cur = 0, dup_cur = 0, total_cur = 0, cb = 0;
   bool have_cur = false;
   for (;;) {
     // ---- 1. draw the NEXT group of this frame.  Every workgroup of the frame stops at its first ticket
@@ -473,28 +496,32 @@ void k_recon_tiles(const DevFrame* __restrict__ frames, uint32_t first,
 
     // ---- 2. count it: occupancy + geometry of the wave's 4 items, all loads of a kind issued together.
     // Geometry registers are transient (the per-item loop re-reads its samples, L2-hot); kept are the
-    // occupancy nibbles (low half of m_next) and the duplicate nibbles (high half).
-    uint32_t m_next = 0;
+    // occupancy nibbles (occ_next) and the duplicate nibbles (dup_next), one nibble per item.
+    uint32_t occ_next = 0, dup_next = 0;
     if (have_next) {
-      const uint32_t item0 = g_next * kTileItemsPerGroup + wave * K;
-      Item it4[4];
-      Samples s4[4];
-      uint32_t raw[4];
 #pragma unroll
-      for (int i = 0; i < 4; ++i) it4[i] = load_item(f.tiles + (item0 + i < f.n_tiles ? item0 + i : 0u));
+      for (uint32_t c0 = 0; c0 < K; c0 += 4u) {            // four items' loads in flight at a time
+        const uint32_t item0 = g_next * kTileItemsPerGroup + wave * K + c0;
+        Item it4[4];
+        Samples s4[4];
+        uint32_t raw[4];
 #pragma unroll
-      for (int i = 0; i < 4; ++i) raw[i] = load_occupancy_raw(f, it4[i], lane);
+        for (int i = 0; i < 4; ++i) it4[i] = load_item(f.tiles + (item0 + i < f.n_tiles ? item0 + i : 0u));
 #pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        s4[i].occ = item0 + i < f.n_tiles ? occupancy_bits(f, raw[i]) : 0u;   // past the end: an empty copy of item 0
-        load_geometry(f, it4[i], lane, s4[i]);
-      }
+        for (int i = 0; i < 4; ++i) raw[i] = load_occupancy_raw(f, it4[i], lane);
 #pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        const uint32_t dup = classify(f, it4[i], s4[i]) & s4[i].occ;
-        m_next |= (s4[i].occ << (4u * i)) | (dup << (16u + 4u * i));
-        const uint32_t cnt = wave_sum(2u * (uint32_t)__builtin_popcount(s4[i].occ) - (uint32_t)__builtin_popcount(dup));
-        if (lane == 0) s_tot[cb ^ 1u][wave * K + i] = cnt;
+        for (int i = 0; i < 4; ++i) {
+          s4[i].occ = item0 + i < f.n_tiles ? occupancy_bits(f, raw[i]) : 0u;   // past the end: an empty copy of item 0
+          load_geometry<false>(f, it4[i], lane, s4[i]);
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          const uint32_t dup = classify(f, it4[i], s4[i]) & s4[i].occ;
+          occ_next |= s4[i].occ << (4u * (c0 + i));
+          dup_next |= dup << (4u * (c0 + i));
+          const uint32_t cnt = wave_sum(2u * (uint32_t)__builtin_popcount(s4[i].occ) - (uint32_t)__builtin_popcount(dup));
+          if (lane == 0) s_tot[cb ^ 1u][wave * K + c0 + i] = cnt;
+        }
       }
     }
     VPCC_STAMP(1)
@@ -508,14 +535,14 @@ void k_recon_tiles(const DevFrame* __restrict__ frames, uint32_t first,
     if (have_cur) {
       const uint32_t first_item = g_cur * kTileItemsPerGroup + wave * K;
       it = load_item(f.tiles + (first_item < f.n_tiles ? first_item : 0u));
-      cur.occ = m_cur & 0xFu;
-      load_geometry(f, it, lane, cur);
+      cur.occ = occ_cur & 0xFu;
+      load_geometry<true>(f, it, lane, cur);
       load_attributes(f, it, lane, cur);
     }
     uint32_t total_next = 0;
     if (wave == 0) {
       if (have_next) {
-        total_next = lane < kTileItemsPerGroup ? s_tot[cb ^ 1u][lane] : 0u;
+        total_next = lane < kTileItemsPerGroup ? s_tot[cb ^ 1u][lane] : 0u;   // kTileItemsPerGroup <= 64
         total_next = wave_sum(total_next);
         if (lane == 0)
           st_store(f.scan_state + g_next, ((uint64_t)gen << kGenShift) | (g_next == 0 ? kPrefix : kAggregate) | total_next);
@@ -551,14 +578,14 @@ void k_recon_tiles(const DevFrame* __restrict__ frames, uint32_t first,
         if (i + 1u < K) {
           const uint32_t next_item = g_cur * kTileItemsPerGroup + wave * K + i + 1u;
           nit = load_item(f.tiles + (next_item < f.n_tiles ? next_item : 0u));
-          nxt.occ = (m_cur >> (4u * (i + 1u))) & 0xFu;
-          load_geometry(f, nit, lane, nxt);
+          nxt.occ = (occ_cur >> (4u * (i + 1u))) & 0xFu;
+          load_geometry<true>(f, nit, lane, nxt);
           load_attributes(f, nit, lane, nxt);
         }
 
         if (n != 0) {                                       // wave-uniform
           uint32_t rk[4];
-          const uint32_t dup = (m_cur >> (16u + 4u * i)) & 0xFu;             // from the count phase
+          const uint32_t dup = (dup_cur >> (4u * i)) & 0xFu;                 // from the count phase
           const uint32_t cnt = 2u * (uint32_t)__builtin_popcount(cur.occ) - (uint32_t)__builtin_popcount(dup);
           pixel_ranks(it, cur, dup, cnt, lane, reinterpret_cast<unsigned char*>(slots), rk);
           uint32_t rgb0[4] = {0, 0, 0, 0}, rgb1[4] = {0, 0, 0, 0};
@@ -624,7 +651,8 @@ void k_recon_tiles(const DevFrame* __restrict__ frames, uint32_t first,
     }
     if (!have_next) break;
     g_cur = g_next;
-    m_cur = m_next;
+    occ_cur = occ_next;
+    dup_cur = dup_next;
     total_cur = total_next;
     cb ^= 1u;
     have_cur = true;
