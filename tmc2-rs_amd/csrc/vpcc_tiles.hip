@@ -66,16 +66,37 @@ __device__ __forceinline__ uint32_t status_of(uint64_t s, uint32_t gen) {
   return (uint32_t)(s >> kGenShift) == gen ? (uint32_t)(s >> kStatusShift) & 3u : 0u;
 }
 
-__device__ uint32_t look_back_groups(const DevFrame& f, uint32_t g, uint32_t gen) {
+// Wave-wide inclusive scan / sum with DPP row shifts and row broadcasts (gfx9 DPP controls; no LDS).
+template <int kCtrl, int kRowMask>
+__device__ __forceinline__ uint32_t dpp_add(uint32_t v) {
+  return v + (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, kCtrl, kRowMask, 0xF, kRowMask == 0xF);
+}
+__device__ __forceinline__ uint32_t wave_inclusive_scan(uint32_t v) {
+  v = dpp_add<0x111, 0xF>(v);        // row_shr:1   (lanes shifted in from outside the row read 0)
+  v = dpp_add<0x112, 0xF>(v);        // row_shr:2
+  v = dpp_add<0x114, 0xF>(v);        // row_shr:4
+  v = dpp_add<0x118, 0xF>(v);        // row_shr:8   -> scan inside each row of 16
+  v = dpp_add<0x142, 0xA>(v);        // row_bcast:15 into rows 1 and 3
+  v = dpp_add<0x143, 0xC>(v);        // row_bcast:31 into rows 2 and 3
+  return v;
+}
+__device__ __forceinline__ uint32_t wave_sum(uint32_t v) {
+  return (uint32_t)__builtin_amdgcn_readlane((int)wave_inclusive_scan(v), 63);
+}
+
+// `early` is this lane's word of the first 64 predecessors, read speculatively before the caller's
+// count phase (the words of a pipelined group were published a step ago, so it is normally final).
+__device__ uint32_t look_back_groups(const DevFrame& f, uint32_t g, uint32_t gen, uint64_t early) {
   uint32_t excl = 0;
   int32_t idx = (int32_t)g - 1;
   const uint32_t lane = lane_id();
+  bool first = true;
   while (idx >= 0) {
     const int32_t my = idx - (int32_t)lane;
     uint64_t s = ((uint64_t)gen << kGenShift) | kPrefix;
     if (my >= 0) {
       uint32_t spins = 0;
-      s = st_load(f.scan_state + my);
+      s = first ? early : st_load(f.scan_state + my);
       while (status_of(s, gen) == 0) {
         __builtin_amdgcn_s_sleep(8);
         if (++spins > kSpinLimit) {               // never reached in a healthy run; reported by the host
@@ -86,10 +107,11 @@ __device__ uint32_t look_back_groups(const DevFrame& f, uint32_t g, uint32_t gen
         s = st_load(f.scan_state + my);
       }
     }
+    first = false;
     const uint64_t pm = __ballot(status_of(s, gen) == 2);
     const uint32_t firstp = pm ? (uint32_t)__builtin_ctzll(pm) : 64u;
     uint32_t v = lane <= firstp ? (uint32_t)s : 0u;
-    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+    v = wave_sum(v);
     excl += v;
     if (pm) break;
     idx -= 64;
@@ -325,24 +347,6 @@ __device__ __forceinline__ void put_records(const Samples& s, uint32_t dup, uint
   slots[second ? rank + 1u : dump] = make_uint2((px<J>(s.g1) >> 2) | (pixel << 16) | (1u << 24), rgb1[J]);
 }
 
-// Wave-wide inclusive scan / sum with DPP row shifts and row broadcasts (gfx9 DPP controls; no LDS).
-template <int kCtrl, int kRowMask>
-__device__ __forceinline__ uint32_t dpp_add(uint32_t v) {
-  return v + (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, kCtrl, kRowMask, 0xF, kRowMask == 0xF);
-}
-__device__ __forceinline__ uint32_t wave_inclusive_scan(uint32_t v) {
-  v = dpp_add<0x111, 0xF>(v);        // row_shr:1   (lanes shifted in from outside the row read 0)
-  v = dpp_add<0x112, 0xF>(v);        // row_shr:2
-  v = dpp_add<0x114, 0xF>(v);        // row_shr:4
-  v = dpp_add<0x118, 0xF>(v);        // row_shr:8   -> scan inside each row of 16
-  v = dpp_add<0x142, 0xA>(v);        // row_bcast:15 into rows 1 and 3
-  v = dpp_add<0x143, 0xC>(v);        // row_bcast:31 into rows 2 and 3
-  return v;
-}
-__device__ __forceinline__ uint32_t wave_sum(uint32_t v) {
-  return (uint32_t)__builtin_amdgcn_readlane((int)wave_inclusive_scan(v), 63);
-}
-
 // Ranks of the lane's 4 pixels inside the item, emission order (src/codec.rs:382-385: v1 outer, u1 inner).
 //   Default patch: u runs along the canvas row, so lane order then pixel order is the emission order.
 //   Swap patch   : u runs down the canvas column.  The per-pixel counts go through a 16x16 byte matrix
@@ -461,7 +465,6 @@ void k_recon_tiles(const DevFrame* __restrict__ frames, uint32_t first,
   const DevFrame& f = frames[first + fi];
 
   __shared__ uint32_t s_group;
-  __shared__ uint32_t s_base;
   __shared__ uint32_t s_tot[2][kTileItemsPerGroup];                     // point counts of the two groups in flight
   __shared__ __attribute__((aligned(16))) uint2 s_slots[4][kSlotsPerWave];
 
@@ -492,6 +495,8 @@ void k_recon_tiles(const DevFrame* __restrict__ frames, uint32_t first,
     __syncthreads();
     const uint32_t g_next = __builtin_amdgcn_readfirstlane(s_group);
     const bool have_next = g_next < n_groups;
+    uint64_t early = 0;                                    // speculative read of the current group's look-back words
+    if (have_cur && lane < g_cur) early = st_load(f.scan_state + (g_cur - 1u - lane));
     VPCC_STAMP(0)
 
     // ---- 2. count it: occupancy + geometry of the wave's 4 items, all loads of a kind issued together.
@@ -528,45 +533,36 @@ void k_recon_tiles(const DevFrame* __restrict__ frames, uint32_t first,
     __syncthreads();
     VPCC_STAMP(2)
 
-    // ---- 3. wave 0 publishes the next group's total, THEN looks back for the current group, whose total
-    // has been public for a whole step; the other waves already fetch their first item's samples.
-    Item it;
-    Samples cur;
-    if (have_cur) {
-      const uint32_t first_item = g_cur * kTileItemsPerGroup + wave * K;
-      it = load_item(f.tiles + (first_item < f.n_tiles ? first_item : 0u));
-      cur.occ = occ_cur & 0xFu;
-      load_geometry<true>(f, it, lane, cur);
-      load_attributes(f, it, lane, cur);
-    }
+    // ---- 3. wave 0 publishes the next group's total.  Then EVERY wave looks back for the current group
+    // (whose total has been public for a whole step: the words were read before the count phase), so no
+    // wave waits for another one here; wave 0 also publishes the group's inclusive prefix.
     uint32_t total_next = 0;
-    if (wave == 0) {
-      if (have_next) {
-        total_next = lane < kTileItemsPerGroup ? s_tot[cb ^ 1u][lane] : 0u;   // kTileItemsPerGroup <= 64
-        total_next = wave_sum(total_next);
-        if (lane == 0)
-          st_store(f.scan_state + g_next, ((uint64_t)gen << kGenShift) | (g_next == 0 ? kPrefix : kAggregate) | total_next);
-      }
-      if (have_cur) {
-        uint32_t excl = (variant & 1u) ? g_cur * 7000u : 0u;   // ablation: no wait, outputs still spread over the frame
-        if (g_cur != 0 && !(variant & 1u)) {
-          excl = look_back_groups(f, g_cur, gen);
-          if (lane == 0)
-            st_store(f.scan_state + g_cur, ((uint64_t)gen << kGenShift) | kPrefix | (uint64_t)(excl + total_cur));
-        }
-        if (lane == 0) {
-          s_base = excl;
-          if (g_cur + 1u == n_groups)                                        // tile.total_number_of_regular_points
-            *glw(f.n_points) = (variant & 1u) ? (excl + total_cur < f.capacity ? excl + total_cur : f.capacity) : excl + total_cur;
-        }
-      }
+    if (wave == 0 && have_next) {
+      total_next = lane < kTileItemsPerGroup ? s_tot[cb ^ 1u][lane] : 0u;   // kTileItemsPerGroup <= 64
+      total_next = wave_sum(total_next);
+      if (lane == 0)
+        st_store(f.scan_state + g_next, ((uint64_t)gen << kGenShift) | (g_next == 0 ? kPrefix : kAggregate) | total_next);
     }
     VPCC_STAMP(3)
 
     if (have_cur) {
-      __syncthreads();
+      const uint32_t first_item = g_cur * kTileItemsPerGroup + wave * K;
+      Item it = load_item(f.tiles + (first_item < f.n_tiles ? first_item : 0u));
+      Samples cur;
+      cur.occ = occ_cur & 0xFu;
+      load_geometry<true>(f, it, lane, cur);
+      load_attributes(f, it, lane, cur);
+
+      uint32_t excl = (variant & 1u) ? g_cur * 7000u : 0u;   // ablation: no wait, outputs still spread over the frame
+      if (g_cur != 0 && !(variant & 1u)) excl = look_back_groups(f, g_cur, gen, early);
+      if (wave == 0 && lane == 0) {
+        if (g_cur != 0 && !(variant & 1u))
+          st_store(f.scan_state + g_cur, ((uint64_t)gen << kGenShift) | kPrefix | (uint64_t)(excl + total_cur));
+        if (g_cur + 1u == n_groups)                                        // tile.total_number_of_regular_points
+          *glw(f.n_points) = (variant & 1u) ? (excl + total_cur < f.capacity ? excl + total_cur : f.capacity) : excl + total_cur;
+      }
       VPCC_STAMP(4)
-      uint32_t base = s_base;
+      uint32_t base = excl;
       for (uint32_t k = 0; k < wave * K; ++k) base += s_tot[cb][k];
 
       // ---- 4. per item: colours, compaction of the records through LDS, then lane <-> point ---------
