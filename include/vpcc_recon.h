@@ -266,6 +266,15 @@ int vpcc_gof_smooth(vpcc_gof* gof, uint32_t first, uint32_t count, const vpcc_sm
  * presentation order through a capacity-1 channel. */
 typedef struct vpcc_decoder vpcc_decoder;
 int  vpcc_decoder_open(const char* path, const int* devices, int n_devices, vpcc_decoder** out);
+/* Same decoder on a V3C sample stream (.bin) parsed by the library (vpcc_v3c_*), with the three video
+ * sub-bitstreams decoded by an EXTERNAL HEVC decoder into raw planar 4:2:0 files in the decoder's native
+ * format, all GOFs back to back: occupancy 8-bit, geometry / attribute 16-bit little endian — the bytes the
+ * reference copies out of libav's frames (src/decoder.rs:1131-1141).  `attribute_yuv` may be null;
+ * `occupancy_precision` = frame width / occupancy video width (src/decoder.rs:194).  A stream the parser
+ * rejects makes vpcc_decoder_start fail with the text in vpcc_decoder_error. */
+int vpcc_decoder_open_v3c(const char* bin_path, const char* occupancy_yuv, const char* geometry_yuv,
+                          const char* attribute_yuv, uint32_t occupancy_precision, const int* devices,
+                          int n_devices, vpcc_decoder** out);
 /* VPCC_ERR_STATE when called twice (the reference panics: "can only be started once"). */
 int  vpcc_decoder_start(vpcc_decoder* dec);
 /* 1 and the next frame (pointers valid until the next call), or 0 at end of stream — also after a
@@ -318,6 +327,47 @@ typedef struct vpcc_intra_pdu {
   uint32_t projection_id, orientation_index, lod_enabled_flag, reserved;
 } vpcc_intra_pdu;
 int   vpcc_patch_from_intra_pdu(const vpcc_patch_frame_params* fp, const vpcc_intra_pdu* pdu, vpcc_patch* out);
+
+/* V3C / V-PCC high-level syntax (SampleStreamV3CUnit::decode + V3CUnit::decode, src/bitstream/reader.rs:23-160,
+ * 257-2037) and the per-GOF patch frames / reconstruction parameters (Decoder::create_patch_frame and
+ * new_generate_point_cloud_params, src/decoder.rs:320-517, 590-627).  One GOF = the V3C units up to the next
+ * V3C parameter set (src/lib.rs:119-133).  Features the reference rejects (assert!/unimplemented!) return
+ * VPCC_ERR_UNSUPPORTED, malformed streams VPCC_ERR_INVALID_ARG; after an error the stream yields no more
+ * GOFs, like the reference's worker thread, which dies on the panic. */
+typedef struct vpcc_v3c_stream vpcc_v3c_stream;
+typedef struct vpcc_v3c_gof_info {
+  uint32_t frame_count;                      /* atlas tile layers == frames of the GOF                         */
+  uint32_t frame_width, frame_height;        /* vps (what occupancy_precision is derived from, decoder.rs:194) */
+  uint32_t atlas_frame_width, atlas_frame_height;   /* asps                                                    */
+  uint32_t map_count;                        /* vps.map_count_minus1 + 1                                       */
+  uint32_t absolute_d1;                      /* map_count_minus1 == 0 || map_absolute_coding_enable_flag[1]    */
+  uint32_t occupancy_resolution;             /* 1 << asps.log2_patch_packing_block_size                        */
+  uint32_t geometry_3d_bitdepth;             /* gi.geometry_3d_coordinates_bitdepth_minus1 + 1                 */
+  uint32_t atlas_geometry_3d_bitdepth;       /* asps.geometry_3d_bitdepth_minus1 + 1 (patch d1, decoder.rs:471) */
+  uint32_t geometry_2d_bitdepth, occupancy_2d_bitdepth, attribute_2d_bitdepth;
+  uint32_t attribute_count;
+  uint32_t occupancy_codec_id, geometry_codec_id, attribute_codec_id;
+  uint32_t profile_codec_group_idc, profile_toolset_idc, profile_reconstruction_idc, level_idc;
+  uint32_t use_eight_orientations_flag, remove_duplicate_point_enabled_flag;
+  uint32_t geometry_smoothing_sei;           /* a prefix geometry-smoothing SEI precedes the first tile layer  */
+  uint32_t smoothing_grid_size, smoothing_threshold;   /* grid_size_minus_2 + 2, threshold of its method-1 instance */
+  uint32_t reserved;
+  size_t   video_bytes[3];                   /* occupancy, geometry, attribute video sub-bitstream sizes       */
+} vpcc_v3c_gof_info;
+int   vpcc_v3c_open(const uint8_t* data, size_t n, vpcc_v3c_stream** out);
+void  vpcc_v3c_close(vpcc_v3c_stream* s);
+const char* vpcc_v3c_error(const vpcc_v3c_stream* s);
+uint32_t vpcc_v3c_unit_count(const vpcc_v3c_stream* s);
+/* Parses the next GOF; *have_gof = 0 at the end of the stream.  `info` may be null. */
+int   vpcc_v3c_next_gof(vpcc_v3c_stream* s, int* have_gof, vpcc_v3c_gof_info* info);
+/* Patches of frame `frame` of the current GOF in atlas order; `out` may be null to query the count.
+ * *frame_index receives the atlas frame order count (as the reference's u8 frame_index). */
+int   vpcc_v3c_frame_patches(const vpcc_v3c_stream* s, uint32_t frame, vpcc_patch* out, uint32_t capacity,
+                             uint32_t* n_patches, uint32_t* frame_index);
+/* Video sub-bitstream of the current GOF (0 occupancy, 1 geometry, 2 attribute), sample-stream framed: pass it
+ * to vpcc_sample_stream_to_bytestream for an external video decoder.  The pointer lives until the next call
+ * of vpcc_v3c_next_gof / vpcc_v3c_close. */
+int   vpcc_v3c_video(const vpcc_v3c_stream* s, int video, const uint8_t** data, size_t* n);
 
 #ifdef __cplusplus
 }

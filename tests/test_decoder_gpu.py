@@ -41,3 +41,35 @@ def test_decoder_error_ends_stream_early(tmp_path):
     assert len(frames) == 1                             # first GOF delivered, then the stream just ends
     assert "canvas" in d.error()
     d.close()
+
+
+def test_decoder_on_a_v3c_stream_with_raw_decoded_video(tmp_path):
+    """.bin parsed by the C++ syntax parser + externally 'decoded' planar videos -> the same points as the
+    oracle on the frames the stream was written from (tests/v3c_writer.py)."""
+    import v3c_writer as W
+    gofs = [[cases.medium_frame(i) for i in range(3)], [cases.medium_frame(40 + i, occupancy_values="random") for i in range(2)]]
+    paths = W.write_sequence(tmp_path, gofs)
+    d = recon.Decoder(paths["bin"], occupancy_yuv=paths["occ"], geometry_yuv=paths["geo"], attribute_yuv=paths["attr"])
+    d.start()
+    frames = list(d)
+    assert d.error() == ""
+    expected = [f for g in gofs for f in g]
+    assert len(frames) == len(expected)
+    for got, f in zip(frames, expected):
+        st, ref = ob.reconstruct(f)
+        assert st == 0 and got["n"] == ref["n"]
+        assert np.array_equal(got["xyz"], ob.xyz_array(ref)) and np.array_equal(got["rgb"], ob.rgb_array(ref))
+    d.close()
+
+
+def test_decoder_v3c_short_video_and_unsupported_stream(tmp_path):
+    import v3c_writer as W
+    gofs = [[cases.medium_frame(i) for i in range(2)]]
+    paths = W.write_sequence(tmp_path, gofs)
+    with open(paths["geo"], "r+b") as f:
+        f.truncate(1000)
+    d = recon.Decoder(paths["bin"], occupancy_yuv=paths["occ"], geometry_yuv=paths["geo"], attribute_yuv=paths["attr"])
+    with pytest.raises(recon.VpccError) as e:
+        d.start()
+    assert "geometry video shorter" in str(e.value)
+    d.close()

@@ -7,8 +7,8 @@
 //                                                       src/bitstream.rs:216-289
 //   the Intra-PDU -> Patch mapping of create_patch_frame   src/decoder.rs:415-486
 // Pinned by the reference's own five bit-reader tests (src/bitstream.rs:349-437), re-expressed in
-// tests/test_bitstream.py with the same vectors.  The atlas syntax parser itself (VPS/ASPS/AFPS/ATL,
-// src/bitstream/reader.rs) is a later round.
+// tests/test_bitstream.py with the same vectors.  The atlas syntax parser (VPS/ASPS/AFPS/SEI/ATL,
+// src/bitstream/reader.rs) is v3c_syntax.{hpp,cpp}.
 #pragma once
 
 #include <cstddef>
@@ -32,6 +32,7 @@ class Bitstream {
   void copy_from(Bitstream& src, size_t start_byte, size_t size);   // advances BOTH positions by `size`
   bool more_data() const { return bytes_ < data_.size(); }
   void reset() { bytes_ = 0; bits_ = 0; }
+  void seek(size_t byte) { bytes_ = byte; bits_ = 0; }
   size_t position_bytes() const { return bytes_; }
   unsigned position_bits() const { return bits_; }
   const std::vector<uint8_t>& data() const { return data_; }

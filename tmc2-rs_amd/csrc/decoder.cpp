@@ -1,6 +1,7 @@
 // decoder.cpp — C++ host mirror of src/lib.rs + the per-GOF driver of src/decoder.rs:188-314, running the
 // reconstruction on one or several MI355X through the C ABI (include/vpcc_recon.h).
 #include "decoder.hpp"
+#include "v3c_syntax.hpp"
 
 #include <chrono>
 #include <cstdio>
@@ -87,6 +88,86 @@ bool parse_container(const std::vector<unsigned char>& buf, std::vector<DecodedG
   return true;
 }
 
+// ------------------------------------------------------------------ V3C sample stream + raw decoded video
+// The per-GOF driver of the reference (src/decoder.rs:82-314) with the three decompress() calls replaced by
+// raw planar files: frame f of a GOF uses occupancy frame f and geometry / attribute frames f*map_count + m
+// (src/codec.rs:317, 589-590).
+bool parse_v3c_with_raw_video(const std::vector<unsigned char>& bin, const unsigned char* occ, size_t occ_bytes,
+                              const unsigned char* geo, size_t geo_bytes, const unsigned char* attr, size_t attr_bytes,
+                              uint32_t occupancy_precision, std::vector<DecodedGof>* gofs, std::string* err, int* status) {
+  *status = VPCC_ERR_INVALID_ARG;
+  gofs->clear();
+  if (occupancy_precision == 0) { *err = "occupancy_precision is zero"; return false; }
+  std::vector<V3CUnit> units;
+  try {
+    Bitstream bs(std::vector<uint8_t>(bin.begin(), bin.end()));
+    size_t header = 0;
+    units = split_sample_stream(bs, &header);
+  } catch (const std::exception& e) {
+    *err = std::string("not a V3C sample stream: ") + e.what();
+    return false;
+  }
+  size_t next = 0, occ_off = 0, geo_off = 0, attr_off = 0;
+  while (next < units.size()) {                       // while ssvu.get_v3c_unit_count() > 0, src/lib.rs:118
+    GofSyntax syn;
+    std::vector<PatchFrame> frames;
+    GofParams gp;
+    try {
+      next = parse_gof(units, next, &syn);
+      gp = build_gof_params(syn);
+      frames = build_patch_frames(syn);
+    } catch (const SyntaxError& e) {
+      *err = e.what();
+      *status = e.status;
+      return false;
+    }
+    const uint32_t W = gp.frame_width, H = gp.frame_height;
+    if (W == 0 || H == 0 || W % occupancy_precision || H % occupancy_precision || (W & 1) || (H & 1)) {
+      *err = "frame size not divisible by the occupancy precision / not even";
+      return false;
+    }
+    if (gp.map_count > 2) { *err = "more than two maps"; *status = VPCC_ERR_UNSUPPORTED; return false; }
+    const uint32_t ow = W / occupancy_precision, oh = H / occupancy_precision;
+    const size_t occ_frame = (size_t)ow * oh + 2 * (size_t)((ow + 1) / 2) * ((oh + 1) / 2);
+    const size_t luma = (size_t)W * H * 2, chroma = (size_t)(W / 2) * (H / 2) * 2;
+    const size_t vid_frame = luma + 2 * chroma;
+    const bool has_attr = !syn.vps.ai.attributes.empty();
+    DecodedGof gof;
+    gof.patch_store.reserve(frames.size());
+    for (size_t f = 0; f < frames.size(); ++f) {
+      vpcc_frame_desc d{};
+      d.width = W; d.height = H;
+      d.occupancy_resolution = gp.occupancy_resolution;
+      d.occupancy_precision = occupancy_precision;
+      d.map_count = gp.map_count;
+      d.absolute_d1 = gp.absolute_d1 ? 1u : 0u;
+      d.attribute_count = has_attr ? 1u : 0u;
+      gof.patch_store.push_back(std::move(frames[f].patches));
+      d.patch_count = (uint32_t)gof.patch_store.back().size();
+      d.patches = d.patch_count ? gof.patch_store.back().data() : nullptr;
+      if (occ_off + occ_frame > occ_bytes) { *err = "occupancy video shorter than the atlas"; *status = VPCC_ERR_SHORT_VIDEO; return false; }
+      d.occupancy = vpcc_image_u8{occ + occ_off, ow, oh, ow};
+      occ_off += occ_frame;
+      for (uint32_t m = 0; m < gp.map_count; ++m) {
+        if (geo_off + vid_frame > geo_bytes) { *err = "geometry video shorter than the atlas"; *status = VPCC_ERR_SHORT_VIDEO; return false; }
+        d.geometry[m] = vpcc_image_u16{reinterpret_cast<const uint16_t*>(geo + geo_off), nullptr, nullptr, W, H, W, W / 2};
+        geo_off += vid_frame;
+        if (has_attr) {
+          if (attr_off + vid_frame > attr_bytes) { *err = "attribute video shorter than the atlas"; *status = VPCC_ERR_SHORT_VIDEO; return false; }
+          const unsigned char* a = attr + attr_off;
+          d.attribute[m] = vpcc_image_u16{reinterpret_cast<const uint16_t*>(a), reinterpret_cast<const uint16_t*>(a + luma),
+                                          reinterpret_cast<const uint16_t*>(a + luma + chroma), W, H, W, W / 2};
+          attr_off += vid_frame;
+        }
+      }
+      gof.frames.push_back(d);
+    }
+    gofs->push_back(std::move(gof));
+  }
+  *status = VPCC_OK;
+  return true;
+}
+
 // ------------------------------------------------------------------ PinnedPool
 PinnedPool::~PinnedPool() { detach(); }
 
@@ -135,13 +216,34 @@ void Decoder::start() {
   if (started_) throw std::logic_error("library decoder can only be started once");   // src/lib.rs:108-111
   started_ = true;
   // Bitstream::from_file on the caller's thread (src/lib.rs:98); the reference unwraps the io error
-  std::ifstream in(params_.compressed_stream_path, std::ios::binary | std::ios::ate);
-  if (!in) throw std::runtime_error("cannot open " + params_.compressed_stream_path);
-  file_.resize((size_t)in.tellg());
-  in.seekg(0);
-  in.read(reinterpret_cast<char*>(file_.data()), (std::streamsize)file_.size());
+  auto slurp = [](const std::string& path, std::vector<unsigned char>* out, size_t at) {
+    std::ifstream in(path, std::ios::binary | std::ios::ate);
+    if (!in) throw std::runtime_error("cannot open " + path);
+    const size_t n = (size_t)in.tellg();
+    out->resize(at + ((n + 15) & ~size_t(15)));        // next section starts 16-B aligned
+    in.seekg(0);
+    in.read(reinterpret_cast<char*>(out->data() + at), (std::streamsize)n);
+    return n;
+  };
+  std::vector<unsigned char> head;
+  head.resize(slurp(params_.compressed_stream_path, &head, 0));   // no padding behind the stream itself
   std::string err;
-  if (!parse_container(file_, &gofs_, &err)) throw std::runtime_error(err);
+  if (head.size() >= 8 && std::memcmp(head.data(), "VPCCGOF1", 8) == 0) {
+    file_ = std::move(head);
+    if (!parse_container(file_, &gofs_, &err)) throw std::runtime_error(err);
+  } else {
+    if (params_.occupancy_yuv_path.empty() || params_.geometry_yuv_path.empty())
+      throw std::runtime_error("V3C input needs the externally decoded occupancy and geometry videos "
+                               "(HEVC decoding is not part of this library)");
+    bin_ = std::move(head);
+    const size_t o0 = 0, on = slurp(params_.occupancy_yuv_path, &file_, o0);
+    const size_t g0 = file_.size(), gn = slurp(params_.geometry_yuv_path, &file_, g0);
+    const size_t a0 = file_.size(), an = params_.attribute_yuv_path.empty() ? 0 : slurp(params_.attribute_yuv_path, &file_, a0);
+    int status = 0;
+    if (!parse_v3c_with_raw_video(bin_, file_.data() + o0, on, file_.data() + g0, gn, file_.data() + a0, an,
+                                  params_.occupancy_precision, &gofs_, &err, &status))
+      throw std::runtime_error(std::string(vpcc_status_string(status)) + ": " + err);
+  }
   thread_ = std::thread([this] { worker(); });
 }
 
@@ -292,6 +394,20 @@ struct vpcc_decoder {
 extern "C" int vpcc_decoder_open(const char* path, const int* devices, int n_devices, vpcc_decoder** out) {
   if (!path || !out) return VPCC_ERR_INVALID_ARG;
   tmc2rs::Params p{std::string(path)};
+  if (devices && n_devices > 0) p.devices.assign(devices, devices + n_devices);
+  *out = new vpcc_decoder(std::move(p));
+  return VPCC_OK;
+}
+
+extern "C" int vpcc_decoder_open_v3c(const char* bin_path, const char* occupancy_yuv, const char* geometry_yuv,
+                                     const char* attribute_yuv, uint32_t occupancy_precision, const int* devices,
+                                     int n_devices, vpcc_decoder** out) {
+  if (!bin_path || !occupancy_yuv || !geometry_yuv || !out) return VPCC_ERR_INVALID_ARG;
+  tmc2rs::Params p{std::string(bin_path)};
+  p.occupancy_yuv_path = occupancy_yuv;
+  p.geometry_yuv_path = geometry_yuv;
+  if (attribute_yuv) p.attribute_yuv_path = attribute_yuv;
+  p.occupancy_precision = occupancy_precision;
   if (devices && n_devices > 0) p.devices.assign(devices, devices + n_devices);
   *out = new vpcc_decoder(std::move(p));
   return VPCC_OK;

@@ -9,7 +9,8 @@
 //     reference's consumer sees None after a worker panic (src/lib.rs:113-145).
 // The reconstruction itself is the GPU path behind include/vpcc_recon.h.  Input is a decoded-GOF
 // container (.vpccgof: patch tables + decoded planes, i.e. the state after the reference's three
-// decompress() calls, src/decoder.rs:82-171); V3C parsing and HEVC decoding are out of scope here.
+// decompress() calls, src/decoder.rs:82-171), or a V3C sample stream parsed by v3c_syntax.cpp together with
+// its externally decoded raw videos; HEVC decoding itself is out of scope (no decoder in this image).
 #pragma once
 
 #include <condition_variable>
@@ -26,9 +27,16 @@
 namespace tmc2rs {
 
 struct Params {                       // src/lib.rs:23-57
-  std::string compressed_stream_path;
+  std::string compressed_stream_path; // a .vpccgof decoded-GOF container, or a V3C sample stream (.bin)
   std::vector<int> devices{0};        // GPUs to shard frames over (extension; the reference is single-threaded)
   bool keep_intermediate_files = false;
+  // V3C input only: the three video sub-bitstreams decoded by an EXTERNAL HEVC decoder to raw planar
+  // 4:2:0 files in the decoder's native format, all GOFs concatenated — occupancy 8-bit, geometry and
+  // attribute 16-bit little endian (10-bit content), i.e. exactly the bytes the reference copies out of
+  // libav's AVFrame (src/decoder.rs:1131-1141).  The attribute path is empty for attribute-less streams.
+  std::string occupancy_yuv_path, geometry_yuv_path, attribute_yuv_path;
+  uint32_t occupancy_precision = 4;   // frame_width / occupancy video width (the reference derives it from
+                                      // the decoded video, src/decoder.rs:194; a raw file carries no size)
   explicit Params(std::string path = {}) : compressed_stream_path(std::move(path)) {}
 };
 
@@ -137,7 +145,14 @@ class BoundedChannel {
 // One decoded GOF: frame descriptors pointing into the container buffer.
 struct DecodedGof {
   std::vector<vpcc_frame_desc> frames;
+  std::vector<std::vector<vpcc_patch>> patch_store;   // V3C input: patch tables built by the syntax parser
 };
+
+// Builds the GOFs of a V3C sample stream `bin` whose decoded videos lie back to back in `yuv` at the given
+// offsets (see Params).  Returns false + message on error; *status receives the vpcc_status of a syntax error.
+bool parse_v3c_with_raw_video(const std::vector<unsigned char>& bin, const unsigned char* occ, size_t occ_bytes,
+                              const unsigned char* geo, size_t geo_bytes, const unsigned char* attr, size_t attr_bytes,
+                              uint32_t occupancy_precision, std::vector<DecodedGof>* gofs, std::string* err, int* status);
 
 // Parses a .vpccgof container held in `buf` (kept alive by the caller).  Returns false + message on error.
 bool parse_container(const std::vector<unsigned char>& buf, std::vector<DecodedGof>* gofs, std::string* err);
@@ -168,6 +183,7 @@ class Decoder {
   Params params_;
   BoundedChannel<PointSet3> chan_{1};
   std::vector<unsigned char> file_;
+  std::vector<unsigned char> bin_;          // V3C input: the sample stream (file_ then holds the raw videos)
   std::vector<DecodedGof> gofs_;
   std::thread thread_;
   bool started_ = false;

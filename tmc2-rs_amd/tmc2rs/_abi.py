@@ -155,6 +155,18 @@ def host_frame_desc(frame):
 _lib = None
 
 
+class V3cGofInfo(C.Structure):
+    """vpcc_v3c_gof_info (include/vpcc_recon.h)."""
+    _fields_ = [(n, C.c_uint32) for n in (
+        "frame_count", "frame_width", "frame_height", "atlas_frame_width", "atlas_frame_height", "map_count",
+        "absolute_d1", "occupancy_resolution", "geometry_3d_bitdepth", "atlas_geometry_3d_bitdepth",
+        "geometry_2d_bitdepth", "occupancy_2d_bitdepth", "attribute_2d_bitdepth", "attribute_count",
+        "occupancy_codec_id", "geometry_codec_id", "attribute_codec_id", "profile_codec_group_idc",
+        "profile_toolset_idc", "profile_reconstruction_idc", "level_idc", "use_eight_orientations_flag",
+        "remove_duplicate_point_enabled_flag", "geometry_smoothing_sei", "smoothing_grid_size",
+        "smoothing_threshold", "reserved")] + [("video_bytes", C.c_size_t * 3)]
+
+
 def load_library():
     """Loads libvpcc_recon.so (built in-tree by `make` / __graft_entry__.build()).
     Raises — never falls back — when it is missing."""
@@ -195,6 +207,8 @@ def load_library():
     lib.vpcc_gof_algorithmic_bytes.argtypes = [vp, u32, C.POINTER(u64)]
     lib.vpcc_gof_smooth.argtypes = [vp, u32, u32, C.POINTER(SmoothingParams), vp]
     lib.vpcc_decoder_open.argtypes = [C.c_char_p, C.POINTER(C.c_int), C.c_int, C.POINTER(vp)]
+    lib.vpcc_decoder_open_v3c.argtypes = [C.c_char_p, C.c_char_p, C.c_char_p, C.c_char_p, u32, C.POINTER(C.c_int), C.c_int,
+                                          C.POINTER(vp)]
     lib.vpcc_decoder_start.argtypes = [vp]
     lib.vpcc_decoder_recv_frame.argtypes = [vp, C.POINTER(sz), C.POINTER(vp), C.POINTER(vp)]
     lib.vpcc_decoder_error.argtypes = [vp]
@@ -205,5 +219,15 @@ def load_library():
     lib.vpcc_decoder_close.argtypes = [vp]
     lib.vpcc_decoder_close.restype = None
     lib.vpcc_write_ply.argtypes = [C.c_char_p, vp, vp, sz]
+    lib.vpcc_v3c_open.argtypes = [C.c_char_p, sz, C.POINTER(vp)]
+    lib.vpcc_v3c_close.argtypes = [vp]
+    lib.vpcc_v3c_close.restype = None
+    lib.vpcc_v3c_error.argtypes = [vp]
+    lib.vpcc_v3c_error.restype = C.c_char_p
+    lib.vpcc_v3c_unit_count.argtypes = [vp]
+    lib.vpcc_v3c_unit_count.restype = u32
+    lib.vpcc_v3c_next_gof.argtypes = [vp, C.POINTER(C.c_int), C.POINTER(V3cGofInfo)]
+    lib.vpcc_v3c_frame_patches.argtypes = [vp, u32, C.POINTER(Patch), u32, C.POINTER(u32), C.POINTER(u32)]
+    lib.vpcc_v3c_video.argtypes = [vp, C.c_int, C.POINTER(C.POINTER(C.c_uint8)), C.POINTER(sz)]
     _lib = lib
     return lib

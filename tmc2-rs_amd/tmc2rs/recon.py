@@ -195,11 +195,18 @@ class Decoder:
     """Binding of the C++ tmc2rs::Decoder (mirror of the reference's Decoder::new / start / recv_frame /
     Iterator, src/lib.rs:70-154).  Iterating yields dicts {n, xyz, rgb} in presentation order."""
 
-    def __init__(self, path, devices=(0,)):
+    def __init__(self, path, devices=(0,), occupancy_yuv=None, geometry_yuv=None, attribute_yuv=None,
+                 occupancy_precision=4):
+        """`path`: a .vpccgof container, or — with the raw decoded videos given — a V3C sample stream (.bin)."""
         self.lib = _abi.load_library()
         self.h = C.c_void_p()
         dev = (C.c_int * len(devices))(*devices)
-        st = self.lib.vpcc_decoder_open(str(path).encode(), dev, len(devices), C.byref(self.h))
+        if occupancy_yuv is None:
+            st = self.lib.vpcc_decoder_open(str(path).encode(), dev, len(devices), C.byref(self.h))
+        else:
+            st = self.lib.vpcc_decoder_open_v3c(str(path).encode(), str(occupancy_yuv).encode(), str(geometry_yuv).encode(),
+                                                str(attribute_yuv).encode() if attribute_yuv else None,
+                                                occupancy_precision, dev, len(devices), C.byref(self.h))
         if st:
             raise VpccError(st, "vpcc_decoder_open")
 
@@ -261,3 +268,60 @@ def write_ply(path, xyz, rgb=None):
     st = lib.vpcc_write_ply(str(path).encode(), x.ctypes.data, c.ctypes.data if c is not None else None, len(x))
     if st:
         raise VpccError(st, "vpcc_write_ply")
+
+
+class V3cStream:
+    """Binding of the V3C syntax parser (vpcc_v3c_*): iterate GOFs, read patch frames and video sub-bitstreams.
+    Pure host code — no GPU needed."""
+
+    def __init__(self, data):
+        self.lib = _abi.load_library()
+        self.h = C.c_void_p()
+        self._data = bytes(data)
+        st = self.lib.vpcc_v3c_open(self._data, len(self._data), C.byref(self.h))
+        if st:
+            raise VpccError(st, "vpcc_v3c_open")
+
+    def unit_count(self):
+        return self.lib.vpcc_v3c_unit_count(self.h)
+
+    def next_gof(self):
+        """Returns the vpcc_v3c_gof_info fields as a dict, or None at the end of the stream."""
+        have, info = C.c_int(0), _abi.V3cGofInfo()
+        st = self.lib.vpcc_v3c_next_gof(self.h, C.byref(have), C.byref(info))
+        if st:
+            raise VpccError(st, "vpcc_v3c_next_gof", self.lib.vpcc_v3c_error(self.h).decode())
+        if not have.value:
+            return None
+        d = {n: getattr(info, n) for n, _ in _abi.V3cGofInfo._fields_ if n not in ("reserved", "video_bytes")}
+        d["video_bytes"] = list(info.video_bytes)
+        return d
+
+    def frame_patches(self, frame):
+        n, fi = C.c_uint32(0), C.c_uint32(0)
+        st = self.lib.vpcc_v3c_frame_patches(self.h, frame, None, 0, C.byref(n), C.byref(fi))
+        if st:
+            raise VpccError(st, "vpcc_v3c_frame_patches")
+        arr = (_abi.Patch * max(n.value, 1))()
+        st = self.lib.vpcc_v3c_frame_patches(self.h, frame, arr, n.value, C.byref(n), C.byref(fi))
+        if st:
+            raise VpccError(st, "vpcc_v3c_frame_patches")
+        return fi.value, [arr[i] for i in range(n.value)]
+
+    def video(self, kind):
+        p, n = C.POINTER(C.c_uint8)(), C.c_size_t(0)
+        st = self.lib.vpcc_v3c_video(self.h, kind, C.byref(p), C.byref(n))
+        if st:
+            raise VpccError(st, "vpcc_v3c_video")
+        return bytes(p[:n.value]) if n.value else b""
+
+    def close(self):
+        if self.h:
+            self.lib.vpcc_v3c_close(self.h)
+            self.h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
