@@ -630,7 +630,7 @@ void k_recon_tiles(const DevFrame* __restrict__ frames, uint32_t first,
             if (two) {
               store_xyz2(gx, (base + k) * 6u, p[0], p[1]);
               if (f.has_attr) store_rgb2(gc, (base + k) * 3u, rgb[0], rgb[1]);
-              if (gp) { gp[base + k] = (uint16_t)it.patch; gp[base + k + 1u] = (uint16_t)it.patch; }   // partition, codec.rs:452
+              if (gp) out_store<u32_a2>((VPCC_GLOBAL unsigned char*)gp + (base + k) * 2u, it.patch | (it.patch << 16));   // partition, codec.rs:452
             } else {
               store_xyz(gx, (base + k) * 6u, p[0]);
               if (f.has_attr) store_rgb(gc, (base + k) * 3u, rgb[0]);
