@@ -140,6 +140,22 @@ def overlapping_3d_frame(index=0, base=None):
     return f
 
 
+def wide_samples_frame():
+    """Samples that use all 16 bits: depths up to 16383 after the /4, attribute samples above 10 bits (the
+    colour conversion then runs the reference formula itself), coordinates that wrap `as u16`."""
+    f = medium_frame(7)
+    rng = np.random.default_rng(99)
+    f["geometry"] = [rng.integers(0, 65536, g.shape, dtype=np.uint16) for g in f["geometry"]]
+    f["attribute"] = [tuple(rng.integers(0, 65536, pl.shape, dtype=np.uint16) for pl in layer) for layer in f["attribute"]]
+    return f
+
+
+def precision_frame(prec, seed):
+    """Block size 16 (tile kernel) with occupancy precision 1, 2, 8 or 16."""
+    return synth.make_frame(160, 128, prec, 16, seed=seed, max_side=4, cover_target=0.7, size_skew=1.5,
+                            occupancy_values="random")
+
+
 PARITY_CASES = {
     "small0": lambda: synth.small_frame(0),
     "small1_randocc": lambda: synth.small_frame(1, occupancy_values="random"),
@@ -156,6 +172,11 @@ PARITY_CASES = {
     "gray_exact_boundaries": gray_boundary_frame,
     "medium0": lambda: medium_frame(0),
     "medium1_randocc": lambda: medium_frame(1, occupancy_values="random"),
+    "wide_samples": wide_samples_frame,
+    "precision1_block16": lambda: precision_frame(1, 201),
+    "precision2_block16": lambda: precision_frame(2, 202),
+    "precision8_block16": lambda: precision_frame(8, 203),
+    "precision16_block16": lambda: precision_frame(16, 204),
     "empty_no_patches": lambda: _tiny_frame([], np.ones((8, 8), np.uint8)),
     "empty_no_occupancy": lambda: _tiny_frame([_patch(0, 0, 2, 2)], np.zeros((8, 8), np.uint8)),
 }

@@ -161,3 +161,31 @@ def test_device_resident_planes(ctx):
     torch.cuda.synchronize()
     _check(g.download(0), ref)
     g.close()
+
+
+TILE_KERNEL_CASES = ["small0", "medium1_randocc", "relative_d1", "overlap", "single_map_extension", "no_attribute",
+                     "gray_exact_boundaries", "wide_samples", "precision1_block16", "precision2_block16",
+                     "precision8_block16", "precision16_block16", "truncation_degenerate_axes"]
+GENERAL_SEQUENCE_CASES = ["exotic_orientations", "block8_ragged", "block32_multichunk"]
+
+
+@pytest.mark.parametrize("name", TILE_KERNEL_CASES + GENERAL_SEQUENCE_CASES)
+def test_which_kernel_path_ran(ctx, name):
+    """The parity cases above must exercise the kernel they are meant for: the single-pass tile kernel for
+    block size 16 with Default/Swap patches, the general sequence for everything else — and both must match
+    the oracle when the general sequence is forced."""
+    f = cases.PARITY_CASES[name]()
+    st, ref = ob.reconstruct(f)
+    g = ctx.gof([f], flags=_abi.VPCC_GOF_PROFILE | _abi.VPCC_GOF_WANT_PATCH_INDEX)
+    g.reconstruct()
+    names = [k for k, _ in g.kernel_times()]
+    if name in TILE_KERNEL_CASES:
+        assert names == ["k_recon_tiles"], names
+    else:
+        assert "k_emit" in names and "k_recon_tiles" not in names, names
+    _check(g.download(0, want_patch_index=True), ref, colour=f.get("attribute_count", 1) > 0)
+    g.close()
+    g = ctx.gof([f], flags=_abi.VPCC_GOF_FORCE_GENERAL | _abi.VPCC_GOF_WANT_PATCH_INDEX)
+    g.reconstruct()
+    _check(g.download(0, want_patch_index=True), ref, colour=f.get("attribute_count", 1) > 0)
+    g.close()
