@@ -460,7 +460,7 @@ void k_recon_tiles(const DevFrame* __restrict__ frames, uint32_t first,
   // The frames of one label are interleaved, so the workgroups of ONE frame start a few slots apart.
   const uint32_t xcd = blockIdx.x & 7u, slot = blockIdx.x >> 3;
   const uint32_t frame_groups = (count + 7u) / 8u;
-  const uint32_t fi = xcd + 8u * (slot % frame_groups);
+  const uint32_t fi = xcd + 8u * (slot % frame_groups);   // (spreading a frame over all XCDs instead: 0.147 -> 0.164 ms)
   if (fi >= count) return;
   const DevFrame& f = frames[first + fi];
 
