@@ -546,15 +546,17 @@ void k_recon_tiles(const DevFrame* __restrict__ frames, uint32_t first,
     VPCC_STAMP(3)
 
     if (have_cur) {
+      // The look-back words were read before the count phase, whose loads have all been consumed: taking
+      // delivery of them here waits for nothing.  (After the first item's loads it would wait for those:
+      // in-order vmcnt.)
+      uint32_t excl = (variant & 1u) ? g_cur * 7000u : 0u;   // ablation: no wait, outputs still spread over the frame
+      if (g_cur != 0 && !(variant & 1u)) excl = look_back_groups(f, g_cur, gen, early);
       const uint32_t first_item = g_cur * kTileItemsPerGroup + wave * K;
       Item it = load_item(f.tiles + (first_item < f.n_tiles ? first_item : 0u));
       Samples cur;
       cur.occ = occ_cur & 0xFu;
       load_geometry<true>(f, it, lane, cur);
       load_attributes(f, it, lane, cur);
-
-      uint32_t excl = (variant & 1u) ? g_cur * 7000u : 0u;   // ablation: no wait, outputs still spread over the frame
-      if (g_cur != 0 && !(variant & 1u)) excl = look_back_groups(f, g_cur, gen, early);
       if (wave == 0 && lane == 0) {
         if (g_cur != 0 && !(variant & 1u))
           st_store(f.scan_state + g_cur, ((uint64_t)gen << kGenShift) | kPrefix | (uint64_t)(excl + total_cur));

@@ -17,7 +17,7 @@ for _ in range(3):
     g.reconstruct()
 g.sync()
 lib.vpcc_debug_read_stamps(buf, 1)
-names = ["ticket+barrier", "count(occ+geo x4)", "barrier#1", "publish/look-back", "barrier#2", "4 items", "drain", "-", "-", "-"]
+names = ["ticket+barrier", "count(occ+geo x4)", "barrier#1", "publish next", "look-back+1st loads", "4 items", "drain", "-", "-", "-"]
 n = buf[15] or 1
 tot = sum(buf[i] for i in range(10))
 for i, nm in enumerate(names):
