@@ -5,6 +5,7 @@ There is no Python implementation of the reconstruction: a missing library or a
 missing GPU raises.
 """
 import ctypes as C
+import weakref
 
 import numpy as np
 
@@ -38,9 +39,12 @@ class Context:
         if st:
             raise VpccError(st, "vpcc_ctx_create")
         self.device = device
+        self._gofs = weakref.WeakSet()          # a vpcc_gof must not outlive its context
 
     def close(self):
         if self.h:
+            for g in list(self._gofs):
+                g.close()
             self.lib.vpcc_ctx_destroy(self.h)
             self.h = C.c_void_p()
 
@@ -118,6 +122,7 @@ class Gof:
         st = self.lib.vpcc_gof_create(ctx.h, arr, self.n_frames, memory, int(capacity), int(flags), C.byref(self.h))
         ctx._check(st, "vpcc_gof_create")
         self.flags = flags
+        ctx._gofs.add(self)
 
     def close(self):
         if self.h:
