@@ -78,11 +78,20 @@ def main():
     import torch
     from tmc2rs import _abi, recon, synth
 
+    # VPCC_BENCH_BACKEND=gloo is a REHEARSAL switch for boxes with fewer GPUs than ranks (ranks then share
+    # devices and the two scalar reductions run on the CPU); measurements use the default, RCCL.
+    backend = os.environ.get("VPCC_BENCH_BACKEND", "nccl")
+    if backend != "nccl":
+        local_rank %= max(torch.cuda.device_count(), 1)
+    red_dev = "cuda" if backend == "nccl" else "cpu"
     torch.cuda.set_device(local_rank)
     dist = None
     if world > 1:
         import torch.distributed as dist
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))   # nccl == RCCL on ROCm
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))   # nccl == RCCL on ROCm
+        else:
+            dist.init_process_group(backend)
 
     # ---- synthetic GOF of this rank (distinct frames: the working set, ~0.8 GB, is >> the 256 MB
     # Infinity Cache, so planes stream from HBM) -------------------------------------------------
@@ -134,10 +143,10 @@ def main():
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
     if dist is not None:
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        t = torch.tensor([elapsed], dtype=torch.float64, device=red_dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
-        p = torch.tensor([points_per_step], dtype=torch.int64, device="cuda")
+        p = torch.tensor([points_per_step], dtype=torch.int64, device=red_dev)
         dist.all_reduce(p, op=dist.ReduceOp.SUM)
         total_points_per_step = int(p.item())
     else:
