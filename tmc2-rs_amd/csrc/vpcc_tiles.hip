@@ -448,8 +448,11 @@ __device__ __forceinline__ void store_rgb(VPCC_GLOBAL unsigned char* base, uint3
 // its total was published, when the totals of the earlier tickets have long arrived: the wait that
 // cost a quarter of the kernel in the count -> look back -> emit form is gone, and the plane loads
 // of the next group overlap the stores of the current one across the waves of a CU.
+// Register budget: 4 waves per SIMD.  Measured (tools/waves.sh): 3..5 waves per SIMD are within 3 % of each
+// other, 4 is marginally best (fewer workgroups in flight keep more of the twice-read geometry in the L2),
+// 6 and more spill.
 #ifndef VPCC_TILES_WAVES_PER_EU
-#define VPCC_TILES_WAVES_PER_EU 5
+#define VPCC_TILES_WAVES_PER_EU 4
 #endif
 template <bool kStamps>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(VPCC_TILES_WAVES_PER_EU, VPCC_TILES_WAVES_PER_EU)))
