@@ -4,6 +4,7 @@
 
 #include <hip/hip_runtime.h>
 
+#include "vpcc_colour.h"
 #include "vpcc_device.hpp"
 
 namespace vpcc {
@@ -103,30 +104,15 @@ __device__ __forceinline__ vpcc_color3 yuv10_to_rgb8(uint16_t y16, uint16_t u16,
   return c;
 }
 
-// Same result as yuv10_to_rgb8, bit for bit, without the three f64 divisions on the common path.
-// The reference computes p = fl(fl(c / 1023) * 255) and floors it.  With T = c*255/1023 the two
-// roundings keep |p - T| <= 2.3e-16*|T|; t = fl(c * fl(255/1023)) likewise has |t - T| <= 2.3e-16*|T|,
-// so |t - p| < 5e-16*|T| < 2.5e-11 for every u16 input (|T| < 4.7e4).  Whenever t is farther than
-// 1e-9 from an integer, floor(t) == floor(p); otherwise (e.g. grey pixels whose luma is a multiple of
-// 341, where T is an exact integer) the lane takes the exact path.  c itself (r, g, b) is computed
-// with the reference's operations in the reference's order.
+// Same result as yuv10_to_rgb8, bit for bit, without a division on the common path: vpcc_colour.h
+// (f64 FMAs on a 2^-20 grid; checked on the whole 10-bit cube by tests/colour_exhaustive.c).  A fraction
+// pattern that could hide an exact integer, or a sample above 10 bits, takes the reference formula.
 __device__ __forceinline__ vpcc_color3 yuv10_to_rgb8_fast(uint16_t y16, uint16_t u16, uint16_t v16) {
-  const double offset = 512.;
-  const double K = 255. / 1023.;
-  const double y = (double)y16, u = (double)u16, v = (double)v16;
-  const double r = y + 1.57480 * (v - offset);
-  const double g = y - 0.18733 * (u - offset) - (0.46813 * (v - offset));
-  const double b = y + 1.85563 * (u - offset);
-  const double tr = r * K, tg = g * K, tb = b * K;
-  const double fr = __builtin_floor(tr), fg = __builtin_floor(tg), fb = __builtin_floor(tb);
-  const double eps = 1e-9;
-  const double dr = tr - fr, dg = tg - fg, db = tb - fb;
-  const bool near = (dr < eps) | (dr > 1. - eps) | (dg < eps) | (dg > 1. - eps) | (db < eps) | (db > 1. - eps);
+  uint32_t fmin = ((uint32_t)(y16 | u16 | v16) > 1023u) ? 0u : 0xFFFFFFFFu;
+  const uint32_t rgb = vpcc_colour_luma(y16, vpcc_colour_chroma(u16, v16), &fmin);
+  if (fmin == 0u) return yuv10_to_rgb8(y16, u16, v16);   // rare
   vpcc_color3 c;
-  c.r = clamp_u8(fr);
-  c.g = clamp_u8(fg);
-  c.b = clamp_u8(fb);
-  if (near) c = yuv10_to_rgb8(y16, u16, v16);   // rare: exact IEEE division path
+  c.r = (uint8_t)rgb; c.g = (uint8_t)(rgb >> 8); c.b = (uint8_t)(rgb >> 16);
   return c;
 }
 
