@@ -498,8 +498,12 @@ void k_recon_tiles(const DevFrame* __restrict__ frames, uint32_t first,
     __syncthreads();
     const uint32_t g_next = __builtin_amdgcn_readfirstlane(s_group);
     const bool have_next = g_next < n_groups;
-    uint64_t early = 0;                                    // speculative read of the current group's look-back words
-    if (have_cur && lane < g_cur) early = st_load(f.scan_state + (g_cur - 1u - lane));
+    // Speculative read of the current group's look-back words.  It is issued BEHIND the count phase's plane
+    // loads: vmcnt retires in order, and this coherent load is the slowest of them.
+    uint64_t early = 0;
+    auto read_early = [&]() {
+      if (have_cur && lane < g_cur) early = st_load(f.scan_state + (g_cur - 1u - lane));
+    };
     VPCC_STAMP(0)
 
     // ---- 2. count it: occupancy + geometry of the wave's 4 items, all loads of a kind issued together.
@@ -522,6 +526,7 @@ void k_recon_tiles(const DevFrame* __restrict__ frames, uint32_t first,
           s4[i].occ = item0 + i < f.n_tiles ? occupancy_bits(f, raw[i]) : 0u;   // past the end: an empty copy of item 0
           load_geometry<false>(f, it4[i], lane, s4[i]);
         }
+        if (c0 == 0) read_early();
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
           const uint32_t dup = classify(f, it4[i], s4[i]) & s4[i].occ;
@@ -532,6 +537,7 @@ void k_recon_tiles(const DevFrame* __restrict__ frames, uint32_t first,
         }
       }
     }
+    if (!have_next) read_early();
     VPCC_STAMP(1)
     __syncthreads();
     VPCC_STAMP(2)
