@@ -1,5 +1,6 @@
 #!/bin/bash
-# Timing-only ablations of the fused kernel (see vpcc_fused.hip): prints kernel ms per variant.
+# Timing-only ablations of the tile kernel (VPCC_TILES_VARIANT bits, see vpcc_tiles.hip: 1 no look-back wait,
+# 8 no colour, 16 no lane<->point loop, 32 no stores): prints ms per step and kernel ms per variant.
 for v in "$@"; do
   VPCC_TILES_VARIANT=$v python bench.py --steps 100 --warmup 10 --ramp-ms 50 --no-cpu-baseline --profile-steps 3 2>/dev/null \
     | python -c "import sys,json; d=json.loads(sys.stdin.read()); print('variant $v', d['ms_per_step'], d['roofline']['all_kernels_ms'])"
