@@ -502,7 +502,11 @@ void k_recon_tiles(const DevFrame* __restrict__ frames, uint32_t first,
     // loads: vmcnt retires in order, and this coherent load is the slowest of them.
     uint64_t early = 0;
     auto read_early = [&]() {
-      if (have_cur && lane < g_cur) early = st_load(f.scan_state + (g_cur - 1u - lane));
+      // A wavefront-scope (i.e. plain, cacheable) load — may be served by this XCD's L2, even a stale L1 line: a look-back word only moves
+      // EMPTY -> AGGREGATE -> PREFIX within a launch and carries the launch generation, so any older state
+      // is safe to act on — a stale EMPTY just sends the lane to the coherent re-read in look_back_groups.
+      if (have_cur && lane < g_cur)
+        early = __hip_atomic_load(gl(f.scan_state + (g_cur - 1u - lane)), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
     };
     VPCC_STAMP(0)
 
