@@ -285,6 +285,9 @@ const char* vpcc_decoder_error(vpcc_decoder* dec);
  * frames, points and wall seconds since the call: the end-to-end, PCIe-inclusive rate of the ingest ->
  * reconstruct -> D2H pipeline. */
 int  vpcc_decoder_drain(vpcc_decoder* dec, uint64_t* frames, uint64_t* points, double* seconds);
+/* Seconds from the start of the last vpcc_decoder_drain to its first frame (contexts, page-locking the input,
+ * first GOF): the start-up latency a long stream amortises. */
+double vpcc_decoder_first_frame_seconds(const vpcc_decoder* d);
 void vpcc_decoder_close(vpcc_decoder* dec);
 
 /* writer::PlyWriter::write, ASCII (src/writer.rs:25-74); rgb may be NULL (no colour properties). */

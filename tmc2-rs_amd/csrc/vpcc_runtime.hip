@@ -22,6 +22,8 @@ struct vpcc_ctx {
   int device = 0;
   hipStream_t stream = nullptr;        // kernels and D2H
   hipStream_t copy_stream = nullptr;   // H2D plane ingest: overlaps the kernels of the previous GOF
+  hipStream_t d2h_stream = nullptr;    // result downloads: wait for ONE gof's kernels only (results_ready), not for
+                                       // whatever else has been queued behind them on the compute stream
   std::string last_error;
   // Arenas of destroyed GOFs are kept for the next GOF of the same shape: hipMalloc/hipFree cost
   // milliseconds and hipFree synchronises the whole device, which would stall a GOF pipeline.
@@ -59,6 +61,7 @@ struct vpcc_gof {
   bool counts_valid = false;
   bool launched = false;
   hipEvent_t upload_done = nullptr;
+  hipEvent_t results_ready = nullptr;   // recorded behind the last kernel launched on this gof
   hipStream_t last_stream = nullptr;
   std::vector<KernelTiming> timings;
   uint32_t n_timed = 0;
@@ -124,7 +127,8 @@ extern "C" int vpcc_ctx_create(int device_id, vpcc_ctx** out) {
   vpcc_ctx* ctx = new vpcc_ctx();
   ctx->device = device_id;
   if (hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) != hipSuccess ||
-      hipStreamCreateWithFlags(&ctx->copy_stream, hipStreamNonBlocking) != hipSuccess) {
+      hipStreamCreateWithFlags(&ctx->copy_stream, hipStreamNonBlocking) != hipSuccess ||
+      hipStreamCreateWithFlags(&ctx->d2h_stream, hipStreamNonBlocking) != hipSuccess) {
     delete ctx;
     return VPCC_ERR_DEVICE;
   }
@@ -138,6 +142,7 @@ extern "C" void vpcc_ctx_destroy(vpcc_ctx* ctx) {
   for (auto& a : ctx->arena_cache) (void)hipFree(a.first);
   if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
   if (ctx->copy_stream) (void)hipStreamDestroy(ctx->copy_stream);
+  if (ctx->d2h_stream) (void)hipStreamDestroy(ctx->d2h_stream);
   delete ctx;
 }
 
@@ -184,11 +189,13 @@ extern "C" void vpcc_gof_destroy(vpcc_gof* gof) {
   if (gof->last_stream) (void)hipStreamSynchronize(gof->last_stream);
   (void)hipStreamSynchronize(gof->ctx->stream);
   (void)hipStreamSynchronize(gof->ctx->copy_stream);
+  (void)hipStreamSynchronize(gof->ctx->d2h_stream);
   for (auto& t : gof->timings) {
     (void)hipEventDestroy(t.start);
     (void)hipEventDestroy(t.stop);
   }
   if (gof->upload_done) (void)hipEventDestroy(gof->upload_done);
+  if (gof->results_ready) (void)hipEventDestroy(gof->results_ready);
   if (gof->smooth_grid) (void)hipFree(gof->smooth_grid);
   if (gof->arena) {                                   // all work on it is complete (streams synchronised above)
     auto& cache = gof->ctx->arena_cache;
@@ -318,6 +325,7 @@ int gof_create_impl(vpcc_ctx* ctx, const vpcc_frame_desc* frames, uint32_t n_fra
   g->d_scan = (uint64_t*)(base + off_scan);
   HIP_TRY(ctx, hipHostMalloc((void**)&g->h_counts, sizeof(uint32_t) * 2 * n_frames, hipHostMallocDefault));
   HIP_TRY(ctx, hipEventCreateWithFlags(&g->upload_done, hipEventDisableTiming));
+  HIP_TRY(ctx, hipEventCreateWithFlags(&g->results_ready, hipEventDisableTiming));
 
   // 3. fill descriptors and upload (plane ingest on the copy stream)
   hipStream_t s = ctx->copy_stream;
@@ -493,6 +501,7 @@ extern "C" int vpcc_gof_reconstruct(vpcc_gof* g, uint32_t first, uint32_t count,
     launch_tiles(g->d_frames, first, count, max_groups, g->generation, s);
     T.end();
     HIP_TRY(ctx, hipGetLastError());
+    HIP_TRY(ctx, hipEventRecord(g->results_ready, s));
     g->launched = true;
     return VPCC_OK;
   }
@@ -519,6 +528,7 @@ extern "C" int vpcc_gof_reconstruct(vpcc_gof* g, uint32_t first, uint32_t count,
   launch_emit(g->d_frames, first, count, max_vb, s);
   T.end();
   HIP_TRY(ctx, hipGetLastError());
+  HIP_TRY(ctx, hipEventRecord(g->results_ready, s));
   g->launched = true;
   return VPCC_OK;
 }
@@ -526,7 +536,7 @@ extern "C" int vpcc_gof_reconstruct(vpcc_gof* g, uint32_t first, uint32_t count,
 extern "C" int vpcc_gof_sync(vpcc_gof* g) {
   if (!g) return VPCC_ERR_INVALID_ARG;
   HIP_TRY(g->ctx, hipSetDevice(g->ctx->device));
-  if (g->last_stream) HIP_TRY(g->ctx, hipStreamSynchronize(g->last_stream));
+  if (g->launched) HIP_TRY(g->ctx, hipEventSynchronize(g->results_ready));
   return VPCC_OK;
 }
 
@@ -534,7 +544,8 @@ namespace {
 int fetch_counts(vpcc_gof* g) {
   if (!g->launched) return fail(g->ctx, VPCC_ERR_STATE, "no reconstruct issued");
   if (g->counts_valid) return VPCC_OK;
-  hipStream_t s = g->last_stream;
+  hipStream_t s = g->ctx->d2h_stream;
+  HIP_TRY(g->ctx, hipStreamWaitEvent(s, g->results_ready, 0));
   HIP_TRY(g->ctx, hipMemcpyAsync(g->h_counts, g->d_counts, sizeof(uint32_t) * g->n_frames, hipMemcpyDeviceToHost, s));
   HIP_TRY(g->ctx, hipMemcpyAsync(g->h_counts + g->n_frames, g->d_errors, sizeof(uint32_t) * g->n_frames,
                                  hipMemcpyDeviceToHost, s));
@@ -586,7 +597,8 @@ extern "C" int vpcc_gof_download(vpcc_gof* g, uint32_t frame, vpcc_point3* xyz_o
   *n_points = n;
   if (n > g->capacity || n > capacity) return fail(ctx, VPCC_ERR_CAPACITY, "frame produced more points than capacity");
   const DevFrame& D = g->h_frames[frame];
-  hipStream_t s = g->last_stream;
+  hipStream_t s = ctx->d2h_stream;
+  HIP_TRY(ctx, hipStreamWaitEvent(s, g->results_ready, 0));   // the latest kernels on this gof (incl. smoothing)
   if (n) {
     if (xyz_out) HIP_TRY(ctx, hipMemcpyAsync(xyz_out, D.out_xyz, n * sizeof(vpcc_point3), hipMemcpyDeviceToHost, s));
     if (rgb_out && D.out_rgb)
@@ -676,6 +688,7 @@ extern "C" int vpcc_gof_smooth(vpcc_gof* g, uint32_t first, uint32_t count, cons
       HIP_TRY(ctx, hipGetLastError());
     }
   }
+  HIP_TRY(ctx, hipEventRecord(g->results_ready, s));
   return VPCC_OK;
 }
 

@@ -210,6 +210,8 @@ def load_library():
     lib.vpcc_decoder_open_v3c.argtypes = [C.c_char_p, C.c_char_p, C.c_char_p, C.c_char_p, u32, C.POINTER(C.c_int), C.c_int,
                                           C.POINTER(vp)]
     lib.vpcc_decoder_start.argtypes = [vp]
+    lib.vpcc_decoder_first_frame_seconds.argtypes = [vp]
+    lib.vpcc_decoder_first_frame_seconds.restype = C.c_double
     lib.vpcc_decoder_recv_frame.argtypes = [vp, C.POINTER(sz), C.POINTER(vp), C.POINTER(vp)]
     lib.vpcc_decoder_error.argtypes = [vp]
     lib.vpcc_decoder_error.restype = C.c_char_p

@@ -244,6 +244,9 @@ class Decoder:
             raise VpccError(st, "vpcc_decoder_drain", self.error())
         return nf.value, npts.value, sec.value
 
+    def first_frame_seconds(self):
+        return self.lib.vpcc_decoder_first_frame_seconds(self.h)
+
     def __iter__(self):
         return self
 

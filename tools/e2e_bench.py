@@ -20,7 +20,11 @@ try:
         dec.start()                      # reads the container on the caller's thread (like the reference)
         t_read = time.perf_counter() - t0
         nf, npts, sec = dec.drain()
+        t_first = dec.first_frame_seconds()
         dec.close()
+        per_gof = (sec - t_first) / max(n_gofs - 1, 1)
+        print(f"rep {rep}: start-up (contexts, page-locking {size/1e9:.1f} GB, first GOF) {t_first*1e3:.0f} ms; then "
+              f"{per_gof*1e3:.2f} ms per 32-frame GOF = {32/per_gof:.0f} frames/s steady state")
         print(f"rep {rep}: {nf} frames, {npts/1e6:.1f} Mpoints in {sec:.3f} s -> {nf/sec:.0f} frames/s, {npts/sec/1e6:.0f} Mpoints/s "
               f"end-to-end ({size/1e9:.2f} GB container, file read {t_read:.2f} s not included); "
               f"H2D {size/sec/1e9:.1f} GB/s + D2H {npts*9/sec/1e9:.1f} GB/s")
