@@ -29,7 +29,10 @@ uint32_t Bitstream::peek(unsigned bits) {
 
 uint32_t Bitstream::read_uvlc() {
   unsigned leading_zeros = 0;
-  while (read(1) == 0) ++leading_zeros;
+  while (read(1) == 0) {
+    // the reference's `1 << leading_zeros` / read(> 32 bits) panic on such a code (src/bitstream.rs:166-175)
+    if (++leading_zeros >= 32) throw std::out_of_range("Exp-Golomb code longer than 32 bits");
+  }
   if (leading_zeros == 0) return 0;
   return (1u << leading_zeros) - 1u + read(leading_zeros);
 }
@@ -47,7 +50,7 @@ void Bitstream::byte_align() {
 void Bitstream::copy_from(Bitstream& src, size_t start_byte, size_t size) {
   if (start_byte + size > src.data_.size()) throw std::out_of_range("Bitstream::copy_from source range");
   if (data_.size() < bytes_ + size) data_.resize(bytes_ + size, 0);
-  std::memcpy(data_.data() + bytes_, src.data_.data() + start_byte, size);
+  if (size) std::memcpy(data_.data() + bytes_, src.data_.data() + start_byte, size);
   bytes_ += size;
   src.bytes_ += size;
 }
