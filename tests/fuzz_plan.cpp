@@ -1,0 +1,70 @@
+// Robustness harness for the host-side frame validation and planning (vpcc_host.cpp), CPU only, built with
+// -fsanitize=address,undefined by tests/test_plan_fuzz.py: random and adversarial patch tables must either be
+// rejected by validate_frame or planned into work lists that stay inside the canvas.
+#include <cstdint>
+#include <cstdio>
+#include <cstdlib>
+#include <vector>
+
+#include "vpcc_host.hpp"
+
+static uint64_t st = 0x243F6A8885A308D3ull;
+static uint64_t rnd() { st ^= st << 13; st ^= st >> 7; st ^= st << 17; return st; }
+static uint32_t below(uint32_t n) { return n ? (uint32_t)(rnd() % n) : 0; }
+
+int main(int argc, char** argv) {
+  const long iterations = argc > 1 ? std::atol(argv[1]) : 1000;
+  static uint8_t dummy8[16];
+  static uint16_t dummy16[16];
+  long accepted = 0, rejected = 0, items = 0;
+  for (long it = 0; it < iterations; ++it) {
+    vpcc_frame_desc f{};
+    const uint32_t R = 1u << (3 + below(3)), prec = 1u << below(3);
+    f.occupancy_resolution = R;
+    f.occupancy_precision = prec;
+    f.width = R * (1 + below(40));
+    f.height = R * (1 + below(40));
+    if (below(50) == 0) f.width += below(R);                       // ragged canvas
+    f.map_count = 1 + below(2);
+    f.absolute_d1 = below(2);
+    f.attribute_count = below(2);
+    f.occupancy = vpcc_image_u8{dummy8, f.width / prec, f.height / prec, f.width / prec};
+    for (uint32_t m = 0; m < f.map_count; ++m) {
+      f.geometry[m] = vpcc_image_u16{dummy16, nullptr, nullptr, f.width, f.height, f.width, f.width / 2};
+      f.attribute[m] = vpcc_image_u16{dummy16, dummy16, dummy16, f.width, f.height, f.width, f.width / 2};
+    }
+    std::vector<vpcc_patch> patches(below(40));
+    const uint32_t bw = f.width / R, bh = f.height / R;
+    const bool wild = below(4) == 0;
+    for (vpcc_patch& p : patches) {
+      p = vpcc_patch{};
+      p.orientation = (uint8_t)below(wild ? 12 : 2);
+      p.size_u0 = 1 + below(wild ? 70000 : 6);
+      p.size_v0 = 1 + below(wild ? 70000 : 6);
+      p.u0 = below(wild ? 0xFFFFFFFFu : bw + 1);
+      p.v0 = below(wild ? 0xFFFFFFFFu : bh + 1);
+      p.u1 = (uint32_t)rnd(); p.v1 = (uint32_t)rnd(); p.d1 = (uint32_t)rnd();
+      p.lod_x = wild ? (uint32_t)rnd() : 1; p.lod_y = wild ? below(3) : 1;
+      p.normal_axis = (uint8_t)below(wild ? 5 : 3); p.tangent_axis = (uint8_t)below(3); p.bitangent_axis = (uint8_t)below(3);
+      p.projection_mode = (uint8_t)below(wild ? 3 : 2);
+      p.axis_of_additional_plane = wild ? (uint8_t)below(2) : 0;
+    }
+    f.patches = patches.empty() ? nullptr : patches.data();
+    f.patch_count = (uint32_t)patches.size();
+    if (vpcc::validate_frame(&f) != VPCC_OK) { ++rejected; continue; }
+    ++accepted;
+    vpcc::FramePlan plan;
+    vpcc::plan_frame(f, &plan);
+    uint64_t expect_vb = 0;
+    for (const vpcc_patch& p : patches) expect_vb += (uint64_t)p.size_u0 * p.size_v0;
+    if (plan.vblocks.size() != expect_vb) { std::fprintf(stderr, "vblock count\n"); return 1; }
+    for (const vpcc::VBlock& b : plan.vblocks)
+      if (b.canvas_block >= (uint64_t)plan.bw * plan.bh) { std::fprintf(stderr, "canvas block out of range\n"); return 1; }
+    for (const vpcc::TileItem& t : plan.tiles) {
+      if ((uint32_t)t.x0 + 16 > f.width || (uint32_t)t.y0 + 16 > f.height) { std::fprintf(stderr, "tile outside the canvas\n"); return 1; }
+      ++items;
+    }
+  }
+  std::printf("iterations %ld accepted %ld rejected %ld tile items %ld\n", iterations, accepted, rejected, items);
+  return accepted > 0 && rejected > 0 ? 0 : 1;
+}
