@@ -292,6 +292,9 @@ void vpcc_decoder_close(vpcc_decoder* dec);
 
 /* writer::PlyWriter::write, ASCII (src/writer.rs:25-74); rgb may be NULL (no colour properties). */
 int  vpcc_write_ply(const char* path, const vpcc_point3* xyz, const vpcc_color3* rgb, size_t n_points);
+/* Same with `binary` != 0: "format binary_little_endian 1.0" (the variant the reference's writer has commented
+ * out, src/writer.rs:10-11, 39-44) with the same property list — 3 x uint32 (+ 3 x uchar) per vertex. */
+int  vpcc_write_ply_format(const char* path, const vpcc_point3* xyz, const vpcc_color3* rgb, size_t n, int binary);
 
 /* -------------------------------------------- syntax side (host only) */
 /* V3C bit reader (src/bitstream.rs:53-190): read/peek MSB-first, Exp-Golomb, byte_align, copy_from. */

@@ -29,6 +29,25 @@ def test_ply_writer_matches_reference_format(tmp_path):
                              "element face 0\nproperty list uint8 int32 vertex_index\nend_header\n1 2 3\n65535 0 7\n")
 
 
+def test_ply_writer_binary_little_endian(tmp_path):
+    # the variant the reference's writer keeps commented out (src/writer.rs:10-11, 39-44): same properties
+    rng = np.random.default_rng(5)
+    xyz = rng.integers(0, 65536, (1000, 3), dtype=np.uint16)
+    rgb = rng.integers(0, 256, (1000, 3), dtype=np.uint8)
+    p = tmp_path / "b.ply"
+    recon.write_ply(p, xyz, rgb, binary=True)
+    raw = p.read_bytes()
+    head, body = raw.split(b"end_header\n", 1)
+    assert head == (b"ply\nformat binary_little_endian 1.0\nelement vertex 1000\nproperty uint x\nproperty uint y\n"
+                    b"property uint z\nproperty uchar red\nproperty uchar green\nproperty uchar blue\nelement face 0\n"
+                    b"property list uint8 int32 vertex_index\n")
+    rec = np.frombuffer(body, dtype=np.dtype([("p", "<u4", 3), ("c", "u1", 3)]))
+    assert len(rec) == 1000 and np.array_equal(rec["p"], xyz) and np.array_equal(rec["c"], rgb)
+    recon.write_ply(p, xyz, None, binary=True)
+    body = p.read_bytes().split(b"end_header\n", 1)[1]
+    assert np.array_equal(np.frombuffer(body, dtype="<u4").reshape(-1, 3), xyz)
+
+
 def test_decoder_api_contract_without_gpu(tmp_path):
     path = tmp_path / "a.vpccgof"
     container.write_container(path, [[cases.medium_frame(0)]])

@@ -381,17 +381,29 @@ void Decoder::worker() {
 }
 
 // ------------------------------------------------------------------ PlyWriter (src/writer.rs:25-74)
-std::string PlyWriter::to_string(const vpcc_point3* xyz, const vpcc_color3* rgb, size_t n) {
+std::string PlyWriter::to_string(const vpcc_point3* xyz, const vpcc_color3* rgb, size_t n, Format format) {
   std::string s;
-  s.reserve(64 + n * 24);
+  const bool binary = format == Format::BinaryLittleEndian;
+  s.reserve(256 + n * (binary ? 15 : 24));
   s += "ply\n";
-  s += "format ascii 1.0\n";
+  s += binary ? "format binary_little_endian 1.0\n" : "format ascii 1.0\n";
   s += "element vertex " + std::to_string(n) + "\n";
   s += "property uint x\nproperty uint y\nproperty uint z\n";
   if (rgb) s += "property uchar red\nproperty uchar green\nproperty uchar blue\n";
   s += "element face 0\n";
   s += "property list uint8 int32 vertex_index\n";
   s += "end_header\n";
+  if (binary) {                                   // same properties as the ASCII form: 3 x uint32 (+ 3 x uchar) per vertex
+    const size_t stride = rgb ? 15 : 12, at = s.size();
+    s.resize(at + n * stride);
+    char* o = &s[at];
+    for (size_t i = 0; i < n; ++i, o += stride) {
+      const uint32_t v[3] = {xyz[i].x, xyz[i].y, xyz[i].z};     // little-endian host (x86-64)
+      std::memcpy(o, v, 12);
+      if (rgb) { o[12] = (char)rgb[i].r; o[13] = (char)rgb[i].g; o[14] = (char)rgb[i].b; }
+    }
+    return s;
+  }
   char line[64];
   for (size_t i = 0; i < n; ++i) {
     const vpcc_point3& p = xyz[i];
@@ -407,7 +419,7 @@ std::string PlyWriter::to_string(const vpcc_point3* xyz, const vpcc_color3* rgb,
 }
 
 std::string PlyWriter::to_string() const {
-  return to_string(pc_.positions.data(), pc_.with_colors ? pc_.colors.data() : nullptr, pc_.len());
+  return to_string(pc_.positions.data(), pc_.with_colors ? pc_.colors.data() : nullptr, pc_.len(), format_);
 }
 
 bool PlyWriter::write(const std::string& path) const {
@@ -501,11 +513,15 @@ extern "C" double vpcc_decoder_first_frame_seconds(const vpcc_decoder* d) { retu
 
 extern "C" void vpcc_decoder_close(vpcc_decoder* d) { delete d; }
 
-extern "C" int vpcc_write_ply(const char* path, const vpcc_point3* xyz, const vpcc_color3* rgb, size_t n) {
+extern "C" int vpcc_write_ply_format(const char* path, const vpcc_point3* xyz, const vpcc_color3* rgb, size_t n, int binary) {
   if (!path || (n && !xyz)) return VPCC_ERR_INVALID_ARG;
   std::ofstream out(path, std::ios::binary);
   if (!out) return VPCC_ERR_INVALID_ARG;
-  const std::string s = tmc2rs::PlyWriter::to_string(xyz, rgb, n);
+  const std::string s = tmc2rs::PlyWriter::to_string(xyz, rgb, n, binary ? tmc2rs::Format::BinaryLittleEndian : tmc2rs::Format::Ascii);
   out.write(s.data(), (std::streamsize)s.size());
   return out ? VPCC_OK : VPCC_ERR_INVALID_ARG;
+}
+
+extern "C" int vpcc_write_ply(const char* path, const vpcc_point3* xyz, const vpcc_color3* rgb, size_t n) {
+  return vpcc_write_ply_format(path, xyz, rgb, n, 0);
 }

@@ -190,13 +190,13 @@ class Decoder {
   std::string error_;
 };
 
-enum class Format { Ascii };                  // src/writer.rs:8-12
+enum class Format { Ascii, BinaryLittleEndian };   // src/writer.rs:8-12 (the binary variant is commented out there)
 
 class PlyWriter {                             // src/writer.rs:14-74
  public:
   PlyWriter(const PointSet3& pc, Format format) : pc_(pc), format_(format) {}
   // plain arrays (C ABI entry point)
-  static std::string to_string(const vpcc_point3* xyz, const vpcc_color3* rgb, size_t n);
+  static std::string to_string(const vpcc_point3* xyz, const vpcc_color3* rgb, size_t n, Format format = Format::Ascii);
   bool write(const std::string& path) const;
   std::string to_string() const;
 

@@ -221,6 +221,7 @@ def load_library():
     lib.vpcc_decoder_close.argtypes = [vp]
     lib.vpcc_decoder_close.restype = None
     lib.vpcc_write_ply.argtypes = [C.c_char_p, vp, vp, sz]
+    lib.vpcc_write_ply_format.argtypes = [C.c_char_p, vp, vp, sz, C.c_int]
     lib.vpcc_v3c_open.argtypes = [C.c_char_p, sz, C.POINTER(vp)]
     lib.vpcc_v3c_close.argtypes = [vp]
     lib.vpcc_v3c_close.restype = None

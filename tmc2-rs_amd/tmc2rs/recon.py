@@ -268,12 +268,13 @@ class Decoder:
             pass
 
 
-def write_ply(path, xyz, rgb=None):
-    """writer::PlyWriter (ASCII), through the C++ mirror."""
+def write_ply(path, xyz, rgb=None, binary=False):
+    """writer::PlyWriter (ASCII, or binary little endian), through the C++ mirror."""
     lib = _abi.load_library()
     x = np.ascontiguousarray(xyz, dtype=np.uint16)
     c = np.ascontiguousarray(rgb, dtype=np.uint8) if rgb is not None else None
-    st = lib.vpcc_write_ply(str(path).encode(), x.ctypes.data, c.ctypes.data if c is not None else None, len(x))
+    st = lib.vpcc_write_ply_format(str(path).encode(), x.ctypes.data, c.ctypes.data if c is not None else None, len(x),
+                                   1 if binary else 0)
     if st:
         raise VpccError(st, "vpcc_write_ply")
 
