@@ -73,3 +73,27 @@ def test_decoder_v3c_short_video_and_unsupported_stream(tmp_path):
         d.start()
     assert "geometry video shorter" in str(e.value)
     d.close()
+
+
+def test_long_multi_sequence_stream_in_order(tmp_path):
+    """BASELINE configs 2/3 in miniature: sequences that cycle a set of distinct frames, several sequences back to
+    back, GOF after GOF through the sharded decoder — every frame must arrive, in presentation order, with the
+    oracle's content (checksum per frame and a checksum of the checksums)."""
+    import zlib
+    distinct = [cases.medium_frame(60 + i, occupancy_values="random" if i % 2 else "one") for i in range(8)]
+    ref = []
+    for f in distinct:
+        st, r = ob.reconstruct(f)
+        assert st == 0
+        ref.append(zlib.crc32(ob.rgb_array(r).tobytes(), zlib.crc32(ob.xyz_array(r).tobytes())))
+    order = [(s * 3 + i) % 8 for s in range(3) for i in range(60)]          # three 60-frame sequences, different phases
+    gofs = [[distinct[k] for k in order[g:g + 12]] for g in range(0, len(order), 12)]
+    path = tmp_path / "long.vpccgof"
+    container.write_container(path, gofs)
+    d = recon.Decoder(path, devices=(0, 0))
+    d.start()
+    got = [zlib.crc32(fr["rgb"].tobytes(), zlib.crc32(fr["xyz"].tobytes())) for fr in d]
+    assert d.error() == ""
+    assert got == [ref[k] for k in order]
+    assert zlib.crc32(np.array(got, np.uint32).tobytes()) == zlib.crc32(np.array([ref[k] for k in order], np.uint32).tobytes())
+    d.close()
