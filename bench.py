@@ -59,7 +59,7 @@ def parse():
     ap.add_argument("--smooth", action="store_true",
                     help="BASELINE config 4: grid geometry + colour smoothing after reconstruction (own spec, see DESIGN.md)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--profile-steps", type=int, default=5)
+    ap.add_argument("--profile-steps", type=int, default=30)
     return ap.parse_args()
 
 
@@ -158,7 +158,8 @@ def main():
     kernels = {}
     if rank == 0:
         pg = ctx.gof(frames, capacity=cap, flags=flags | _abi.VPCC_GOF_PROFILE)
-        pg.reconstruct()
+        for _ in range(3):                      # warm the profile GOF's own buffers
+            pg.reconstruct()
         pg.sync()
         acc = {}
         for _ in range(max(args.profile_steps, 1)):
