@@ -129,14 +129,23 @@ __global__ __launch_bounds__(256) void k_emit(const DevFrame* __restrict__ frame
       const Pt& pt = j == 0 ? o.p0 : o.p1;
       vpcc_point3 q;
       q.x = pt.c[0]; q.y = pt.c[1]; q.z = pt.c[2];
-      gstore(f.out_xyz + k, q);
+      {   // non-temporal: the output stream must not evict the geometry k_count just pulled into the L2
+        VPCC_GLOBAL uint16_t* o = (VPCC_GLOBAL uint16_t*)(f.out_xyz + k);
+        __builtin_nontemporal_store(q.x, o);
+        __builtin_nontemporal_store(q.y, o + 1);
+        __builtin_nontemporal_store(q.z, o + 2);
+      }
       if (f.out_patch) glw(f.out_patch)[k] = b.patch;                           // partition, codec.rs:452
       if (f.has_attr) {                                                         // color_point_cloud, codec.rs:626-644
         const uint32_t cidx = (o.y >> 1) * f.attr_cstride[j] + (o.x >> 1);     // chroma nearest neighbour
         const uint16_t Y = gl(f.attr_y[j])[o.y * f.attr_stride[j] + o.x];
         const uint16_t U = gl(f.attr_u[j])[cidx];
         const uint16_t V = gl(f.attr_v[j])[cidx];
-        gstore(f.out_rgb + k, yuv10_to_rgb8_fast(Y, U, V));
+        const vpcc_color3 c = yuv10_to_rgb8_fast(Y, U, V);
+        VPCC_GLOBAL uint8_t* oc = (VPCC_GLOBAL uint8_t*)(f.out_rgb + k);
+        __builtin_nontemporal_store(c.r, oc);
+        __builtin_nontemporal_store(c.g, oc + 1);
+        __builtin_nontemporal_store(c.b, oc + 2);
       }
     }
     base += tot;
