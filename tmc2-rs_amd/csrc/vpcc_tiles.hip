@@ -210,7 +210,8 @@ __device__ __forceinline__ uint32_t load_occupancy_raw(const DevFrame& f, const 
 }
 // bit j: pixel j of the lane is occupied; pixel j reads byte j >> prec_shift (byte 0 for precision >= 4)
 __device__ __forceinline__ uint32_t occupancy_bits(const DevFrame& f, uint32_t raw) {
-  const uint32_t sh = f.prec_shift < 2u ? f.prec_shift : 2u;
+  if (f.prec_shift >= 2u) return (raw & 0xFFu) ? 0xFu : 0u;     // the usual case (precision 4): one byte, four pixels
+  const uint32_t sh = f.prec_shift;
   uint32_t bits = 0;
 #pragma unroll
   for (uint32_t j = 0; j < 4; ++j) bits |= (((raw >> (8u * (j >> sh))) & 0xFFu) ? 1u : 0u) << j;
@@ -343,8 +344,11 @@ template <int J>
 __device__ __forceinline__ void put_records(const Samples& s, uint32_t dup, uint32_t pixel, uint32_t rank,
                                             uint32_t dump, const uint32_t rgb0[4], const uint32_t rgb1[4], uint2* slots) {
   const bool occ = (s.occ >> J) & 1u, second = occ && !((dup >> J) & 1u);
-  slots[occ ? rank : dump] = make_uint2((px<J>(s.g0) >> 2) | (pixel << 16), rgb0[J]);
-  slots[second ? rank + 1u : dump] = make_uint2((px<J>(s.g1) >> 2) | (pixel << 16) | (1u << 24), rgb1[J]);
+  // depth = sample / 4 (src/codec.rs:534, 548): bits 2..15 of the pixel's half of the dword
+  const uint32_t d0 = __builtin_amdgcn_ubfe(J < 2 ? s.g0.lo : s.g0.hi, 2u + 16u * (J & 1), 14u);
+  const uint32_t d1 = __builtin_amdgcn_ubfe(J < 2 ? s.g1.lo : s.g1.hi, 2u + 16u * (J & 1), 14u);
+  slots[occ ? rank : dump] = make_uint2(d0 | (pixel << 16), rgb0[J]);
+  slots[second ? rank + 1u : dump] = make_uint2(d1 | (pixel << 16) | (1u << 24), rgb1[J]);
 }
 
 // Ranks of the lane's 4 pixels inside the item, emission order (src/codec.rs:382-385: v1 outer, u1 inner).
