@@ -136,12 +136,20 @@ def main():
     for _ in range(args.warmup):
         step(gof)
     barrier()
+    # HIP events on the stream the kernels are launched on, bracketing exactly the timed region
+    # (torch.cuda.Event on torch's current stream would not see this stream)
+    ext = torch.cuda.ExternalStream(ctx.stream(), device=torch.device("cuda", local_rank))
+    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     t0 = time.perf_counter()
+    ev0.record(ext)
     for _ in range(args.steps):
         step(gof)
+    ev1.record(ext)
     gof.sync()
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
+    ev1.synchronize()
+    region_ms_per_step = ev0.elapsed_time(ev1) / args.steps
     if dist is not None:
         t = torch.tensor([elapsed], dtype=torch.float64, device=red_dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -175,6 +183,7 @@ def main():
                     "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBPS, 4),
                     "traffic": measured_traffic(dom, args.workload, args.frames),
                     "algorithmic_bytes_per_launch": alg_bytes, "kernel_ms": round(dom_ms, 4),
+                    "timed_region_ms_per_step": round(region_ms_per_step, 4),
                     "all_kernels_ms": {k: round(v, 4) for k, v in kernels.items()},
                     "pipeline_achieved": round(alg_bytes / (sum(kernels.values()) * 1e-3) / 1e9, 1)}
 

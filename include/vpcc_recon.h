@@ -142,6 +142,9 @@ const char* vpcc_status_string(int status);
 int  vpcc_ctx_create(int device_id, vpcc_ctx** out);
 void vpcc_ctx_destroy(vpcc_ctx* ctx);
 const char* vpcc_last_error(const vpcc_ctx* ctx);
+/* The context's compute stream (a hipStream_t): the stream kernels are launched on when a call is given a null
+ * stream.  For callers that order their own work behind the reconstruction or time it with HIP events. */
+void* vpcc_ctx_stream(const vpcc_ctx* ctx);
 
 /* Plane ingest (stand-in for LibavcodecDecoder::decode, src/decoder.rs:1089-1156, whose Vec<u8> planes
  * are the H2D source): page-locks a host range so that uploads from it are true asynchronous DMA. */

@@ -148,6 +148,8 @@ extern "C" void vpcc_ctx_destroy(vpcc_ctx* ctx) {
 
 extern "C" const char* vpcc_last_error(const vpcc_ctx* ctx) { return ctx ? ctx->last_error.c_str() : ""; }
 
+extern "C" void* vpcc_ctx_stream(const vpcc_ctx* ctx) { return ctx ? (void*)ctx->stream : nullptr; }
+
 extern "C" int vpcc_host_pin(vpcc_ctx* ctx, const void* ptr, size_t bytes) {
   if (!ctx || !ptr || !bytes) return VPCC_ERR_INVALID_ARG;
   HIP_TRY(ctx, hipSetDevice(ctx->device));

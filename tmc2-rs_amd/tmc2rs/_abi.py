@@ -185,6 +185,8 @@ def load_library():
     lib.vpcc_status_string.argtypes = [C.c_int]
     lib.vpcc_ctx_create.argtypes = [C.c_int, C.POINTER(vp)]
     lib.vpcc_ctx_destroy.argtypes = [vp]
+    lib.vpcc_ctx_stream.argtypes = [vp]
+    lib.vpcc_ctx_stream.restype = vp
     lib.vpcc_ctx_destroy.restype = None
     lib.vpcc_last_error.argtypes = [vp]
     lib.vpcc_last_error.restype = C.c_char_p

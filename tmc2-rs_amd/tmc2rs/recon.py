@@ -54,6 +54,10 @@ class Context:
         except Exception:
             pass
 
+    def stream(self):
+        """The compute stream's hipStream_t as an integer (e.g. for torch.cuda.ExternalStream)."""
+        return self.lib.vpcc_ctx_stream(self.h)
+
     def _check(self, st, where):
         if st:
             raise VpccError(st, where, self.lib.vpcc_last_error(self.h).decode())
