@@ -11,17 +11,32 @@ no data-path collective); `value` is the whole-job Mpoints/s.
   python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
          --master-port P bench.py --gpus N --steps K --warmup W
 
+The timed region is tmc2rs.sharding.timed_region (the function the world-size-2 gloo test runs): W warm-up
+steps, then K steps between barrier + synchronisation pairs; K is raised to `steps_effective` until the
+region lasts >= --min-seconds (a step is ~0.1 ms).  Every launch of the region carries a HIP-event pair
+on the launch stream (profile mode of the library), so `roofline.kernel_ms` is the mean duration of
+exactly the launches `ms_per_step` was measured on (the last <= 512 of them).
+
 One JSON line is printed by rank 0, with the contract fields plus
-  roofline     : HBM roofline of the dominant kernel (algorithmic bytes of SURVEY §8d per launch /
-                 its mean launch duration, measured with HIP events on the launch stream)
-  cpu_baseline : the CPU oracle (a port of the reference's algorithm; the Rust crate cannot be
-                 built here) timed single-threaded on this box, rank 0 at N=1 only.
+  roofline        : HBM roofline of the dominant kernel.  `achieved`/`frac` use the ALGORITHMIC bytes of
+                    SURVEY §8d (whole planes once + 9 B/point).  Next to it: `necessary_bytes` (only the
+                    16x16 blocks a patch owns and that hold occupancy, + occupancy plane + 9 B/point),
+                    `line_floor_bytes` (distinct 128-B lines of the raster planes holding needed samples:
+                    the floor of any kernel reading this layout), `traffic` (memory-side bytes per launch
+                    from the committed rocprofv3 PMC passes) with `frac_traffic`, `frac_necessary`.
+  verified_frames : frames of the TIMED gof downloaded after the region and compared (xyz, rgb, count)
+                    with the CPU oracle — the run fails if they differ.
+  end_to_end      : host-buffer (PCIe-inclusive) rate through the C++ Decoder (pinned container -> H2D ->
+                    kernels -> D2H -> consumer); never `value`.  N=1 only.
+  cpu_baseline    : the CPU oracle (a port of the reference's algorithm; the Rust crate cannot be built
+                    here) timed single-threaded on this box, rank 0 at N=1 only.
 """
 import argparse
 import json
 import os
 import sys
 import time
+import zlib
 
 REPO = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, os.path.join(REPO, "tmc2-rs_amd"))
@@ -30,11 +45,11 @@ HBM_PEAK_GBPS = 8000.0   # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6300 G
 
 
 def measured_traffic(kernel, workload, frames):
-    """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes
-    (profiles/rNN/traffic.json: FETCH_SIZE x2 + WRITE_SIZE, calibrated there), or None."""
+    """Memory-side bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes
+    (latest profiles/rNN/traffic*.json whose kernel / workload / frame count match), or None."""
     import glob
     best = None
-    for path in sorted(glob.glob(os.path.join(REPO, "profiles", "r*", "traffic.json"))):
+    for path in sorted(glob.glob(os.path.join(REPO, "profiles", "r*", "traffic*.json"))):
         try:
             d = json.load(open(path))
         except Exception:
@@ -42,7 +57,7 @@ def measured_traffic(kernel, workload, frames):
         if kernel.split("<")[0] in d.get("kernel", "") and workload in d.get("workload", "") \
                 and f"{frames} frames" in d.get("workload", ""):
             best = d
-    return best["hbm_bytes_per_launch"] if best else None
+    return best
 
 
 def parse():
@@ -50,8 +65,10 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--min-seconds", type=float, default=0.5,
+                    help="the timed region runs max(--steps, enough steps to last this long)")
     ap.add_argument("--ramp-ms", type=float, default=150.0,
-                    help="untimed launches before the warmup steps until this much wall time has passed: a step is ~0.15 ms, "
+                    help="untimed launches before the warmup steps until this much wall time has passed: a step is ~0.1 ms, "
                          "far shorter than the GPU's clock ramp from idle")
     ap.add_argument("--frames", type=int, default=32, help="frames per GOF (per rank)")
     ap.add_argument("--workload", default="longdress", choices=["longdress", "owlii"])
@@ -59,8 +76,31 @@ def parse():
     ap.add_argument("--smooth", action="store_true",
                     help="BASELINE config 4: grid geometry + colour smoothing after reconstruction (own spec, see DESIGN.md)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--profile-steps", type=int, default=30)
+    ap.add_argument("--no-verify", action="store_true", help="skip the oracle check of the timed GOF's output (tools/ only)")
+    ap.add_argument("--no-end-to-end", action="store_true", help="skip the PCIe-inclusive Decoder run")
+    ap.add_argument("--e2e-gofs", type=int, default=4, help="GOFs in the end-to-end container")
+    ap.add_argument("--profile-steps", type=int, default=0, help=argparse.SUPPRESS)   # accepted for old tool scripts
     return ap.parse_args()
+
+
+def smoothing_algorithmic_bytes(gof, n_frames, bitdepth, grid, cgrid):
+    """Algorithmic bytes of one smoothing pass pair over the GOF: per point read
+    xyz 6 + rgb 3 + patch index 2 B and write 9 B; per occupied grid cell 24 B written and read once,
+    for the geometry grid and for the colour grid."""
+    import numpy as np
+    total = 0
+    for i in range(n_frames):
+        r = gof.download(i)
+        n = r["n"]
+        total += n * (6 + 3 + 2 + 9)
+        for g in (grid, cgrid):
+            if not g:
+                continue
+            w = ((1 << bitdepth) + g - 1) // g
+            c = r["xyz"].astype(np.int64) // g
+            cells = np.unique((c[:, 0] * w + c[:, 1]) * w + c[:, 2]).size
+            total += cells * 24 * 2
+    return total
 
 
 def main():
@@ -76,10 +116,10 @@ def main():
 
     import numpy as np
     import torch
-    from tmc2rs import _abi, recon, synth
+    from tmc2rs import _abi, recon, sharding, synth, traffic
 
     # VPCC_BENCH_BACKEND=gloo is a REHEARSAL switch for boxes with fewer GPUs than ranks (ranks then share
-    # devices and the two scalar reductions run on the CPU); measurements use the default, RCCL.
+    # devices and the scalar reductions run on the CPU); measurements use the default, RCCL.
     backend = os.environ.get("VPCC_BENCH_BACKEND", "nccl")
     if backend != "nccl":
         local_rank %= max(torch.cuda.device_count(), 1)
@@ -103,7 +143,7 @@ def main():
     cap = 1_000_000 if args.workload == "longdress" else 2_400_000
 
     ctx = recon.Context(local_rank)
-    flags = _abi.VPCC_GOF_FORCE_GENERAL if args.general else 0
+    flags = (_abi.VPCC_GOF_FORCE_GENERAL if args.general else 0) | _abi.VPCC_GOF_PROFILE
     if args.smooth:
         flags |= _abi.VPCC_GOF_WANT_PATCH_INDEX
     bitdepth = 10 if args.workload == "longdress" else 11
@@ -111,81 +151,128 @@ def main():
                      color_threshold_difference=100)
     gof = ctx.gof(frames, capacity=cap, flags=flags)          # H2D happens here, outside the timed region
 
-    def step(g):
-        g.reconstruct()
+    def step():
+        gof.reconstruct()
         if args.smooth:
-            g.smooth(bitdepth, **smooth_kw)
+            gof.smooth(bitdepth, **smooth_kw)
 
     gof.reconstruct()
     counts = gof.point_counts().astype(np.int64)
     assert all(gof.frame_status(i) == 0 for i in range(args.frames)), "capacity too small"
     points_per_step = int(counts.sum())
     alg_bytes = sum(gof.algorithmic_bytes(i) for i in range(args.frames))
-
-    def barrier():
-        torch.cuda.synchronize()
-        if dist is not None:
-            dist.barrier()
-        gof.sync()
+    smooth_bytes = smoothing_algorithmic_bytes(gof, args.frames, bitdepth, smooth_kw["grid_size"],
+                                               smooth_kw["color_grid_size"]) if args.smooth and rank == 0 else 0
 
     t_ramp = time.perf_counter()
     while (time.perf_counter() - t_ramp) * 1e3 < args.ramp_ms:     # untimed: brings the clocks up from idle
         for _ in range(16):
-            step(gof)
+            step()
         gof.sync()
-    for _ in range(args.warmup):
-        step(gof)
-    barrier()
-    # HIP events on the stream the kernels are launched on, bracketing exactly the timed region
+
+    # HIP events on the stream the kernels are launched on, bracketing the timed region as a whole
     # (torch.cuda.Event on torch's current stream would not see this stream)
     ext = torch.cuda.ExternalStream(ctx.stream(), device=torch.device("cuda", local_rank))
-    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    t0 = time.perf_counter()
-    ev0.record(ext)
-    for _ in range(args.steps):
-        step(gof)
-    ev1.record(ext)
-    gof.sync()
-    torch.cuda.synchronize()
-    elapsed = time.perf_counter() - t0
-    ev1.synchronize()
-    region_ms_per_step = ev0.elapsed_time(ev1) / args.steps
-    if dist is not None:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=red_dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
-        p = torch.tensor([points_per_step], dtype=torch.int64, device=red_dev)
-        dist.all_reduce(p, op=dist.ReduceOp.SUM)
-        total_points_per_step = int(p.item())
-    else:
-        total_points_per_step = points_per_step
-    barrier()
+    ev = [torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)]
+    n_steps = [0]
 
-    # ---- roofline of the dominant kernel: HIP events on the launch stream (profile-mode GOF) ------
+    def timed_step():
+        if n_steps[0] == args.warmup:
+            ev[0].record(ext)                                       # first timed step
+        n_steps[0] += 1
+        step()
+
+    reg = sharding.timed_region(timed_step, gof.sync, args.steps, args.warmup, points_per_step, dist=dist,
+                                device=red_dev, min_seconds=args.min_seconds, device_sync=torch.cuda.synchronize)
+    ev[1].record(ext)
+    ev[1].synchronize()
+    steps_eff = reg["steps_effective"]
+    elapsed = reg["elapsed_s"]
+    region_ms_per_step = ev[0].elapsed_time(ev[1]) / steps_eff
+    kernels, launches_averaged = gof.kernel_time_means(min(steps_eff, 512))   # the same launches
+
+    # ---- the timed GOF's output against the CPU oracle (checker only) -----------------------------
+    verified, ok = [], 1
+    if not args.no_verify and not args.smooth:
+        sys.path.insert(0, os.path.join(REPO, "tests"))
+        import oracle_binding as ob            # checker/baseline only — never on the product path
+        after = gof.point_counts().astype(np.int64)
+        ok = int(np.array_equal(after, counts))
+        for i in sorted({0, args.frames // 2, args.frames - 1}):
+            st, ref = ob.reconstruct(frames[i])
+            res = gof.download(i)
+            good = st == 0 and res["n"] == ref["n"] and np.array_equal(res["xyz"], ob.xyz_array(ref)) and \
+                np.array_equal(res["rgb"], ob.rgb_array(ref))
+            ok &= int(good)
+            verified.append({"frame": rank * args.frames + i, "points": int(res["n"]),
+                             "xyz_crc32": zlib.crc32(res["xyz"].tobytes()), "rgb_crc32": zlib.crc32(res["rgb"].tobytes()),
+                             "equals_oracle": bool(good)})
+    if dist is not None:
+        v = torch.tensor([ok], dtype=torch.int64, device=red_dev)
+        dist.all_reduce(v, op=dist.ReduceOp.MIN)
+        ok = int(v.item())
+    if not ok:
+        print(f"bench.py: rank {rank}: output of the timed GOF differs from the CPU oracle: {verified}", file=sys.stderr)
+        sys.exit(3)
+
+    # ---- roofline of the dominant kernel ---------------------------------------------------------
     roofline = None
-    kernels = {}
     if rank == 0:
-        pg = ctx.gof(frames, capacity=cap, flags=flags | _abi.VPCC_GOF_PROFILE)
-        for _ in range(3):                      # warm the profile GOF's own buffers
-            pg.reconstruct()
-        pg.sync()
-        acc = {}
-        for _ in range(max(args.profile_steps, 1)):
-            pg.reconstruct()
-            for name, ms in pg.kernel_times():
-                acc.setdefault(name, []).append(ms)
-        pg.close()
-        kernels = {k: float(np.mean(v)) for k, v in acc.items()}
+        rd = traffic.gof_read_bytes(frames)
+        out_bytes = 9 * points_per_step
+        necessary = rd["block_bytes"] + rd["occupancy_plane"] + out_bytes
+        line_floor = rd["seg128"] + rd["occupancy_plane"] + out_bytes
         dom = max(kernels, key=kernels.get)
         dom_ms = kernels[dom]
-        achieved = alg_bytes / (dom_ms * 1e-3) / 1e9
+        dom_bytes = alg_bytes
+        if args.smooth and dom.startswith(("k_smooth", "smooth_")):
+            dom_bytes = smooth_bytes           # a smoothing kernel dominates: its own algorithmic bytes (whole pass pair)
+            dom_ms = sum(v for k, v in kernels.items() if k.startswith(("k_smooth", "smooth_")))
+        achieved = dom_bytes / (dom_ms * 1e-3) / 1e9
+        tr = measured_traffic(dom, args.workload, args.frames) if not args.smooth else None
         roofline = {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 1), "peak": HBM_PEAK_GBPS,
                     "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBPS, 4),
-                    "traffic": measured_traffic(dom, args.workload, args.frames),
-                    "algorithmic_bytes_per_launch": alg_bytes, "kernel_ms": round(dom_ms, 4),
+                    "traffic": tr["hbm_bytes_per_launch"] if tr else None,
+                    "algorithmic_bytes_per_launch": dom_bytes, "kernel_ms": round(dom_ms, 4),
+                    "kernel_ms_launches_averaged": launches_averaged,
+                    "necessary_bytes": necessary, "line_floor_bytes": line_floor,
+                    "frac_necessary": round(necessary / (kernels.get("k_recon_tiles", dom_ms) * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4),
+                    "frac_line_floor": round(line_floor / (kernels.get("k_recon_tiles", dom_ms) * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4),
+                    "frac_traffic": round(tr["hbm_bytes_per_launch"] / (dom_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4) if tr else None,
+                    "traffic_source": tr.get("source") if tr else None,
                     "timed_region_ms_per_step": round(region_ms_per_step, 4),
-                    "all_kernels_ms": {k: round(v, 4) for k, v in kernels.items()},
-                    "pipeline_achieved": round(alg_bytes / (sum(kernels.values()) * 1e-3) / 1e9, 1)}
+                    "all_kernels_ms": {k: round(v, 4) for k, v in kernels.items()}}
+        if args.smooth:
+            roofline["smoothing_algorithmic_bytes_per_launch"] = smooth_bytes
+            roofline["reconstruction_algorithmic_bytes_per_launch"] = alg_bytes
+
+    # ---- end to end: host buffers in, host buffers out (C++ Decoder) -----------------------------
+    e2e = None
+    if rank == 0 and world == 1 and not args.no_end_to_end and not args.smooth and not args.general:
+        import tempfile
+        from tmc2rs import container
+        d = tempfile.mkdtemp(dir="/dev/shm" if os.path.isdir("/dev/shm") else None)
+        path = os.path.join(d, "bench_e2e.vpccgof")
+        try:
+            container.write_container(path, [frames] * args.e2e_gofs)
+            size = os.path.getsize(path)
+            dec = recon.Decoder(path, devices=(local_rank,))
+            dec.start()
+            nf, npts, sec = dec.drain()
+            t_first = dec.first_frame_seconds()
+            dec.close()
+            steady = (sec - t_first) / max(args.e2e_gofs - 1, 1)
+            assert nf == args.frames * args.e2e_gofs and npts == points_per_step * args.e2e_gofs, "Decoder output differs"
+            e2e = {"frames_per_s": round(args.frames / steady, 1), "Mpoints_per_s": round(points_per_step / steady / 1e6, 1),
+                   "h2d_GBps": round(size / args.e2e_gofs / steady / 1e9, 2),
+                   "d2h_GBps": round(points_per_step * 9 / steady / 1e9, 2), "startup_s": round(t_first, 3),
+                   "whole_run_frames_per_s": round(nf / sec, 1),
+                   "sample": f"{args.e2e_gofs} GOFs x {args.frames} frames through tmc2rs::Decoder (pinned container -> "
+                             f"H2D -> kernels -> D2H -> consumer), steady state after the first GOF"}
+        finally:
+            if os.path.exists(path):
+                os.remove(path)
+            os.rmdir(d)
 
     # ---- CPU baseline: the oracle (port of the reference algorithm), single thread, rank 0, N=1 ---
     cpu = None
@@ -231,13 +318,13 @@ def main():
                             "sample": f"{n_cpu} frames dealt to {n_thr} threads, one pass"}
 
     if rank == 0:
-        ms_per_step = elapsed / args.steps * 1e3
+        ms_per_step = elapsed / steps_eff * 1e3
         out = {
             "metric": "V-PCC reconstruction throughput (points/s; frames/s alongside)",
-            "value": round(total_points_per_step * args.steps / elapsed / 1e6, 2),
+            "value": round(reg["points_total_per_step"] * steps_eff / elapsed / 1e6, 2),
             "unit": "Mpoints/s",
-            "frames_per_s": round(args.frames * world * args.steps / elapsed, 1),
-            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "frames_per_s": round(args.frames * world * steps_eff / elapsed, 1),
+            "n_gpus": world, "steps": args.steps, "steps_effective": steps_eff, "warmup": args.warmup,
             "ms_per_step": round(ms_per_step, 4),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "u16", "data": "synthetic",
@@ -249,6 +336,8 @@ def main():
                        "smoothing": smooth_kw if args.smooth else None,
                        "parallelism": f"frame-sharded x{world}, no collective on the data path"},
             "roofline": roofline,
+            "verified_frames": verified,
+            "end_to_end": e2e,
             "cpu_baseline": cpu,
         }
         print(json.dumps(out))

@@ -233,6 +233,14 @@ int vpcc_gof_frame_status(vpcc_gof* gof, uint32_t frame);
  * Returns the number of kernels (<= max). */
 int vpcc_gof_kernel_times(vpcc_gof* gof, const char** names_out, float* ms_out, int max);
 
+/* Profile mode keeps the event pairs of the last 512 launches (one per vpcc_gof_reconstruct; a following
+ * vpcc_gof_smooth adds its kernels to the same launch).  Mean duration per kernel name over the last
+ * `last_n` launches (0 = all kept); *launches_out = launches averaged.  Lets a caller time a long
+ * back-to-back region and read the per-launch kernel durations of exactly those launches.
+ * Returns the number of distinct kernels (<= max). */
+int vpcc_gof_kernel_time_means(vpcc_gof* gof, uint32_t last_n, const char** names_out, float* mean_ms_out,
+                               uint32_t* launches_out, int max);
+
 /* Algorithmic bytes of frame `frame` as SURVEY.md §8(d) defines them
  * (occupancy + geometry luma + attribute Y/U/V planes read once, 9 B/point
  * written once), using the measured point count of the last reconstruct. */

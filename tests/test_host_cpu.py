@@ -95,7 +95,12 @@ def _gloo_worker(rank, world, port, n_frames, q):
     local_counts = [1000 * f + 7 for f in mine]             # stand-in for the per-frame point counts of this rank
     counts = sharding.presentation_order_counts(dist, local_counts, n_frames)
     elapsed, points = sharding.job_totals(dist, 0.5 + rank, sum(local_counts))
-    q.put((rank, counts, elapsed, points))
+    # the timed region bench.py runs on every rank (same function, fake step): rank 1 is the slow one
+    import time
+    ran = []
+    reg = sharding.timed_region(step=lambda: (ran.append(1), time.sleep(0.002 * (1 + rank))), sync=lambda: None,
+                                steps=3, warmup=2, points_per_step=100 + rank, dist=dist, min_seconds=0.05)
+    q.put((rank, counts, elapsed, points, reg, len(ran)))
     dist.destroy_process_group()
 
 
@@ -112,7 +117,24 @@ def test_multi_rank_bookkeeping_over_gloo():
     for p in procs:
         p.join(60)
         assert p.exitcode == 0
-    for rank, counts, elapsed, points in res:
+    regs = {}
+    for rank, counts, elapsed, points, reg, ran in res:
         assert counts == [1000 * f + 7 for f in range(n_frames)]       # presentation order on every rank
         assert elapsed == 1.5                                           # MAX over ranks
         assert points == sum(1000 * f + 7 for f in range(n_frames))    # SUM over ranks
+        assert reg["world"] == 2 and reg["points_total_per_step"] == 201
+        assert ran == 2 + reg["steps_effective"]                        # warm-up + exactly K timed steps
+        regs[rank] = reg
+    # both ranks ran the same K (raised from 3 to cover min_seconds at the FAST rank's pace) and report the
+    # slow rank's time
+    assert regs[0]["steps_effective"] == regs[1]["steps_effective"] >= 10
+    assert regs[0]["elapsed_s"] == regs[1]["elapsed_s"] >= 0.004 * regs[0]["steps_effective"]
+
+
+def test_timed_region_single_rank():
+    import time
+    n = []
+    reg = sharding.timed_region(step=lambda: (n.append(1), time.sleep(0.001)), sync=lambda: None, steps=5, warmup=1,
+                                points_per_step=42)
+    assert reg["steps_effective"] == 5 and len(n) == 6 and reg["points_total_per_step"] == 42 and reg["world"] == 1
+    assert reg["elapsed_s"] >= 0.005

@@ -33,8 +33,15 @@ struct vpcc_ctx {
 struct KernelTiming {
   const char* name;
   hipEvent_t start, stop;
-  float ms;
 };
+// Profile mode keeps the event pairs of the last kProfileRing launches (one slot per vpcc_gof_reconstruct,
+// a following vpcc_gof_smooth appends to the same slot), so that a caller can time a long back-to-back
+// region and read the mean duration per kernel of exactly those launches afterwards.
+struct LaunchTimings {
+  std::vector<KernelTiming> k;   // event pairs are created once and reused when the ring wraps
+  uint32_t n = 0;                // kernels timed in this launch
+};
+constexpr uint32_t kProfileRing = 512;
 
 struct vpcc_gof {
   vpcc_ctx* ctx = nullptr;
@@ -63,8 +70,8 @@ struct vpcc_gof {
   hipEvent_t upload_done = nullptr;
   hipEvent_t results_ready = nullptr;   // recorded behind the last kernel launched on this gof
   hipStream_t last_stream = nullptr;
-  std::vector<KernelTiming> timings;
-  uint32_t n_timed = 0;
+  std::vector<LaunchTimings> history;   // profile mode: ring of kProfileRing launches
+  uint64_t launches_profiled = 0;       // slot of the current launch = (launches_profiled - 1) % kProfileRing
   uint32_t generation = 0;             // launch counter of the tile kernel (tags look-back words)
   void* smooth_grid = nullptr;         // dense cell grids of the smoothing filters (scratch, on demand)
   size_t smooth_bytes = 0;
@@ -192,10 +199,11 @@ extern "C" void vpcc_gof_destroy(vpcc_gof* gof) {
   (void)hipStreamSynchronize(gof->ctx->stream);
   (void)hipStreamSynchronize(gof->ctx->copy_stream);
   (void)hipStreamSynchronize(gof->ctx->d2h_stream);
-  for (auto& t : gof->timings) {
-    (void)hipEventDestroy(t.start);
-    (void)hipEventDestroy(t.stop);
-  }
+  for (auto& l : gof->history)
+    for (auto& t : l.k) {
+      (void)hipEventDestroy(t.start);
+      (void)hipEventDestroy(t.stop);
+    }
   if (gof->upload_done) (void)hipEventDestroy(gof->upload_done);
   if (gof->results_ready) (void)hipEventDestroy(gof->results_ready);
   if (gof->smooth_grid) (void)hipFree(gof->smooth_grid);
@@ -456,22 +464,32 @@ struct Timer {
   vpcc_gof* g;
   hipStream_t s;
   bool on;
+  LaunchTimings* slot = nullptr;
+  // new_launch: a vpcc_gof_reconstruct opens the next ring slot; vpcc_gof_smooth appends to the current one
+  Timer(vpcc_gof* g_, hipStream_t s_, bool new_launch) : g(g_), s(s_), on((g_->flags & VPCC_GOF_PROFILE) != 0) {
+    if (!on) return;
+    if (g->history.empty()) g->history.resize(kProfileRing);
+    if (new_launch || g->launches_profiled == 0) {
+      g->launches_profiled++;
+      g->history[(g->launches_profiled - 1) % kProfileRing].n = 0;
+    }
+    slot = &g->history[(g->launches_profiled - 1) % kProfileRing];
+  }
   void begin(const char* name) {
     if (!on) return;
-    if (g->n_timed == g->timings.size()) {
+    if (slot->n == slot->k.size()) {
       KernelTiming t{};
       (void)hipEventCreate(&t.start);
       (void)hipEventCreate(&t.stop);
-      g->timings.push_back(t);
+      slot->k.push_back(t);
     }
-    g->timings[g->n_timed].name = name;
-    g->timings[g->n_timed].ms = 0.f;
-    (void)hipEventRecord(g->timings[g->n_timed].start, s);
+    slot->k[slot->n].name = name;
+    (void)hipEventRecord(slot->k[slot->n].start, s);
   }
   void end() {
     if (!on) return;
-    (void)hipEventRecord(g->timings[g->n_timed].stop, s);
-    g->n_timed++;
+    (void)hipEventRecord(slot->k[slot->n].stop, s);
+    slot->n++;
   }
 };
 
@@ -487,8 +505,7 @@ extern "C" int vpcc_gof_reconstruct(vpcc_gof* g, uint32_t first, uint32_t count,
   HIP_TRY(ctx, hipStreamWaitEvent(s, g->upload_done, 0));        // the planes' H2D copies (copy stream) come first
   g->last_stream = s;
   g->counts_valid = false;
-  g->n_timed = 0;
-  Timer T{g, s, (g->flags & VPCC_GOF_PROFILE) != 0};
+  Timer T(g, s, true);
 
   if (!g->general) {
     // single-pass tile kernel: re-arm counts, tickets and look-back words, then ONE kernel
@@ -615,16 +632,46 @@ extern "C" int vpcc_gof_download(vpcc_gof* g, uint32_t frame, vpcc_point3* xyz_o
 }
 
 extern "C" int vpcc_gof_kernel_times(vpcc_gof* g, const char** names_out, float* ms_out, int max) {
-  if (!g) return 0;
+  if (!g || g->launches_profiled == 0) return 0;
   (void)hipSetDevice(g->ctx->device);
   if (g->last_stream) (void)hipStreamSynchronize(g->last_stream);
+  const LaunchTimings& l = g->history[(g->launches_profiled - 1) % kProfileRing];
   int n = 0;
-  for (uint32_t i = 0; i < g->n_timed && n < max; ++i, ++n) {
+  for (uint32_t i = 0; i < l.n && n < max; ++i, ++n) {
     float ms = 0.f;
-    (void)hipEventElapsedTime(&ms, g->timings[i].start, g->timings[i].stop);
-    g->timings[i].ms = ms;
-    if (names_out) names_out[n] = g->timings[i].name;
+    (void)hipEventElapsedTime(&ms, l.k[i].start, l.k[i].stop);
+    if (names_out) names_out[n] = l.k[i].name;
     if (ms_out) ms_out[n] = ms;
+  }
+  return n;
+}
+
+extern "C" int vpcc_gof_kernel_time_means(vpcc_gof* g, uint32_t last_n, const char** names_out, float* mean_ms_out,
+                                          uint32_t* launches_out, int max) {
+  if (launches_out) *launches_out = 0;
+  if (!g || g->launches_profiled == 0 || max <= 0) return 0;
+  (void)hipSetDevice(g->ctx->device);
+  if (g->last_stream) (void)hipStreamSynchronize(g->last_stream);
+  const uint64_t have = std::min<uint64_t>(g->launches_profiled, kProfileRing);
+  const uint64_t take = std::min<uint64_t>(last_n ? last_n : have, have);
+  std::vector<const char*> names;
+  std::vector<double> sums;
+  for (uint64_t j = 0; j < take; ++j) {
+    const LaunchTimings& l = g->history[(g->launches_profiled - 1 - j) % kProfileRing];
+    for (uint32_t i = 0; i < l.n; ++i) {
+      float ms = 0.f;
+      if (hipEventElapsedTime(&ms, l.k[i].start, l.k[i].stop) != hipSuccess) continue;
+      size_t q = 0;
+      while (q < names.size() && std::strcmp(names[q], l.k[i].name) != 0) ++q;
+      if (q == names.size()) { names.push_back(l.k[i].name); sums.push_back(0.0); }
+      sums[q] += ms;
+    }
+  }
+  if (launches_out) *launches_out = (uint32_t)take;
+  int n = 0;
+  for (size_t q = 0; q < names.size() && n < max; ++q, ++n) {
+    if (names_out) names_out[n] = names[q];
+    if (mean_ms_out) mean_ms_out[n] = (float)(sums[q] / (double)take);
   }
   return n;
 }
@@ -653,6 +700,7 @@ extern "C" int vpcc_gof_smooth(vpcc_gof* g, uint32_t first, uint32_t count, cons
   if (st) return st;
   hipStream_t s = hip_stream ? (hipStream_t)hip_stream : ctx->stream;
   g->last_stream = s;
+  Timer T(g, s, false);
   for (int pass = 0; pass < 2; ++pass) {
     const bool geo = pass == 0;
     if (!(p->flags & (geo ? VPCC_SMOOTH_GEOMETRY : VPCC_SMOOTH_COLOR))) continue;
@@ -680,13 +728,19 @@ extern "C" int vpcc_gof_smooth(vpcc_gof* g, uint32_t first, uint32_t count, cons
       const uint32_t c = std::min(chunk, first + count - c0);
       uint32_t max_points = 0;
       for (uint32_t i = c0; i < c0 + c; ++i) max_points = std::max(max_points, std::min<uint32_t>(g->h_counts[i], (uint32_t)g->capacity));
+      T.begin(geo ? "smooth_geometry_grid_clear" : "smooth_color_grid_clear");
       HIP_TRY(ctx, hipMemsetAsync(g->smooth_grid, 0, per_frame * c, s));
+      T.end();
+      T.begin(geo ? "k_smooth_stats<geometry>" : "k_smooth_stats<color>");
       launch_smooth_stats(g->d_frames, c0, c, max_points, (SmoothCell*)g->smooth_grid, w, G, geo ? 0u : 1u, s);
+      T.end();
+      T.begin(geo ? "k_smooth_apply_geometry" : "k_smooth_apply_color");
       if (geo)
         launch_smooth_apply_geometry(g->d_frames, c0, c, max_points, (const SmoothCell*)g->smooth_grid, w, G, p->threshold, s);
       else
         launch_smooth_apply_color(g->d_frames, c0, c, max_points, (const SmoothCell*)g->smooth_grid, w, G,
                                   p->color_threshold_smoothing, p->color_threshold_difference, s);
+      T.end();
       HIP_TRY(ctx, hipGetLastError());
     }
   }

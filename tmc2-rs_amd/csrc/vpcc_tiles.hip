@@ -388,9 +388,20 @@ __device__ __forceinline__ void pixel_ranks(const Item& it, const Samples& s, ui
   wave_sync();                                                             // scratch is overwritten by records next
 }
 
+// Ablation switches and in-kernel stamps exist in the DIAGNOSTIC build only (`make diag`:
+// -DVPCC_DIAGNOSTIC, libvpcc_recon_diag.so, used by tools/ — never by tests, bench.py or the
+// product): in the product build `variant` is the constant 0 and every switch folds away.
+#ifdef VPCC_DIAGNOSTIC
+constexpr bool kDiagnostic = true;
+#else
+constexpr bool kDiagnostic = false;
+#endif
+
 // Diagnostic build only (variant bit 64): per-phase cycle sums of waves 0 and 8 of every group.
 // Never read by the kernel; fetched with vpcc_debug_read_stamps().
+#ifdef VPCC_DIAGNOSTIC
 __device__ unsigned long long g_stamps[16];
+#endif
 
 __device__ __forceinline__ unsigned long long stamp() {
   unsigned long long t;
@@ -403,11 +414,15 @@ __device__ __forceinline__ unsigned long long stamp() {
     t_acc[slot] += now_ - t_prev;                                                            \
     t_prev = now_;                                                                          \
   }
+#ifdef VPCC_DIAGNOSTIC
 #define VPCC_STAMP_FLUSH()                                                                \
   if ((variant & 64u) && lane == 0) {                           \
     for (int q_ = 0; q_ < 10; ++q_) atomicAdd(&g_stamps[q_], t_acc[q_]);                    \
     atomicAdd(&g_stamps[15], 1ull);                                                         \
   }
+#else
+#define VPCC_STAMP_FLUSH()
+#endif
 
 typedef uint32_t u32x3 __attribute__((ext_vector_type(3)));
 typedef u32x3 u32x3_a4 __attribute__((aligned(4)));
@@ -443,8 +458,10 @@ __device__ __forceinline__ void store_rgb(VPCC_GLOBAL unsigned char* base, uint3
 
 }  // namespace
 
-// `variant`: 0 in production; timing-only ablation bits (VPCC_TILES_VARIANT): 1 skip look-back wait,
-// 8 skip colour conversion, 16 skip the lane<->point loop, 32 skip only its stores, 64 in-kernel stamps (diagnostic build path).
+// `variant_arg`: ignored by the product build.  Diagnostic build (VPCC_TILES_VARIANT): timing/traffic-only
+// ablation bits: 1 skip look-back wait, 8 skip colour conversion, 16 skip the lane<->point loop, 32 skip only its
+// stores, 64 in-kernel stamps, 128 no geometry re-read in the emit phase, 256 no attribute loads, 512 no
+// count-phase geometry loads.  Outputs of an ablated run are wrong by construction.
 //
 // Every workgroup is a short pipeline over the groups of ONE frame: it draws a ticket, counts that
 // group and publishes the group total BEFORE it looks back for and emits the group it counted one
@@ -462,7 +479,8 @@ template <bool kStamps>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(VPCC_TILES_WAVES_PER_EU, VPCC_TILES_WAVES_PER_EU)))
 void k_recon_tiles(const DevFrame* __restrict__ frames, uint32_t first,
                                                      uint32_t count, uint32_t groups_stride, uint32_t gen,
-                                                     uint32_t variant) {
+                                                     uint32_t variant_arg) {
+  const uint32_t variant = kDiagnostic ? variant_arg : 0u;
   // XCD-aware placement (speed only): ids equal mod 8 share an XCD/L2; a frame stays on one label.
   // The frames of one label are interleaved, so the workgroups of ONE frame start a few slots apart.
   const uint32_t xcd = blockIdx.x & 7u, slot = blockIdx.x >> 3;
@@ -532,7 +550,8 @@ void k_recon_tiles(const DevFrame* __restrict__ frames, uint32_t first,
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
           s4[i].occ = item0 + i < f.n_tiles ? occupancy_bits(f, raw[i]) : 0u;   // past the end: an empty copy of item 0
-          load_geometry<false>(f, it4[i], lane, s4[i]);
+          if (variant & 512u) { s4[i].g0 = Px4{lane, 0u}; s4[i].g1 = Px4{0u, lane}; }
+          else load_geometry<false>(f, it4[i], lane, s4[i]);
         }
         if (c0 == 0) read_early();
 #pragma unroll
@@ -570,10 +589,10 @@ void k_recon_tiles(const DevFrame* __restrict__ frames, uint32_t first,
       if (g_cur != 0 && !(variant & 1u)) excl = look_back_groups(f, g_cur, gen, early);
       const uint32_t first_item = g_cur * kTileItemsPerGroup + wave * K;
       Item it = load_item(f.tiles + (first_item < f.n_tiles ? first_item : 0u));
-      Samples cur;
+      Samples cur = {};
       cur.occ = occ_cur & 0xFu;
-      load_geometry<true>(f, it, lane, cur);
-      load_attributes(f, it, lane, cur);
+      if (!(variant & 128u)) load_geometry<true>(f, it, lane, cur);
+      if (!(variant & 256u)) load_attributes(f, it, lane, cur);
       if (wave == 0 && lane == 0) {
         if (g_cur != 0 && !(variant & 1u))
           st_store(f.scan_state + g_cur, ((uint64_t)gen << kGenShift) | kPrefix | (uint64_t)(excl + total_cur));
@@ -594,8 +613,8 @@ void k_recon_tiles(const DevFrame* __restrict__ frames, uint32_t first,
           const uint32_t next_item = g_cur * kTileItemsPerGroup + wave * K + i + 1u;
           nit = load_item(f.tiles + (next_item < f.n_tiles ? next_item : 0u));
           nxt.occ = (occ_cur >> (4u * (i + 1u))) & 0xFu;
-          load_geometry<true>(f, nit, lane, nxt);
-          load_attributes(f, nit, lane, nxt);
+          if (!(variant & 128u)) load_geometry<true>(f, nit, lane, nxt);
+          if (!(variant & 256u)) load_attributes(f, nit, lane, nxt);
         }
 
         if (n != 0) {                                       // wave-uniform
@@ -679,6 +698,7 @@ void k_recon_tiles(const DevFrame* __restrict__ frames, uint32_t first,
 
 }  // namespace vpcc
 
+#ifdef VPCC_DIAGNOSTIC
 extern "C" int vpcc_debug_read_stamps(unsigned long long* out16, int reset) {
   if (hipMemcpyFromSymbol(out16, HIP_SYMBOL(vpcc::g_stamps), sizeof(unsigned long long) * 16) != hipSuccess) return 1;
   if (reset) {
@@ -687,31 +707,40 @@ extern "C" int vpcc_debug_read_stamps(unsigned long long* out16, int reset) {
   }
   return 0;
 }
+#endif
 
 namespace vpcc {
 
 void launch_tiles(const DevFrame* d_frames, uint32_t first, uint32_t count, uint32_t max_groups, uint32_t gen,
                   void* stream) {
   if (!count || !max_groups) return;
-  static const uint32_t variant = [] {
+  // groups each workgroup is expected to pipeline (tickets are drawn dynamically; this only sizes the grid)
+  uint32_t depth = 3, variant = 0;
+#ifdef VPCC_DIAGNOSTIC
+  static const uint32_t env_variant = [] {
     const char* e = getenv("VPCC_TILES_VARIANT");
     return e ? (uint32_t)atoi(e) : 0u;
   }();
-  // groups each workgroup is expected to pipeline (tickets are drawn dynamically; this only sizes the grid)
-  static const uint32_t depth = [] {
+  static const uint32_t env_depth = [] {
     const char* e = getenv("VPCC_TILES_DEPTH");
     const int v = e ? atoi(e) : 3;
     return (uint32_t)(v < 1 ? 1 : v);
   }();
+  variant = env_variant;
+  depth = env_depth;
+#endif
   const uint32_t frame_groups = (count + 7u) / 8u;
   const uint32_t wgs = (max_groups + depth - 1u) / depth;     // workgroups per frame
   const uint32_t grid = 8u * frame_groups * wgs;
-  if (variant & 64u)
+#ifdef VPCC_DIAGNOSTIC
+  if (variant & 64u) {
     hipLaunchKernelGGL(k_recon_tiles<true>, dim3(grid), dim3(256), 0, (hipStream_t)stream, d_frames, first, count,
                        wgs, gen, variant);
-  else
-    hipLaunchKernelGGL(k_recon_tiles<false>, dim3(grid), dim3(256), 0, (hipStream_t)stream, d_frames, first, count,
-                       wgs, gen, variant);
+    return;
+  }
+#endif
+  hipLaunchKernelGGL(k_recon_tiles<false>, dim3(grid), dim3(256), 0, (hipStream_t)stream, d_frames, first, count,
+                     wgs, gen, variant);
 }
 
 }  // namespace vpcc

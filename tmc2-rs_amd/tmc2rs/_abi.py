@@ -14,6 +14,10 @@ PKG_DIR = os.path.dirname(os.path.abspath(__file__))
 PROJECT_DIR = os.path.dirname(PKG_DIR)          # tmc2-rs_amd/
 REPO_ROOT = os.path.dirname(PROJECT_DIR)
 LIB_PATH = os.path.join(PROJECT_DIR, "libvpcc_recon.so")
+# tools/ only: the diagnostic build of the same sources (`make diag`, run-time ablation switches of the
+# tile kernel).  tests/, bench.py and __graft_entry__ never set this.
+if os.environ.get("VPCC_DIAG_LIB") == "1":
+    LIB_PATH = os.path.join(PROJECT_DIR, "libvpcc_recon_diag.so")
 
 VPCC_OK = 0
 VPCC_ERR_INVALID_ARG = 1
@@ -206,6 +210,8 @@ def load_library():
     lib.vpcc_gof_download.argtypes = [vp, u32, vp, vp, vp, sz, C.POINTER(sz)]
     lib.vpcc_gof_frame_status.argtypes = [vp, u32]
     lib.vpcc_gof_kernel_times.argtypes = [vp, C.POINTER(C.c_char_p), C.POINTER(C.c_float), C.c_int]
+    lib.vpcc_gof_kernel_time_means.argtypes = [vp, u32, C.POINTER(C.c_char_p), C.POINTER(C.c_float),
+                                               C.POINTER(u32), C.c_int]
     lib.vpcc_gof_algorithmic_bytes.argtypes = [vp, u32, C.POINTER(u64)]
     lib.vpcc_gof_smooth.argtypes = [vp, u32, u32, C.POINTER(SmoothingParams), vp]
     lib.vpcc_decoder_open.argtypes = [C.c_char_p, C.POINTER(C.c_int), C.c_int, C.POINTER(vp)]

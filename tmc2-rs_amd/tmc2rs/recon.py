@@ -194,6 +194,14 @@ class Gof:
         n = self.lib.vpcc_gof_kernel_times(self.h, names, ms, 16)
         return [(names[i].decode(), float(ms[i])) for i in range(n)]
 
+    def kernel_time_means(self, last_n=0):
+        """({kernel name: mean ms over the last `last_n` profiled launches}, launches averaged)."""
+        names = (C.c_char_p * 16)()
+        ms = (C.c_float * 16)()
+        launches = C.c_uint32(0)
+        n = self.lib.vpcc_gof_kernel_time_means(self.h, int(last_n), names, ms, C.byref(launches), 16)
+        return {names[i].decode(): float(ms[i]) for i in range(n)}, launches.value
+
     def algorithmic_bytes(self, frame):
         b = C.c_uint64(0)
         self.ctx._check(self.lib.vpcc_gof_algorithmic_bytes(self.h, frame, C.byref(b)), "vpcc_gof_algorithmic_bytes")

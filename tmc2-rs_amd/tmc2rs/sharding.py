@@ -37,3 +37,59 @@ def presentation_order_counts(dist, local_counts, n_frames, device="cpu"):
         r, i = owner_of_frame(f, world)
         out.append(int(allc[r][i].item()))
     return out
+
+
+def timed_region(step, sync, steps, warmup, points_per_step, dist=None, device="cpu", min_seconds=0.0,
+                 device_sync=None):
+    """The timed region of bench.py, as the driver contract words it: `warmup` untimed steps, then K steps
+    bracketed by a barrier + device synchronisation on both sides, MAX of the elapsed time over ranks, SUM of
+    the points.  K = `steps`, raised (identically on every rank) until the region lasts about `min_seconds`:
+    a step of ~0.1 ms would otherwise give a region far shorter than any clock or power ramp.
+
+    step()        enqueues one pass of the hot path (asynchronous)
+    sync()        waits for everything this rank has enqueued
+    device_sync() optional extra device-wide synchronisation (torch.cuda.synchronize on the GPU)
+    Returns {"elapsed_s", "steps_effective", "points_total_per_step", "world"}."""
+    import math
+    import time
+
+    def full_sync():
+        sync()
+        if device_sync is not None:
+            device_sync()
+
+    def barrier():
+        full_sync()
+        if dist is not None:
+            dist.barrier()
+        full_sync()
+
+    t_est = 0.0
+    if warmup > 0:
+        full_sync()
+        t0 = time.perf_counter()
+        for _ in range(warmup):
+            step()
+        full_sync()
+        t_est = (time.perf_counter() - t0) / warmup
+    k = int(steps)
+    if min_seconds > 0.0 and t_est > 0.0:
+        k = max(k, int(math.ceil(min_seconds / t_est)))
+    if dist is not None:                       # every rank must run the same number of steps
+        import torch
+        kk = torch.tensor([k], dtype=torch.int64, device=device)
+        dist.all_reduce(kk, op=dist.ReduceOp.MAX)
+        k = int(kk.item())
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(k):
+        step()
+    full_sync()
+    elapsed = time.perf_counter() - t0
+    if dist is not None:
+        elapsed, total = job_totals(dist, elapsed, points_per_step, device)
+        dist.barrier()
+        world = dist.get_world_size()
+    else:
+        total, world = int(points_per_step), 1
+    return {"elapsed_s": elapsed, "steps_effective": k, "points_total_per_step": total, "world": world}
