@@ -219,14 +219,22 @@ __device__ __forceinline__ uint32_t occupancy_bits(const DevFrame& f, uint32_t r
 }
 
 // Plane loads are UNCONDITIONAL (no exec-masked region, so loads of several items stay in flight
-// together): a lane without an occupied pixel reads the block's first pixels instead — a line the
-// wave touches anyway — and its samples are never used.
+// together): a lane without an occupied pixel reads what the wave's first occupied lane reads — lines
+// the wave fetches anyway (HBM is read in whole 128-byte lines: a row nobody needs costs as much as a
+// needed one) — and an item without any occupancy reads the plane's first pixels, which stay cached.
+// Its samples are never used.
+__device__ __forceinline__ void load_origin(const Item& it, uint32_t lane, uint32_t occ, uint32_t& px0, uint32_t& py0) {
+  const uint64_t any = __ballot(occ != 0);
+  const uint32_t src = any ? (uint32_t)__builtin_ctzll(any) : 0u;          // wave-uniform
+  const uint32_t l = occ ? lane : src;
+  px0 = any ? it.x0 + 4u * (l & 3u) : 0u;
+  py0 = any ? it.y0 + (l >> 2) : 0u;
+}
 template <bool kLastUse>
 __device__ __forceinline__ void load_geometry(const DevFrame& f, const Item& it, uint32_t lane, Samples& s) {
   constexpr bool kS = kLastUse && (VPCC_TILES_NT & 4);
   uint32_t px0, py0;
-  lane_origin(it, lane, px0, py0);
-  if (s.occ == 0) { px0 = it.x0; py0 = it.y0; }
+  load_origin(it, lane, s.occ, px0, py0);
   s.g0 = load4_row<kS>(f.geo[0], (__umul24(py0, f.geo_stride[0]) + px0) * 2u);
   s.g1 = load4_row<kS>(f.geo[1], (__umul24(py0, f.geo_stride[1]) + px0) * 2u);      // single map: an alias of layer 0
 }
@@ -235,8 +243,7 @@ __device__ __forceinline__ void load_geometry(const DevFrame& f, const Item& it,
 // chroma sample px0/2, pixels 2,3 the next one.
 __device__ __forceinline__ void load_attributes(const DevFrame& f, const Item& it, uint32_t lane, Samples& s) {
   uint32_t px0, py0;
-  lane_origin(it, lane, px0, py0);
-  if (s.occ == 0) { px0 = it.x0; py0 = it.y0; }
+  load_origin(it, lane, s.occ, px0, py0);
   const uint32_t c0 = (__umul24(py0 >> 1, f.attr_cstride[0]) + (px0 >> 1)) * 2u;
   const uint32_t c1 = (__umul24(py0 >> 1, f.attr_cstride[1]) + (px0 >> 1)) * 2u;
   constexpr bool kS = VPCC_TILES_NT & 2;
@@ -475,6 +482,88 @@ __device__ __forceinline__ void store_rgb(VPCC_GLOBAL unsigned char* base, uint3
 #ifndef VPCC_TILES_WAVES_PER_EU
 #define VPCC_TILES_WAVES_PER_EU 4
 #endif
+// 1: pipelined (count group g+1, then emit group g; geometry read twice)   2: resident (all of a group's
+// samples in registers, every plane byte read once)
+//                                                   3: pipelined, the counted geometry stays in registers
+#ifndef VPCC_TILES_STRUCTURE
+#define VPCC_TILES_STRUCTURE 3
+#endif
+// One item from samples in registers to its points in HBM: ranks, colours, compaction of the 8-B records
+// through the wave's LDS slots, then lane <-> point (back-projection, contiguous stores at `base`).
+// `n` = the item's point count (wave-uniform, from the count phase), `dup` its duplicate nibble.
+template <class Hook>
+__device__ __forceinline__ void emit_item(const DevFrame& f, const Item& it, const Samples& cur, uint32_t dup, uint32_t n,
+                                          uint32_t base, uint32_t lane, uint2* slots, uint32_t variant, Hook before_stores) {
+  VPCC_GLOBAL unsigned char* const gx = (VPCC_GLOBAL unsigned char*)f.out_xyz;
+  VPCC_GLOBAL unsigned char* const gc = (VPCC_GLOBAL unsigned char*)f.out_rgb;
+  VPCC_GLOBAL uint16_t* const gp = glw(f.out_patch);
+  if (n == 0) return;                                       // wave-uniform
+  uint32_t rk[4];
+  const uint32_t cnt = 2u * (uint32_t)__builtin_popcount(cur.occ) - (uint32_t)__builtin_popcount(dup);
+  pixel_ranks(it, cur, dup, cnt, lane, reinterpret_cast<unsigned char*>(slots), rk);
+  uint32_t rgb0[4] = {0, 0, 0, 0}, rgb1[4] = {0, 0, 0, 0};
+  if (f.has_attr && !(variant & 8u)) {
+    colours4(cur.y0, cur.u0, cur.v0, rgb0);
+    if (f.map_count > 1) colours4(cur.y1, cur.u1, cur.v1, rgb1);
+  }
+  // patch-local offsets of the lane's pixels: Default (du, dv) = (4q + j, r); Swap (du, dv) = (r, 4q + j)
+  const uint32_t q4 = 4u * (lane & 3u), r = lane >> 2;
+  const bool swap = it.flags & kTileSwap;
+  const uint32_t pix0 = swap ? q4 * 16u + r : r * 16u + q4, pstep = swap ? 16u : 1u;
+  const uint32_t dump = 512u + lane;
+  put_records<0>(cur, dup, pix0, rk[0], dump, rgb0, rgb1, slots);
+  put_records<1>(cur, dup, pix0 + pstep, rk[1], dump, rgb0, rgb1, slots);
+  put_records<2>(cur, dup, pix0 + 2u * pstep, rk[2], dump, rgb0, rgb1, slots);
+  put_records<3>(cur, dup, pix0 + 3u * pstep, rk[3], dump, rgb0, rgb1, slots);
+  wave_sync();                                      // records written by other lanes are read below
+  before_stores();
+
+  const uint32_t room = base < f.capacity ? f.capacity - base : 0u;   // never write past the caller's arrays
+  const uint32_t nw = (variant & 16u) ? 0u : (n < room ? n : room);
+  // Two consecutive points per lane: one 16-B record read, one 12-B xyz store and one 6-B rgb store
+  // per lane and step (the CU issues a vector-memory instruction only every few cycles).
+  for (uint32_t k = 2u * lane; k < nw; k += 128u) {
+    const uint4 rr = *reinterpret_cast<const uint4*>(slots + k);       // records k and k+1
+    const bool two = k + 1u < nw;
+    uint2 p[2];
+    uint32_t rgb[2];
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      // an odd tail has no second record: reuse the first (a stale slot could hold anything)
+      const uint32_t rx = (h && two) ? rr.z : rr.x, ry = (h && two) ? rr.w : rr.y;
+      const uint32_t depth = rx & 0xFFFFu, du = (rx >> 16) & 15u, dv = (rx >> 20) & 15u;
+      p[h] = pack_point(it, depth, du, dv);
+      if (!f.absolute_d1 && (rx >> 24) != 0) {      // relative D1: the D0 record of this pixel precedes it
+        const uint32_t d0 = h ? (rr.x & 0xFFFFu) : (slots[k - 1u].x & 0xFFFFu);
+        p[h] = relative_point(it.axes & 3u, it.flags & kTileMode1, pack_point(it, d0, du, dv), depth);
+      }
+      rgb[h] = ry;
+    }
+    if ((variant & 32u) && p[0].x != 0xFFFFFFFEu) continue;           // ablation: all the arithmetic, no stores
+    if (two) {
+      store_xyz2(gx, (base + k) * 6u, p[0], p[1]);
+      if (f.has_attr) store_rgb2(gc, (base + k) * 3u, rgb[0], rgb[1]);
+      if (gp) out_store<u32_a2>((VPCC_GLOBAL unsigned char*)gp + (base + k) * 2u, it.patch | (it.patch << 16));   // partition, codec.rs:452
+    } else {
+      store_xyz(gx, (base + k) * 6u, p[0]);
+      if (f.has_attr) store_rgb(gc, (base + k) * 3u, rgb[0]);
+      if (gp) gp[base + k] = (uint16_t)it.patch;
+    }
+  }
+  wave_sync();                                      // the next item overwrites the slots
+}
+
+// Which item of its group a wave handles in its i-th turn.  Interleaved (default): the four waves take four
+// CONSECUTIVE items at the same time — in a Default patch these are horizontal neighbours that share
+// every 128-byte line (a 16-pixel row is 32 B), so the line is requested once while it is in flight or
+// L1/L2-hot instead of four times, 6 us apart (measured: profiles/r02).  0: wave w takes items 4w..4w+3.
+#ifndef VPCC_TILES_INTERLEAVE
+#define VPCC_TILES_INTERLEAVE 1
+#endif
+__device__ __forceinline__ uint32_t item_in_group(uint32_t wave, uint32_t i) {
+  return VPCC_TILES_INTERLEAVE ? i * 4u + wave : wave * kTileItemsPerWave + i;
+}
+
 template <bool kStamps>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(VPCC_TILES_WAVES_PER_EU, VPCC_TILES_WAVES_PER_EU)))
 void k_recon_tiles(const DevFrame* __restrict__ frames, uint32_t first,
@@ -498,15 +587,17 @@ void k_recon_tiles(const DevFrame* __restrict__ frames, uint32_t first,
   const uint32_t n_groups = (f.n_tiles + kTileItemsPerGroup - 1u) / kTileItemsPerGroup;
   const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = lane_id();
   constexpr uint32_t K = kTileItemsPerWave;
-  static_assert(K % 4 == 0 && K <= 8, "one occupancy / duplicate nibble per item in a 32-bit register");
+  static_assert(K == 4, "one occupancy / duplicate nibble per item; four items of resident geometry");
 
   uint2* slots = s_slots[wave];
-  VPCC_GLOBAL unsigned char* const gx = (VPCC_GLOBAL unsigned char*)f.out_xyz;
-  VPCC_GLOBAL unsigned char* const gc = (VPCC_GLOBAL unsigned char*)f.out_rgb;
-  VPCC_GLOBAL uint16_t* const gp = glw(f.out_patch);
 
   uint32_t g_cur = 0, occ_cur = 0, dup_cur = 0, total_cur = 0, cb = 0;
   bool have_cur = false;
+  // Structure 3: the geometry the count phase loaded stays in registers until the group is emitted one step
+  // later (16 VGPRs per group in flight) instead of being read again: the re-read missed the L2 almost
+  // always (23 us and ~60 MB of output per XCD lie between the two reads; profiles/r02).
+  constexpr bool kGeoResident = VPCC_TILES_STRUCTURE == 3;
+  Px4 gn0[4] = {}, gn1[4] = {}, gc0[4] = {}, gc1[4] = {};
   for (;;) {
     // ---- 1. draw the NEXT group of this frame.  Every workgroup of the frame stops at its first ticket
     // past the end, so exactly n_groups + groups_stride tickets are drawn per launch: the last re-arms
@@ -539,17 +630,19 @@ void k_recon_tiles(const DevFrame* __restrict__ frames, uint32_t first,
     if (have_next) {
 #pragma unroll
       for (uint32_t c0 = 0; c0 < K; c0 += 4u) {            // four items' loads in flight at a time
-        const uint32_t item0 = g_next * kTileItemsPerGroup + wave * K + c0;
+        uint32_t idx4[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) idx4[i] = g_next * kTileItemsPerGroup + item_in_group(wave, c0 + i);
         Item it4[4];
         Samples s4[4];
         uint32_t raw[4];
 #pragma unroll
-        for (int i = 0; i < 4; ++i) it4[i] = load_item(f.tiles + (item0 + i < f.n_tiles ? item0 + i : 0u));
+        for (int i = 0; i < 4; ++i) it4[i] = load_item(f.tiles + (idx4[i] < f.n_tiles ? idx4[i] : 0u));
 #pragma unroll
         for (int i = 0; i < 4; ++i) raw[i] = load_occupancy_raw(f, it4[i], lane);
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-          s4[i].occ = item0 + i < f.n_tiles ? occupancy_bits(f, raw[i]) : 0u;   // past the end: an empty copy of item 0
+          s4[i].occ = idx4[i] < f.n_tiles ? occupancy_bits(f, raw[i]) : 0u;   // past the end: an empty copy of item 0
           if (variant & 512u) { s4[i].g0 = Px4{lane, 0u}; s4[i].g1 = Px4{0u, lane}; }
           else load_geometry<false>(f, it4[i], lane, s4[i]);
         }
@@ -557,10 +650,11 @@ void k_recon_tiles(const DevFrame* __restrict__ frames, uint32_t first,
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
           const uint32_t dup = classify(f, it4[i], s4[i]) & s4[i].occ;
+          if (kGeoResident) { gn0[i] = s4[i].g0; gn1[i] = s4[i].g1; }
           occ_next |= s4[i].occ << (4u * (c0 + i));
           dup_next |= dup << (4u * (c0 + i));
           const uint32_t cnt = wave_sum(2u * (uint32_t)__builtin_popcount(s4[i].occ) - (uint32_t)__builtin_popcount(dup));
-          if (lane == 0) s_tot[cb ^ 1u][wave * K + c0 + i] = cnt;
+          if (lane == 0) s_tot[cb ^ 1u][item_in_group(wave, c0 + i)] = cnt;
         }
       }
     }
@@ -587,11 +681,12 @@ void k_recon_tiles(const DevFrame* __restrict__ frames, uint32_t first,
       // in-order vmcnt.)
       uint32_t excl = (variant & 1u) ? g_cur * 7000u : 0u;   // ablation: no wait, outputs still spread over the frame
       if (g_cur != 0 && !(variant & 1u)) excl = look_back_groups(f, g_cur, gen, early);
-      const uint32_t first_item = g_cur * kTileItemsPerGroup + wave * K;
+      const uint32_t first_item = g_cur * kTileItemsPerGroup + item_in_group(wave, 0);
       Item it = load_item(f.tiles + (first_item < f.n_tiles ? first_item : 0u));
       Samples cur = {};
       cur.occ = occ_cur & 0xFu;
-      if (!(variant & 128u)) load_geometry<true>(f, it, lane, cur);
+      if (kGeoResident) { cur.g0 = gc0[0]; cur.g1 = gc1[0]; }
+      else if (!(variant & 128u)) load_geometry<true>(f, it, lane, cur);
       if (!(variant & 256u)) load_attributes(f, it, lane, cur);
       if (wave == 0 && lane == 0) {
         if (g_cur != 0 && !(variant & 1u))
@@ -601,83 +696,39 @@ void k_recon_tiles(const DevFrame* __restrict__ frames, uint32_t first,
       }
       VPCC_STAMP(4)
       uint32_t base = excl;
-      for (uint32_t k = 0; k < wave * K; ++k) base += s_tot[cb][k];
+      for (uint32_t k = 0; k < item_in_group(wave, 0); ++k) base += s_tot[cb][k];
 
       // ---- 4. per item: colours, compaction of the records through LDS, then lane <-> point ---------
       for (uint32_t i = 0; i < K; ++i) {
-        const uint32_t n = s_tot[cb][wave * K + i];
+        const uint32_t n = s_tot[cb][item_in_group(wave, i)];
         // prefetch the next item's samples; nothing here depends on an outstanding vector load
         Item nit = it;
         Samples nxt = {};
         if (i + 1u < K) {
-          const uint32_t next_item = g_cur * kTileItemsPerGroup + wave * K + i + 1u;
+          const uint32_t next_item = g_cur * kTileItemsPerGroup + item_in_group(wave, i + 1u);
           nit = load_item(f.tiles + (next_item < f.n_tiles ? next_item : 0u));
           nxt.occ = (occ_cur >> (4u * (i + 1u))) & 0xFu;
-          if (!(variant & 128u)) load_geometry<true>(f, nit, lane, nxt);
+          if (kGeoResident) { nxt.g0 = gc0[1]; nxt.g1 = gc1[1]; }
+          else if (!(variant & 128u)) load_geometry<true>(f, nit, lane, nxt);
           if (!(variant & 256u)) load_attributes(f, nit, lane, nxt);
         }
-
-        if (n != 0) {                                       // wave-uniform
-          uint32_t rk[4];
-          const uint32_t dup = (dup_cur >> (4u * i)) & 0xFu;                 // from the count phase
-          const uint32_t cnt = 2u * (uint32_t)__builtin_popcount(cur.occ) - (uint32_t)__builtin_popcount(dup);
-          pixel_ranks(it, cur, dup, cnt, lane, reinterpret_cast<unsigned char*>(slots), rk);
-          uint32_t rgb0[4] = {0, 0, 0, 0}, rgb1[4] = {0, 0, 0, 0};
-          if (f.has_attr && !(variant & 8u)) {
-            colours4(cur.y0, cur.u0, cur.v0, rgb0);
-            if (f.map_count > 1) colours4(cur.y1, cur.u1, cur.v1, rgb1);
-          }
-          // patch-local offsets of the lane's pixels: Default (du, dv) = (4q + j, r); Swap (du, dv) = (r, 4q + j)
-          const uint32_t q4 = 4u * (lane & 3u), r = lane >> 2;
-          const bool swap = it.flags & kTileSwap;
-          const uint32_t pix0 = swap ? q4 * 16u + r : r * 16u + q4, pstep = swap ? 16u : 1u;
-          const uint32_t dump = 512u + lane;
-          put_records<0>(cur, dup, pix0, rk[0], dump, rgb0, rgb1, slots);
-          put_records<1>(cur, dup, pix0 + pstep, rk[1], dump, rgb0, rgb1, slots);
-          put_records<2>(cur, dup, pix0 + 2u * pstep, rk[2], dump, rgb0, rgb1, slots);
-          put_records<3>(cur, dup, pix0 + 3u * pstep, rk[3], dump, rgb0, rgb1, slots);
-          wave_sync();                                      // records written by other lanes are read below
-          // Take delivery of the prefetched samples NOW, before this item's stores are issued: waited for
-          // later, the in-order vmcnt would make that wait cover the stores as well.
-          asm volatile("" : "+v"(nxt.g0.lo), "+v"(nxt.g0.hi), "+v"(nxt.g1.lo), "+v"(nxt.g1.hi), "+v"(nxt.y0.lo),
-                       "+v"(nxt.y0.hi), "+v"(nxt.y1.lo), "+v"(nxt.y1.hi));
-          asm volatile("" : "+v"(nxt.u0), "+v"(nxt.v0), "+v"(nxt.u1), "+v"(nxt.v1));
-
-          const uint32_t room = base < f.capacity ? f.capacity - base : 0u;   // never write past the caller's arrays
-          const uint32_t nw = (variant & 16u) ? 0u : (n < room ? n : room);
-          // Two consecutive points per lane: one 16-B record read, one 12-B xyz store and one 6-B rgb store
-          // per lane and step (the CU issues a vector-memory instruction only every few cycles).
-          for (uint32_t k = 2u * lane; k < nw; k += 128u) {
-            const uint4 rr = *reinterpret_cast<const uint4*>(slots + k);       // records k and k+1
-            const bool two = k + 1u < nw;
-            uint2 p[2];
-            uint32_t rgb[2];
-#pragma unroll
-            for (int h = 0; h < 2; ++h) {
-              // an odd tail has no second record: reuse the first (a stale slot could hold anything)
-              const uint32_t rx = (h && two) ? rr.z : rr.x, ry = (h && two) ? rr.w : rr.y;
-              const uint32_t depth = rx & 0xFFFFu, du = (rx >> 16) & 15u, dv = (rx >> 20) & 15u;
-              p[h] = pack_point(it, depth, du, dv);
-              if (!f.absolute_d1 && (rx >> 24) != 0) {      // relative D1: the D0 record of this pixel precedes it
-                const uint32_t d0 = h ? (rr.x & 0xFFFFu) : (slots[k - 1u].x & 0xFFFFu);
-                p[h] = relative_point(it.axes & 3u, it.flags & kTileMode1, pack_point(it, d0, du, dv), depth);
-              }
-              rgb[h] = ry;
-            }
-            if ((variant & 32u) && p[0].x != 0xFFFFFFFEu) continue;           // ablation: all the arithmetic, no stores
-            if (two) {
-              store_xyz2(gx, (base + k) * 6u, p[0], p[1]);
-              if (f.has_attr) store_rgb2(gc, (base + k) * 3u, rgb[0], rgb[1]);
-              if (gp) out_store<u32_a2>((VPCC_GLOBAL unsigned char*)gp + (base + k) * 2u, it.patch | (it.patch << 16));   // partition, codec.rs:452
-            } else {
-              store_xyz(gx, (base + k) * 6u, p[0]);
-              if (f.has_attr) store_rgb(gc, (base + k) * 3u, rgb[0]);
-              if (gp) gp[base + k] = (uint16_t)it.patch;
-            }
-          }
-          wave_sync();                                      // the next item overwrites the slots
+        if (kGeoResident) {                                 // rotate: static register indices in a rolled loop
+          gc0[0] = gc0[1]; gc0[1] = gc0[2]; gc0[2] = gc0[3];
+          gc1[0] = gc1[1]; gc1[1] = gc1[2]; gc1[2] = gc1[3];
         }
-        base += n;
+
+        {
+          const uint32_t dup = (dup_cur >> (4u * i)) & 0xFu;                 // from the count phase
+          // Take delivery of the prefetched samples before this item's stores are issued: waited for
+          // later, the in-order vmcnt would make that wait cover the stores as well.
+          emit_item(f, it, cur, dup, n, base, lane, slots, variant, [&]() {
+            asm volatile("" : "+v"(nxt.g0.lo), "+v"(nxt.g0.hi), "+v"(nxt.g1.lo), "+v"(nxt.g1.hi), "+v"(nxt.y0.lo),
+                         "+v"(nxt.y0.hi), "+v"(nxt.y1.lo), "+v"(nxt.y1.hi));
+            asm volatile("" : "+v"(nxt.u0), "+v"(nxt.v0), "+v"(nxt.u1), "+v"(nxt.v1));
+          });
+        }
+        // the items between this one and the wave's next one (the other waves' when interleaved)
+        for (uint32_t k = item_in_group(wave, i); k < item_in_group(wave, i + 1u) && k < kTileItemsPerGroup; ++k) base += s_tot[cb][k];
         it = nit;
         cur = nxt;
       }
@@ -688,12 +739,127 @@ void k_recon_tiles(const DevFrame* __restrict__ frames, uint32_t first,
     occ_cur = occ_next;
     dup_cur = dup_next;
     total_cur = total_next;
+    if (kGeoResident) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) { gc0[i] = gn0[i]; gc1[i] = gn1[i]; }
+    }
     cb ^= 1u;
     have_cur = true;
   }
   if constexpr (kStamps) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   VPCC_STAMP(6)
   VPCC_STAMP_FLUSH()
+}
+
+
+// ---------------------------------------------------------------------------------------------------
+// Structure 2 ("resident"): every plane byte is read ONCE.  A wave issues the loads of all four of its
+// items up front (occupancy, then geometry, the speculative look-back read, then the attributes: ~10 KB in
+// flight per wave instead of 2.5 KB), counts as soon as the geometry has landed, and emits the group
+// from registers.  No load is issued between or behind the output stores, so no wait for samples ever
+// covers stores (gfx9's single in-order vmcnt).  The look-back of group g waits only for the jitter between
+// workgroups: every predecessor drew its ticket — and issued its loads — earlier than this workgroup.
+template <bool kStamps>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(VPCC_TILES_WAVES_PER_EU, VPCC_TILES_WAVES_PER_EU)))
+void k_recon_tiles_resident(const DevFrame* __restrict__ frames, uint32_t first, uint32_t count, uint32_t groups_stride,
+                            uint32_t gen, uint32_t variant_arg) {
+  const uint32_t variant = kDiagnostic ? variant_arg : 0u;
+  const uint32_t xcd = blockIdx.x & 7u, slot = blockIdx.x >> 3;
+  const uint32_t frame_groups = (count + 7u) / 8u;
+  const uint32_t fi = xcd + 8u * (slot % frame_groups);
+  if (fi >= count) return;
+  const DevFrame& f = frames[first + fi];
+
+  __shared__ uint32_t s_group;
+  __shared__ uint32_t s_tot[kTileItemsPerGroup];
+  __shared__ __attribute__((aligned(16))) uint2 s_slots[4][kSlotsPerWave];
+
+  const uint32_t n_groups = (f.n_tiles + kTileItemsPerGroup - 1u) / kTileItemsPerGroup;
+  const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = lane_id();
+  constexpr uint32_t K = kTileItemsPerWave;
+  static_assert(K == 4, "four items per wave are kept in registers");
+  uint2* slots = s_slots[wave];
+
+  for (;;) {
+    // ---- 1. ticket (see k_recon_tiles: n_groups + groups_stride tickets per launch, the last re-arms) ----
+    if (threadIdx.x == 0) {
+      const uint32_t t = __hip_atomic_fetch_add(glw(f.ticket), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if (t + 1u == n_groups + groups_stride)
+        __hip_atomic_store(glw(f.ticket), 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      s_group = t;
+    }
+    __syncthreads();
+    const uint32_t g = __builtin_amdgcn_readfirstlane(s_group);
+    if (g >= n_groups) break;
+
+    // ---- 2. all loads of the wave's four items -------------------------------------------------------
+    uint32_t idx[K];
+    Samples s[K];
+    {
+      Item it4[K];
+      uint32_t raw[K];
+#pragma unroll
+      for (uint32_t i = 0; i < K; ++i) {
+        idx[i] = g * kTileItemsPerGroup + item_in_group(wave, i);
+        it4[i] = load_item(f.tiles + (idx[i] < f.n_tiles ? idx[i] : 0u));
+      }
+#pragma unroll
+      for (uint32_t i = 0; i < K; ++i) raw[i] = load_occupancy_raw(f, it4[i], lane);
+#pragma unroll
+      for (uint32_t i = 0; i < K; ++i) {
+        s[i].occ = idx[i] < f.n_tiles ? occupancy_bits(f, raw[i]) : 0u;     // past the end: an empty copy of item 0
+        if (variant & 512u) { s[i].g0 = Px4{lane, 0u}; s[i].g1 = Px4{0u, lane}; }
+        else load_geometry<true>(f, it4[i], lane, s[i]);
+      }
+    }
+    // speculative look-back read behind the geometry (a cacheable load: an older state of a word is always
+    // safe to act on, see k_recon_tiles); it lands before the attributes
+    uint64_t early = 0;
+    if (lane < g)
+      early = __hip_atomic_load(gl(f.scan_state + (g - 1u - lane)), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+#pragma unroll
+    for (uint32_t i = 0; i < K; ++i) {
+      const Item it = load_item(f.tiles + (idx[i] < f.n_tiles ? idx[i] : 0u));
+      s[i].y0 = s[i].y1 = Px4{0u, 0u};
+      s[i].u0 = s[i].v0 = s[i].u1 = s[i].v1 = 0u;
+      if (!(variant & 256u)) load_attributes(f, it, lane, s[i]);
+    }
+
+    // ---- 3. count (needs the geometry only) -----------------------------------------------------------
+    uint32_t dups = 0;
+#pragma unroll
+    for (uint32_t i = 0; i < K; ++i) {
+      const Item it = load_item(f.tiles + (idx[i] < f.n_tiles ? idx[i] : 0u));
+      const uint32_t dup = classify(f, it, s[i]) & s[i].occ;
+      dups |= dup << (4u * i);
+      const uint32_t cnt = wave_sum(2u * (uint32_t)__builtin_popcount(s[i].occ) - (uint32_t)__builtin_popcount(dup));
+      if (lane == 0) s_tot[item_in_group(wave, i)] = cnt;
+    }
+    __syncthreads();
+    uint32_t total = lane < kTileItemsPerGroup ? s_tot[lane] : 0u;
+    total = wave_sum(total);
+    if (wave == 0 && lane == 0 && g != 0)
+      st_store(f.scan_state + g, ((uint64_t)gen << kGenShift) | kAggregate | total);
+
+    // ---- 4. look back (every wave for itself), publish the inclusive prefix ----------------------------
+    uint32_t excl = (variant & 1u) ? g * 7000u : 0u;
+    if (g != 0 && !(variant & 1u)) excl = look_back_groups(f, g, gen, early);
+    if (wave == 0 && lane == 0) {
+      st_store(f.scan_state + g, ((uint64_t)gen << kGenShift) | kPrefix | (uint64_t)(excl + total));
+      if (g + 1u == n_groups)                                            // tile.total_number_of_regular_points
+        *glw(f.n_points) = (variant & 1u) ? (excl + total < f.capacity ? excl + total : f.capacity) : excl + total;
+    }
+
+    // ---- 5. emit the four items from registers ----------------------------------------------------------
+    uint32_t base = excl;
+    for (uint32_t k = 0; k < item_in_group(wave, 0); ++k) base += s_tot[k];
+#pragma unroll
+    for (uint32_t i = 0; i < K; ++i) {
+      const Item it = load_item(f.tiles + (idx[i] < f.n_tiles ? idx[i] : 0u));
+      emit_item(f, it, s[i], (dups >> (4u * i)) & 0xFu, s_tot[item_in_group(wave, i)], base, lane, slots, variant, [] {});
+      for (uint32_t k = item_in_group(wave, i); k < item_in_group(wave, i + 1u) && k < kTileItemsPerGroup; ++k) base += s_tot[k];
+    }
+  }
 }
 
 }  // namespace vpcc
@@ -739,8 +905,13 @@ void launch_tiles(const DevFrame* d_frames, uint32_t first, uint32_t count, uint
     return;
   }
 #endif
+#if VPCC_TILES_STRUCTURE == 2
+  hipLaunchKernelGGL(k_recon_tiles_resident<false>, dim3(grid), dim3(256), 0, (hipStream_t)stream, d_frames, first, count,
+                     wgs, gen, variant);
+#else
   hipLaunchKernelGGL(k_recon_tiles<false>, dim3(grid), dim3(256), 0, (hipStream_t)stream, d_frames, first, count,
                      wgs, gen, variant);
+#endif
 }
 
 }  // namespace vpcc
