@@ -271,7 +271,7 @@ int gof_create_impl(vpcc_ctx* ctx, const vpcc_frame_desc* frames, uint32_t n_fra
   // control words of the single-pass path: contiguous so that one memset re-arms a launch
   g->scan_off.assign(n_frames + 1, 0);
   for (uint32_t i = 0; i < n_frames; ++i)
-    g->scan_off[i + 1] = g->scan_off[i] + (g->plans[i].tiles.size() + kTileItemsPerGroup - 1) / kTileItemsPerGroup;
+    g->scan_off[i + 1] = g->scan_off[i] + (g->plans[i].tiles.size() + kTileScanGranule - 1) / kTileScanGranule;
   const size_t ctrl_begin = L.total;
   const size_t off_tickets = L.total;
   L.total += 256 * (size_t)n_frames;              // one ticket per 256-B line: same-line atomics serialise
@@ -511,7 +511,7 @@ extern "C" int vpcc_gof_reconstruct(vpcc_gof* g, uint32_t first, uint32_t count,
     // single-pass tile kernel: re-arm counts, tickets and look-back words, then ONE kernel
     uint32_t max_groups = 0;
     for (uint32_t i = first; i < first + count; ++i)
-      max_groups = std::max(max_groups, (uint32_t)(g->scan_off[i + 1] - g->scan_off[i]));
+      max_groups = std::max(max_groups, (uint32_t)((g->plans[i].tiles.size() + kTileItemsPerGroup - 1) / kTileItemsPerGroup));
     // Nothing to clear: look-back words carry the launch generation, every ticket counter is re-armed by
     // the last workgroup that draws from it, and a frame's point count is rewritten by its last group
     // (a frame without tiles keeps the zero written at creation).

@@ -485,9 +485,18 @@ __device__ __forceinline__ void store_rgb(VPCC_GLOBAL unsigned char* base, uint3
 // 1: pipelined (count group g+1, then emit group g; geometry read twice)   2: resident (all of a group's
 // samples in registers, every plane byte read once)
 //                                                   3: pipelined, the counted geometry stays in registers
+//                                                   4: structure 3 with wave-level tickets, no workgroup barriers
 #ifndef VPCC_TILES_STRUCTURE
 #define VPCC_TILES_STRUCTURE 3
 #endif
+// "Take delivery" of prefetched samples: an empty asm that uses the registers, so the compiler places the
+// wait for their loads HERE (and knows them complete afterwards).
+__device__ __forceinline__ void take_delivery(Samples& s) {
+  asm volatile("" : "+v"(s.g0.lo), "+v"(s.g0.hi), "+v"(s.g1.lo), "+v"(s.g1.hi), "+v"(s.y0.lo), "+v"(s.y0.hi),
+               "+v"(s.y1.lo), "+v"(s.y1.hi));
+  asm volatile("" : "+v"(s.u0), "+v"(s.v0), "+v"(s.u1), "+v"(s.v1));
+}
+
 // One item from samples in registers to its points in HBM: ranks, colours, compaction of the 8-B records
 // through the wave's LDS slots, then lane <-> point (back-projection, contiguous stores at `base`).
 // `n` = the item's point count (wave-uniform, from the count phase), `dup` its duplicate nibble.
@@ -497,7 +506,12 @@ __device__ __forceinline__ void emit_item(const DevFrame& f, const Item& it, con
   VPCC_GLOBAL unsigned char* const gx = (VPCC_GLOBAL unsigned char*)f.out_xyz;
   VPCC_GLOBAL unsigned char* const gc = (VPCC_GLOBAL unsigned char*)f.out_rgb;
   VPCC_GLOBAL uint16_t* const gp = glw(f.out_patch);
-  if (n == 0) return;                                       // wave-uniform
+  if (n == 0) {                                             // wave-uniform
+    // Same counter state on both paths: were the prefetched samples still pending here, the compiler would
+    // have to wait for vmcnt(0) where the paths join — i.e. for this wave's output stores, after every item.
+    before_stores();
+    return;
+  }
   uint32_t rk[4];
   const uint32_t cnt = 2u * (uint32_t)__builtin_popcount(cur.occ) - (uint32_t)__builtin_popcount(dup);
   pixel_ranks(it, cur, dup, cnt, lane, reinterpret_cast<unsigned char*>(slots), rk);
@@ -598,6 +612,8 @@ void k_recon_tiles(const DevFrame* __restrict__ frames, uint32_t first,
   // always (23 us and ~60 MB of output per XCD lie between the two reads; profiles/r02).
   constexpr bool kGeoResident = VPCC_TILES_STRUCTURE == 3;
   Px4 gn0[4] = {}, gn1[4] = {}, gc0[4] = {}, gc1[4] = {};
+  Samples a_first = {};                // attribute samples of the wave's first item of the current group,
+                                       // prefetched during the previous step
   for (;;) {
     // ---- 1. draw the NEXT group of this frame.  Every workgroup of the frame stops at its first ticket
     // past the end, so exactly n_groups + groups_stride tickets are drawn per launch: the last re-arms
@@ -650,7 +666,13 @@ void k_recon_tiles(const DevFrame* __restrict__ frames, uint32_t first,
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
           const uint32_t dup = classify(f, it4[i], s4[i]) & s4[i].occ;
-          if (kGeoResident) { gn0[i] = s4[i].g0; gn1[i] = s4[i].g1; }
+          if (kGeoResident) {
+            gn0[i] = s4[i].g0; gn1[i] = s4[i].g1;
+            // classify() does not touch the samples on every path (single map, degenerate axes): make the
+            // loads complete on ALL paths, or the emit loop has to wait for vmcnt(0) — its own stores — at
+            // the first move of these registers
+            asm volatile("" : "+v"(gn0[i].lo), "+v"(gn0[i].hi), "+v"(gn1[i].lo), "+v"(gn1[i].hi));
+          }
           occ_next |= s4[i].occ << (4u * (c0 + i));
           dup_next |= dup << (4u * (c0 + i));
           const uint32_t cnt = wave_sum(2u * (uint32_t)__builtin_popcount(s4[i].occ) - (uint32_t)__builtin_popcount(dup));
@@ -677,17 +699,21 @@ void k_recon_tiles(const DevFrame* __restrict__ frames, uint32_t first,
 
     if (have_cur) {
       // The look-back words were read before the count phase, whose loads have all been consumed: taking
-      // delivery of them here waits for nothing.  (After the first item's loads it would wait for those:
-      // in-order vmcnt.)
+      // delivery of them here waits for nothing.
       uint32_t excl = (variant & 1u) ? g_cur * 7000u : 0u;   // ablation: no wait, outputs still spread over the frame
       if (g_cur != 0 && !(variant & 1u)) excl = look_back_groups(f, g_cur, gen, early);
+      // the speculative read is complete on EVERY path from here on (group 0 never looks at it): a pending
+      // load into registers the item loop reuses would cost a vmcnt(0) — a wait for the output stores — per item
+      asm volatile("" : "+v"(early));
       const uint32_t first_item = g_cur * kTileItemsPerGroup + item_in_group(wave, 0);
       Item it = load_item(f.tiles + (first_item < f.n_tiles ? first_item : 0u));
-      Samples cur = {};
+      Samples cur = a_first;                                 // attributes prefetched during the previous step
       cur.occ = occ_cur & 0xFu;
       if (kGeoResident) { cur.g0 = gc0[0]; cur.g1 = gc1[0]; }
-      else if (!(variant & 128u)) load_geometry<true>(f, it, lane, cur);
-      if (!(variant & 256u)) load_attributes(f, it, lane, cur);
+      else {
+        if (!(variant & 128u)) load_geometry<true>(f, it, lane, cur);
+        take_delivery(cur);
+      }
       if (wave == 0 && lane == 0) {
         if (g_cur != 0 && !(variant & 1u))
           st_store(f.scan_state + g_cur, ((uint64_t)gen << kGenShift) | kPrefix | (uint64_t)(excl + total_cur));
@@ -701,38 +727,49 @@ void k_recon_tiles(const DevFrame* __restrict__ frames, uint32_t first,
       // ---- 4. per item: colours, compaction of the records through LDS, then lane <-> point ---------
       for (uint32_t i = 0; i < K; ++i) {
         const uint32_t n = s_tot[cb][item_in_group(wave, i)];
-        // prefetch the next item's samples; nothing here depends on an outstanding vector load
-        Item nit = it;
-        Samples nxt = {};
-        if (i + 1u < K) {
-          const uint32_t next_item = g_cur * kTileItemsPerGroup + item_in_group(wave, i + 1u);
-          nit = load_item(f.tiles + (next_item < f.n_tiles ? next_item : 0u));
-          nxt.occ = (occ_cur >> (4u * (i + 1u))) & 0xFu;
-          if (kGeoResident) { nxt.g0 = gc0[1]; nxt.g1 = gc1[1]; }
-          else if (!(variant & 128u)) load_geometry<true>(f, nit, lane, nxt);
-          if (!(variant & 256u)) load_attributes(f, nit, lane, nxt);
-        }
-        if (kGeoResident) {                                 // rotate: static register indices in a rolled loop
-          gc0[0] = gc0[1]; gc0[1] = gc0[2]; gc0[2] = gc0[3];
+        // Prefetch the attribute samples of the wave's next item — after its last item of this group, of
+        // its first item of the NEXT group (counted above), so that no step begins with an exposed load.
+        // The loads are unconditional (at the very end of the frame they re-read the current item): one
+        // counter state on every path.  Nothing here depends on an outstanding vector load.
+        const bool within = i + 1u < K;
+        uint32_t next_item = within ? g_cur * kTileItemsPerGroup + item_in_group(wave, i + 1u)
+                                    : g_next * kTileItemsPerGroup + item_in_group(wave, 0);
+        if (!within && !have_next) next_item = g_cur * kTileItemsPerGroup + item_in_group(wave, i);
+        const Item nit = load_item(f.tiles + (next_item < f.n_tiles ? next_item : 0u));
+        Samples nxt;
+        nxt.occ = within ? (occ_cur >> (4u * (i + 1u))) & 0xFu : (have_next ? occ_next & 0xFu : cur.occ);
+        if (kGeoResident) {
+          nxt.g0 = within ? gc0[1] : gn0[0];
+          nxt.g1 = within ? gc1[1] : gn1[0];
+          gc0[0] = gc0[1]; gc0[1] = gc0[2]; gc0[2] = gc0[3];             // rotate: static register indices in a rolled loop
           gc1[0] = gc1[1]; gc1[1] = gc1[2]; gc1[2] = gc1[3];
+        } else if (!(variant & 128u)) {
+          load_geometry<true>(f, nit, lane, nxt);
         }
+        if (!(variant & 256u)) load_attributes(f, nit, lane, nxt);
+        else { nxt.y0 = nxt.y1 = Px4{0u, 0u}; nxt.u0 = nxt.v0 = nxt.u1 = nxt.v1 = 0u; }
 
         {
           const uint32_t dup = (dup_cur >> (4u * i)) & 0xFu;                 // from the count phase
           // Take delivery of the prefetched samples before this item's stores are issued: waited for
           // later, the in-order vmcnt would make that wait cover the stores as well.
-          emit_item(f, it, cur, dup, n, base, lane, slots, variant, [&]() {
-            asm volatile("" : "+v"(nxt.g0.lo), "+v"(nxt.g0.hi), "+v"(nxt.g1.lo), "+v"(nxt.g1.hi), "+v"(nxt.y0.lo),
-                         "+v"(nxt.y0.hi), "+v"(nxt.y1.lo), "+v"(nxt.y1.hi));
-            asm volatile("" : "+v"(nxt.u0), "+v"(nxt.v0), "+v"(nxt.u1), "+v"(nxt.v1));
-          });
+          emit_item(f, it, cur, dup, n, base, lane, slots, variant, [&]() { take_delivery(nxt); });
         }
         // the items between this one and the wave's next one (the other waves' when interleaved)
         for (uint32_t k = item_in_group(wave, i); k < item_in_group(wave, i + 1u) && k < kTileItemsPerGroup; ++k) base += s_tot[cb][k];
         it = nit;
         cur = nxt;
       }
+      a_first = cur;
       VPCC_STAMP(5)
+    } else if (have_next) {
+      // first step of the workgroup: nothing to emit yet; fetch the attributes of the first item just counted
+      const uint32_t next_item = g_next * kTileItemsPerGroup + item_in_group(wave, 0);
+      const Item nit = load_item(f.tiles + (next_item < f.n_tiles ? next_item : 0u));
+      a_first.occ = occ_next & 0xFu;
+      a_first.g0 = gn0[0]; a_first.g1 = gn1[0];
+      if (!(variant & 256u)) load_attributes(f, nit, lane, a_first);
+      take_delivery(a_first);                                // once per workgroup: keeps the item loop free of waits on `cur`
     }
     if (!have_next) break;
     g_cur = g_next;
@@ -862,6 +899,139 @@ void k_recon_tiles_resident(const DevFrame* __restrict__ frames, uint32_t first,
   }
 }
 
+
+// ---------------------------------------------------------------------------------------------------
+// Structure 4 ("wave-autonomous"): the pipeline of structure 3, but every WAVE draws its own tickets
+// (4 consecutive items), publishes its own look-back word and computes its own output offsets.  No workgroup
+// barrier, no count exchange through LDS: in the workgroup-level structures the four waves of a group wait
+// at two barriers per step for the slowest of them (stamps: 15 % of a wave's life between the ticket
+// barrier and its release).  A workgroup is only a container of four independent waves here.
+template <bool kStamps>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(VPCC_TILES_WAVES_PER_EU, VPCC_TILES_WAVES_PER_EU)))
+void k_recon_tiles_wave(const DevFrame* __restrict__ frames, uint32_t first, uint32_t count, uint32_t waves_per_frame,
+                        uint32_t gen, uint32_t variant_arg) {
+  const uint32_t variant = kDiagnostic ? variant_arg : 0u;
+  const uint32_t xcd = blockIdx.x & 7u, slot = blockIdx.x >> 3;
+  const uint32_t frame_groups = (count + 7u) / 8u;
+  const uint32_t fi = xcd + 8u * (slot % frame_groups);
+  if (fi >= count) return;
+  const DevFrame& f = frames[first + fi];
+
+  __shared__ __attribute__((aligned(16))) uint2 s_slots[4][kSlotsPerWave];
+  constexpr uint32_t K = 4;                                  // items per ticket
+  static_assert(K == kTileScanGranule, "one look-back word per ticket");
+  const uint32_t n_tickets = (f.n_tiles + K - 1u) / K;
+  const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = lane_id();
+  uint2* slots = s_slots[wave];
+
+  uint32_t t_cur = 0, occ_cur = 0, dup_cur = 0, total_cur = 0;
+  uint32_t cnt_cur[K] = {0, 0, 0, 0};
+  bool have_cur = false;
+  Px4 gn0[K] = {}, gn1[K] = {}, gc0[K] = {}, gc1[K] = {};
+  for (;;) {
+    // ---- 1. the wave's next ticket.  Every wave of the frame stops at its first ticket past the end, so
+    // n_tickets + waves_per_frame tickets are drawn per launch: the last re-arms the counter.
+    uint32_t t = 0;
+    if (lane == 0) {
+      t = __hip_atomic_fetch_add(glw(f.ticket), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if (t + 1u == n_tickets + waves_per_frame)
+        __hip_atomic_store(glw(f.ticket), 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    const uint32_t t_next = __builtin_amdgcn_readfirstlane(t);
+    const bool have_next = t_next < n_tickets;
+    uint64_t early = 0;
+    auto read_early = [&]() {                                  // see k_recon_tiles: any older state of a word is safe
+      if (have_cur && lane < t_cur)
+        early = __hip_atomic_load(gl(f.scan_state + (t_cur - 1u - lane)), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+    };
+
+    // ---- 2. count the next ticket's items and publish their total ------------------------------------
+    uint32_t occ_next = 0, dup_next = 0, total_next = 0;
+    uint32_t cnt_next[K] = {0, 0, 0, 0};
+    if (have_next) {
+      uint32_t idx4[K];
+      Item it4[K];
+      Samples s4[K];
+      uint32_t raw[K];
+#pragma unroll
+      for (uint32_t i = 0; i < K; ++i) {
+        idx4[i] = t_next * K + i;
+        it4[i] = load_item(f.tiles + (idx4[i] < f.n_tiles ? idx4[i] : 0u));
+      }
+#pragma unroll
+      for (uint32_t i = 0; i < K; ++i) raw[i] = load_occupancy_raw(f, it4[i], lane);
+#pragma unroll
+      for (uint32_t i = 0; i < K; ++i) {
+        s4[i].occ = idx4[i] < f.n_tiles ? occupancy_bits(f, raw[i]) : 0u;   // past the end: an empty copy of item 0
+        if (variant & 512u) { s4[i].g0 = Px4{lane, 0u}; s4[i].g1 = Px4{0u, lane}; }
+        else load_geometry<false>(f, it4[i], lane, s4[i]);
+      }
+      read_early();
+#pragma unroll
+      for (uint32_t i = 0; i < K; ++i) {
+        const uint32_t dup = classify(f, it4[i], s4[i]) & s4[i].occ;
+        gn0[i] = s4[i].g0; gn1[i] = s4[i].g1;
+        occ_next |= s4[i].occ << (4u * i);
+        dup_next |= dup << (4u * i);
+        cnt_next[i] = wave_sum(2u * (uint32_t)__builtin_popcount(s4[i].occ) - (uint32_t)__builtin_popcount(dup));
+        total_next += cnt_next[i];
+      }
+      if (lane == 0)
+        st_store(f.scan_state + t_next, ((uint64_t)gen << kGenShift) | (t_next == 0 ? kPrefix : kAggregate) | total_next);
+    } else {
+      read_early();
+    }
+
+    // ---- 3. look back for and emit the current ticket --------------------------------------------------
+    if (have_cur) {
+      uint32_t excl = (variant & 1u) ? t_cur * 1750u : 0u;
+      if (t_cur != 0 && !(variant & 1u)) excl = look_back_groups(f, t_cur, gen, early);
+      Item it = load_item(f.tiles + (t_cur * K < f.n_tiles ? t_cur * K : 0u));
+      Samples cur = {};
+      cur.occ = occ_cur & 0xFu;
+      cur.g0 = gc0[0]; cur.g1 = gc1[0];
+      if (!(variant & 256u)) load_attributes(f, it, lane, cur);
+      if (lane == 0) {
+        if (t_cur != 0 && !(variant & 1u))
+          st_store(f.scan_state + t_cur, ((uint64_t)gen << kGenShift) | kPrefix | (uint64_t)(excl + total_cur));
+        if (t_cur + 1u == n_tickets)                                       // tile.total_number_of_regular_points
+          *glw(f.n_points) = (variant & 1u) ? (excl + total_cur < f.capacity ? excl + total_cur : f.capacity) : excl + total_cur;
+      }
+      uint32_t base = excl;
+      for (uint32_t i = 0; i < K; ++i) {
+        const uint32_t n = cnt_cur[0];
+        Item nit = it;
+        Samples nxt = {};
+        if (i + 1u < K) {
+          const uint32_t next_item = t_cur * K + i + 1u;
+          nit = load_item(f.tiles + (next_item < f.n_tiles ? next_item : 0u));
+          nxt.occ = (occ_cur >> (4u * (i + 1u))) & 0xFu;
+          nxt.g0 = gc0[1]; nxt.g1 = gc1[1];
+          if (!(variant & 256u)) load_attributes(f, nit, lane, nxt);
+        }
+        gc0[0] = gc0[1]; gc0[1] = gc0[2]; gc0[2] = gc0[3];                   // rotate: static register indices
+        gc1[0] = gc1[1]; gc1[1] = gc1[2]; gc1[2] = gc1[3];
+        cnt_cur[0] = cnt_cur[1]; cnt_cur[1] = cnt_cur[2]; cnt_cur[2] = cnt_cur[3];
+        emit_item(f, it, cur, (dup_cur >> (4u * i)) & 0xFu, n, base, lane, slots, variant, [&]() {
+          asm volatile("" : "+v"(nxt.y0.lo), "+v"(nxt.y0.hi), "+v"(nxt.y1.lo), "+v"(nxt.y1.hi));
+          asm volatile("" : "+v"(nxt.u0), "+v"(nxt.v0), "+v"(nxt.u1), "+v"(nxt.v1));
+        });
+        base += n;
+        it = nit;
+        cur = nxt;
+      }
+    }
+    if (!have_next) break;
+    t_cur = t_next;
+    occ_cur = occ_next;
+    dup_cur = dup_next;
+    total_cur = total_next;
+#pragma unroll
+    for (uint32_t i = 0; i < K; ++i) { gc0[i] = gn0[i]; gc1[i] = gn1[i]; cnt_cur[i] = cnt_next[i]; }
+    have_cur = true;
+  }
+}
+
 }  // namespace vpcc
 
 #ifdef VPCC_DIAGNOSTIC
@@ -905,7 +1075,10 @@ void launch_tiles(const DevFrame* d_frames, uint32_t first, uint32_t count, uint
     return;
   }
 #endif
-#if VPCC_TILES_STRUCTURE == 2
+#if VPCC_TILES_STRUCTURE == 4
+  hipLaunchKernelGGL(k_recon_tiles_wave<false>, dim3(grid), dim3(256), 0, (hipStream_t)stream, d_frames, first, count,
+                     4u * wgs, gen, variant);
+#elif VPCC_TILES_STRUCTURE == 2
   hipLaunchKernelGGL(k_recon_tiles_resident<false>, dim3(grid), dim3(256), 0, (hipStream_t)stream, d_frames, first, count,
                      wgs, gen, variant);
 #else

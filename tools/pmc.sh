@@ -3,12 +3,12 @@
 # counter group (SQ: 8 slots, TCC: FETCH_SIZE 3 / WRITE_SIZE 2), kernel-trace only, as
 # MI355X_MICROARCH.md prescribes.  Usage: tools/pmc.sh <outdir> [bench args...]
 out=$1; shift
-mkdir -p "$out"
+mkdir -p "$out"; out=$(cd "$out" && pwd)
 cd /tmp && export TMPDIR=/tmp
 run() {
   name=$1; shift
   rocprofv3 --kernel-trace --pmc "$@" --output-format csv -d "$out/$name" -- \
-    python3 "$GRAFT_REPO_ROOT/bench.py" --steps 3 --warmup 1 --ramp-ms 0 --no-cpu-baseline --profile-steps 1 $BENCH_ARGS \
+    python3 "$GRAFT_REPO_ROOT/bench.py" --steps 3 --warmup 1 --ramp-ms 0 --no-cpu-baseline --no-verify --no-end-to-end --min-seconds 0 $BENCH_ARGS \
     > "$out/$name.log" 2>&1 || echo "pass $name failed"
 }
 run sq1 SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS

@@ -2,6 +2,7 @@
 """Diagnostic: per-phase cycle shares of the tile kernel (VPCC_TILES_VARIANT=64 build path).
 Shares only — the stamped run serialises loads and must not be used for timing."""
 import ctypes as C, os, sys
+os.environ["VPCC_DIAG_LIB"] = "1"          # libvpcc_recon_diag.so (`make diag`): stamps exist in the diagnostic build only
 os.environ["VPCC_TILES_VARIANT"] = os.environ.get("VPCC_TILES_VARIANT", "64")
 REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(REPO, "tmc2-rs_amd"))
@@ -23,5 +24,3 @@ tot = sum(buf[i] for i in range(10)) or 1
 for i, nm in enumerate(names):
     print(f"{nm:16s} {buf[i]/n:10.0f} cycles/wave  {100.0*buf[i]/tot:5.1f}%")
 print("waves sampled", n, " total cycles/wave", tot / n, "(s_memtime ticks; 100 MHz? see below)")
-
-print("look-backs", buf[10], "extra chunk steps", buf[11], "lane-spins", buf[12])
