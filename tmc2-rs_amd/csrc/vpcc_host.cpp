@@ -196,11 +196,18 @@ bool tile_planes_aligned(const DevFrame& d) {
   // the kernel addresses every plane with 32-bit byte offsets
   const uint64_t lim = 1ull << 32;
   if ((uint64_t)d.occ_h * d.occ_stride >= lim) return false;
+  // row offsets are formed with 24-bit multiplies
+  if (d.occ_stride >= (1u << 24) || d.height >= (1u << 24)) return false;
+  // the layers of one video share a row pitch: the kernel forms one offset per plane kind
+  if (d.map_count > 1 && (d.geo_stride[0] != d.geo_stride[1] ||
+                          (d.has_attr && (d.attr_stride[0] != d.attr_stride[1] || d.attr_cstride[0] != d.attr_cstride[1]))))
+    return false;
   for (uint32_t m = 0; m < d.map_count; ++m) {
     if ((uint64_t)d.height * d.geo_stride[m] * 2 >= lim) return false;
     if (d.has_attr && ((uint64_t)d.height * d.attr_stride[m] * 2 >= lim || (uint64_t)d.height * d.attr_cstride[m] >= lim))
       return false;
-    if (!al(d.geo[m], 8) || d.geo_stride[m] % 4) return false;
+    if (!al(d.geo[m], 8) || d.geo_stride[m] % 4 || d.geo_stride[m] >= (1u << 24)) return false;
+    if (d.has_attr && (d.attr_stride[m] >= (1u << 24) || d.attr_cstride[m] >= (1u << 24))) return false;
     if (d.has_attr) {
       if (!al(d.attr_y[m], 8) || d.attr_stride[m] % 4) return false;
       if (!al(d.attr_u[m], 4) || !al(d.attr_v[m], 4) || d.attr_cstride[m] % 2) return false;

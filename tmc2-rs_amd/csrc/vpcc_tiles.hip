@@ -219,24 +219,21 @@ __device__ __forceinline__ uint32_t occupancy_bits(const DevFrame& f, uint32_t r
 }
 
 // Plane loads are UNCONDITIONAL (no exec-masked region, so loads of several items stay in flight
-// together): a lane without an occupied pixel reads what the wave's first occupied lane reads — lines
-// the wave fetches anyway (HBM is read in whole 128-byte lines: a row nobody needs costs as much as a
-// needed one) — and an item without any occupancy reads the plane's first pixels, which stay cached.
-// Its samples are never used.
+// together): a lane without an occupied pixel reads the block's first pixels instead and its samples are
+// never used.  (Redirecting such lanes to the wave's first occupied lane, so that no unneeded 128-byte line
+// is ever touched, changed neither the traffic counters nor the time and costs ~7 instructions per call.)
 __device__ __forceinline__ void load_origin(const Item& it, uint32_t lane, uint32_t occ, uint32_t& px0, uint32_t& py0) {
-  const uint64_t any = __ballot(occ != 0);
-  const uint32_t src = any ? (uint32_t)__builtin_ctzll(any) : 0u;          // wave-uniform
-  const uint32_t l = occ ? lane : src;
-  px0 = any ? it.x0 + 4u * (l & 3u) : 0u;
-  py0 = any ? it.y0 + (l >> 2) : 0u;
+  px0 = occ ? it.x0 + 4u * (lane & 3u) : it.x0;
+  py0 = occ ? it.y0 + (lane >> 2) : it.y0;
 }
 template <bool kLastUse>
 __device__ __forceinline__ void load_geometry(const DevFrame& f, const Item& it, uint32_t lane, Samples& s) {
   constexpr bool kS = kLastUse && (VPCC_TILES_NT & 4);
   uint32_t px0, py0;
   load_origin(it, lane, s.occ, px0, py0);
-  s.g0 = load4_row<kS>(f.geo[0], (__umul24(py0, f.geo_stride[0]) + px0) * 2u);
-  s.g1 = load4_row<kS>(f.geo[1], (__umul24(py0, f.geo_stride[1]) + px0) * 2u);      // single map: an alias of layer 0
+  const uint32_t off = (__umul24(py0, f.geo_stride[0]) + px0) * 2u;                // both layers: one video, one row pitch
+  s.g0 = load4_row<kS>(f.geo[0], off);
+  s.g1 = load4_row<kS>(f.geo[1], off);                                             // single map: an alias of layer 0
 }
 
 // Attribute samples; chroma is nearest-neighbour (src/decoder.rs:977): pixels 0,1 of the lane use
@@ -244,15 +241,16 @@ __device__ __forceinline__ void load_geometry(const DevFrame& f, const Item& it,
 __device__ __forceinline__ void load_attributes(const DevFrame& f, const Item& it, uint32_t lane, Samples& s) {
   uint32_t px0, py0;
   load_origin(it, lane, s.occ, px0, py0);
+  // both layers come from one video: one row pitch (tile_planes_aligned), one offset per plane kind
   const uint32_t c0 = (__umul24(py0 >> 1, f.attr_cstride[0]) + (px0 >> 1)) * 2u;
-  const uint32_t c1 = (__umul24(py0 >> 1, f.attr_cstride[1]) + (px0 >> 1)) * 2u;
+  const uint32_t y0 = (__umul24(py0, f.attr_stride[0]) + px0) * 2u;
   constexpr bool kS = VPCC_TILES_NT & 2;
-  s.y0 = load4_row<kS>(f.attr_y[0], (__umul24(py0, f.attr_stride[0]) + px0) * 2u);   // absent planes alias present ones
+  s.y0 = load4_row<kS>(f.attr_y[0], y0);   // absent planes alias present ones
   s.u0 = load2<kS>(f.attr_u[0], c0);
   s.v0 = load2<kS>(f.attr_v[0], c0);
-  s.y1 = load4_row<kS>(f.attr_y[1], (__umul24(py0, f.attr_stride[1]) + px0) * 2u);
-  s.u1 = load2<kS>(f.attr_u[1], c1);
-  s.v1 = load2<kS>(f.attr_v[1], c1);
+  s.y1 = load4_row<kS>(f.attr_y[1], y0);
+  s.u1 = load2<kS>(f.attr_u[1], c0);
+  s.v1 = load2<kS>(f.attr_v[1], c0);
 }
 
 // Which D1 points duplicate their D0 point (src/codec.rs:422-427), one bit per pixel of the lane.
@@ -292,15 +290,33 @@ __device__ __forceinline__ uint32_t classify(const DevFrame& f, const Item& it, 
 // {x | y << 16, z} of a point as the reference builds it (src/decoder.rs:871-888): assignment order
 // normal, tangent, bitangent, `as u16` truncation.  The axes are wave-uniform per item, so the
 // assignment is two byte permutes with the item's selectors (vpcc_host.cpp).
-__device__ __forceinline__ uint2 pack_point(const Item& it, uint32_t depth, uint32_t du, uint32_t dv) {
+struct PointConsts {
+  uint32_t nmin;           // scalar: d1 in mode 1, 2^32-1 in mode 0
+  int32_t nsign;           // scalar: -1 in mode 1, +1 in mode 0
+  uint32_t lod_x, lod_y;   // scalar
+  uint32_t sel_xy, sel_z;  // scalar byte-permute selectors
+  uint32_t v_d1, v_tb, v_bb;   // vector copies of the addends
+};
+__device__ __forceinline__ PointConsts point_consts(const Item& it) {
+  PointConsts c;
+  c.nmin = (it.flags & kTileMode1) ? it.d1 : 0xFFFFFFFFu;
+  c.nsign = (it.flags & kTileMode1) ? -1 : 1;
+  c.lod_x = it.lod_x; c.lod_y = it.lod_y;
+  c.sel_xy = it.sel_xy; c.sel_z = it.sel_z;
+  c.v_d1 = it.d1; c.v_tb = it.tb; c.v_bb = it.bb;
+  c.nmin = __builtin_amdgcn_readfirstlane(c.nmin);            // opaque: one v_min_u32, not min + select on the mode
+  asm volatile("" : "+v"(c.v_d1), "+v"(c.v_tb), "+v"(c.v_bb));
+  return c;
+}
+// rx = depth | du << 16 | dv << 20 | ... (the low three bytes of a point record)
+__device__ __forceinline__ uint2 pack_point(const PointConsts& c, uint32_t rx) {
+  const uint32_t depth = rx & 0xFFFFu, du = __builtin_amdgcn_ubfe(rx, 16u, 4u), dv = __builtin_amdgcn_ubfe(rx, 20u, 4u);
   // normal coordinate: mode 0: depth + d1; mode 1: max(d1, depth) - depth = d1 - min(depth, d1)
-  const uint32_t nmin = (it.flags & kTileMode1) ? it.d1 : 0xFFFFFFFFu;
-  const int32_t nsign = (it.flags & kTileMode1) ? -1 : 1;
-  const uint32_t m = depth < nmin ? depth : nmin;                           // depth < 2^14
-  const uint32_t n = (uint32_t)((int32_t)m * nsign) + it.d1;
-  const uint32_t t = it.tb + __umul24(du, it.lod_x), b = it.bb + __umul24(dv, it.lod_y);
+  const uint32_t m = __builtin_elementwise_min(depth, c.nmin);               // depth < 2^14
+  const uint32_t n = (uint32_t)__mul24((int32_t)m, c.nsign) + c.v_d1;
+  const uint32_t t = __umul24(du, c.lod_x) + c.v_tb, b = __umul24(dv, c.lod_y) + c.v_bb;
   const uint32_t nt = __builtin_amdgcn_perm(t, n, 0x05040100u);             // n (low half) | t << 16
-  return make_uint2(__builtin_amdgcn_perm(b, nt, it.sel_xy), __builtin_amdgcn_perm(b, nt, it.sel_z));
+  return make_uint2(__builtin_amdgcn_perm(b, nt, c.sel_xy), __builtin_amdgcn_perm(b, nt, c.sel_z));
 }
 
 // D1 point in relative mode (src/codec.rs:551-559): point0 with +-d1 on coordinate index normal_axis.
@@ -432,7 +448,7 @@ __device__ __forceinline__ unsigned long long stamp() {
 #endif
 
 typedef uint32_t u32x3 __attribute__((ext_vector_type(3)));
-typedef u32x3 u32x3_a4 __attribute__((aligned(4)));
+typedef u32x3 u32x3_a2 __attribute__((aligned(2)));   // point pairs start at (base + k) * 6: 2-byte aligned only
 typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
 typedef uint32_t u32_a2 __attribute__((aligned(2)));
 typedef uint16_t u16_a2 __attribute__((aligned(2)));
@@ -452,7 +468,7 @@ __device__ __forceinline__ void store_xyz(VPCC_GLOBAL unsigned char* base, uint3
 __device__ __forceinline__ void store_xyz2(VPCC_GLOBAL unsigned char* base, uint32_t byte_off, uint2 p, uint2 q) {
   u32x3 o;
   o.x = p.x; o.y = (p.y & 0xFFFFu) | (q.x << 16); o.z = (q.x >> 16) | (q.y << 16);
-  out_store<u32x3_a4>(base + byte_off, o);               // one unaligned dwordx3
+  out_store<u32x3_a2>(base + byte_off, o);               // one unaligned dwordx3
 }
 __device__ __forceinline__ void store_rgb2(VPCC_GLOBAL unsigned char* base, uint32_t byte_off, uint32_t c0, uint32_t c1) {
   out_store<u32_a2>(base + byte_off, (c0 & 0xFFFFFFu) | (c1 << 24));
@@ -481,6 +497,10 @@ __device__ __forceinline__ void store_rgb(VPCC_GLOBAL unsigned char* base, uint3
 // 6 and more spill.
 #ifndef VPCC_TILES_WAVES_PER_EU
 #define VPCC_TILES_WAVES_PER_EU 4
+#endif
+// 1: the loop over a wave's four items of a group is unrolled (no register rotation, no cur = nxt copies)
+#ifndef VPCC_TILES_UNROLL_ITEMS
+#define VPCC_TILES_UNROLL_ITEMS 1
 #endif
 // 1: pipelined (count group g+1, then emit group g; geometry read twice)   2: resident (all of a group's
 // samples in registers, every plane byte read once)
@@ -534,33 +554,31 @@ __device__ __forceinline__ void emit_item(const DevFrame& f, const Item& it, con
 
   const uint32_t room = base < f.capacity ? f.capacity - base : 0u;   // never write past the caller's arrays
   const uint32_t nw = (variant & 16u) ? 0u : (n < room ? n : room);
+  // Per-item constants of the back-projection (src/decoder.rs:871-888).  The addends live in VGPRs (a VOP3
+  // takes one scalar operand: with two, the compiler re-materialises one as v_mov inside the loop), the
+  // mode-1 clamp is a plain unsigned min against d1 (mode 0: against 2^32-1).
+  const PointConsts pc = point_consts(it);
   // Two consecutive points per lane: one 16-B record read, one 12-B xyz store and one 6-B rgb store
-  // per lane and step (the CU issues a vector-memory instruction only every few cycles).
+  // per lane and step (the CU issues a vector-memory instruction only every few cycles).  An odd tail
+  // reads one record too many — whatever it holds becomes a point that is not stored.
   for (uint32_t k = 2u * lane; k < nw; k += 128u) {
     const uint4 rr = *reinterpret_cast<const uint4*>(slots + k);       // records k and k+1
     const bool two = k + 1u < nw;
-    uint2 p[2];
-    uint32_t rgb[2];
-#pragma unroll
-    for (int h = 0; h < 2; ++h) {
-      // an odd tail has no second record: reuse the first (a stale slot could hold anything)
-      const uint32_t rx = (h && two) ? rr.z : rr.x, ry = (h && two) ? rr.w : rr.y;
-      const uint32_t depth = rx & 0xFFFFu, du = (rx >> 16) & 15u, dv = (rx >> 20) & 15u;
-      p[h] = pack_point(it, depth, du, dv);
-      if (!f.absolute_d1 && (rx >> 24) != 0) {      // relative D1: the D0 record of this pixel precedes it
-        const uint32_t d0 = h ? (rr.x & 0xFFFFu) : (slots[k - 1u].x & 0xFFFFu);
-        p[h] = relative_point(it.axes & 3u, it.flags & kTileMode1, pack_point(it, d0, du, dv), depth);
-      }
-      rgb[h] = ry;
+    uint2 p0 = pack_point(pc, rr.x), p1 = pack_point(pc, rr.z);
+    if (!f.absolute_d1) {                                   // wave-uniform; relative D1: the D0 record of the pixel precedes it
+      if ((rr.x >> 24) != 0)
+        p0 = relative_point(it.axes & 3u, it.flags & kTileMode1, pack_point(pc, (slots[k - 1u].x & 0xFFFFu) | (rr.x & 0xFF0000u)), rr.x & 0xFFFFu);
+      if ((rr.z >> 24) != 0)
+        p1 = relative_point(it.axes & 3u, it.flags & kTileMode1, pack_point(pc, (rr.x & 0xFFFFu) | (rr.z & 0xFF0000u)), rr.z & 0xFFFFu);
     }
-    if ((variant & 32u) && p[0].x != 0xFFFFFFFEu) continue;           // ablation: all the arithmetic, no stores
+    if ((variant & 32u) && p0.x != 0xFFFFFFFEu) continue;               // ablation: all the arithmetic, no stores
     if (two) {
-      store_xyz2(gx, (base + k) * 6u, p[0], p[1]);
-      if (f.has_attr) store_rgb2(gc, (base + k) * 3u, rgb[0], rgb[1]);
+      store_xyz2(gx, (base + k) * 6u, p0, p1);
+      if (f.has_attr) store_rgb2(gc, (base + k) * 3u, rr.y, rr.w);
       if (gp) out_store<u32_a2>((VPCC_GLOBAL unsigned char*)gp + (base + k) * 2u, it.patch | (it.patch << 16));   // partition, codec.rs:452
     } else {
-      store_xyz(gx, (base + k) * 6u, p[0]);
-      if (f.has_attr) store_rgb(gc, (base + k) * 3u, rgb[0]);
+      store_xyz(gx, (base + k) * 6u, p0);
+      if (f.has_attr) store_rgb(gc, (base + k) * 3u, rr.y);
       if (gp) gp[base + k] = (uint16_t)it.patch;
     }
   }
@@ -725,6 +743,9 @@ void k_recon_tiles(const DevFrame* __restrict__ frames, uint32_t first,
       for (uint32_t k = 0; k < item_in_group(wave, 0); ++k) base += s_tot[cb][k];
 
       // ---- 4. per item: colours, compaction of the records through LDS, then lane <-> point ---------
+#if VPCC_TILES_UNROLL_ITEMS
+#pragma unroll
+#endif
       for (uint32_t i = 0; i < K; ++i) {
         const uint32_t n = s_tot[cb][item_in_group(wave, i)];
         // Prefetch the attribute samples of the wave's next item — after its last item of this group, of
@@ -739,10 +760,15 @@ void k_recon_tiles(const DevFrame* __restrict__ frames, uint32_t first,
         Samples nxt;
         nxt.occ = within ? (occ_cur >> (4u * (i + 1u))) & 0xFu : (have_next ? occ_next & 0xFu : cur.occ);
         if (kGeoResident) {
+#if VPCC_TILES_UNROLL_ITEMS
+          nxt.g0 = within ? gc0[(i + 1u) & 3u] : gn0[0];                  // unrolled: static indices
+          nxt.g1 = within ? gc1[(i + 1u) & 3u] : gn1[0];
+#else
           nxt.g0 = within ? gc0[1] : gn0[0];
           nxt.g1 = within ? gc1[1] : gn1[0];
           gc0[0] = gc0[1]; gc0[1] = gc0[2]; gc0[2] = gc0[3];             // rotate: static register indices in a rolled loop
           gc1[0] = gc1[1]; gc1[1] = gc1[2]; gc1[2] = gc1[3];
+#endif
         } else if (!(variant & 128u)) {
           load_geometry<true>(f, nit, lane, nxt);
         }
