@@ -13,9 +13,9 @@ no data-path collective); `value` is the whole-job Mpoints/s.
 
 The timed region is tmc2rs.sharding.timed_region (the function the world-size-2 gloo test runs): W warm-up
 steps, then K steps between barrier + synchronisation pairs; K is raised to `steps_effective` until the
-region lasts >= --min-seconds (a step is ~0.1 ms).  Every launch of the region carries a HIP-event pair
-on the launch stream (profile mode of the library), so `roofline.kernel_ms` is the mean duration of
-exactly the launches `ms_per_step` was measured on (the last <= 512 of them).
+region lasts >= --min-seconds (a step is ~0.1 ms).  Every 16th launch of the region carries a HIP-event pair
+on the launch stream (profile mode of the library; a pair on EVERY launch would add ~10 us of stream time per
+step), so `roofline.kernel_ms` is the mean duration of launches `ms_per_step` was measured on.
 
 One JSON line is printed by rank 0, with the contract fields plus
   roofline        : HBM roofline of the dominant kernel.  `achieved`/`frac` use the ALGORITHMIC bytes of
@@ -79,6 +79,8 @@ def parse():
     ap.add_argument("--no-verify", action="store_true", help="skip the oracle check of the timed GOF's output (tools/ only)")
     ap.add_argument("--no-end-to-end", action="store_true", help="skip the PCIe-inclusive Decoder run")
     ap.add_argument("--e2e-gofs", type=int, default=4, help="GOFs in the end-to-end container")
+    ap.add_argument("--profile-every", type=int, default=16,
+                    help="an event pair around every n-th launch of the timed region (each costs a few us of stream time)")
     ap.add_argument("--profile-steps", type=int, default=0, help=argparse.SUPPRESS)   # accepted for old tool scripts
     return ap.parse_args()
 
@@ -150,6 +152,7 @@ def main():
     smooth_kw = dict(grid_size=8, threshold=4, color_grid_size=8, color_threshold_smoothing=10,
                      color_threshold_difference=100)
     gof = ctx.gof(frames, capacity=cap, flags=flags)          # H2D happens here, outside the timed region
+    gof.profile_interval(args.profile_every)
 
     def step():
         gof.reconstruct()
@@ -189,7 +192,8 @@ def main():
     steps_eff = reg["steps_effective"]
     elapsed = reg["elapsed_s"]
     region_ms_per_step = ev[0].elapsed_time(ev[1]) / steps_eff
-    kernels, launches_averaged = gof.kernel_time_means(min(steps_eff, 512))   # the same launches
+    # the timed region's own launches: every --profile-every-th of them carries an event pair
+    kernels, launches_averaged = gof.kernel_time_means(min(max(steps_eff // args.profile_every, 1), 512))
 
     # ---- the timed GOF's output against the CPU oracle (checker only) -----------------------------
     verified, ok = [], 1

@@ -208,7 +208,12 @@ void vpcc_gof_destroy(vpcc_gof* gof);
 
 /* Enqueues the reconstruction of frames [first, first+count) on `hip_stream`
  * (a hipStream_t passed as void*; NULL = the context's own stream).  Returns
- * immediately; results are valid after vpcc_gof_sync() or a stream sync. */
+ * immediately; results are valid after vpcc_gof_sync() or a stream sync.
+ * Launches on one gof are serialised by the library (a launch on a different stream first waits for the
+ * previous launch's kernels): they share the gof's output arrays and control words.  A device-side error
+ * (VPCC_ERR_DEVICE from the counts/download calls: a look-back wait that gave up) is sticky for the gof.
+ * Every vpcc_* call that touches the GPU makes the context's device the calling thread's current HIP
+ * device and leaves it so (vpcc_host_free does not). */
 int vpcc_gof_reconstruct(vpcc_gof* gof, uint32_t first, uint32_t count, void* hip_stream);
 int vpcc_gof_sync(vpcc_gof* gof);
 
@@ -238,6 +243,10 @@ int vpcc_gof_kernel_times(vpcc_gof* gof, const char** names_out, float* ms_out, 
  * `last_n` launches (0 = all kept); *launches_out = launches averaged.  Lets a caller time a long
  * back-to-back region and read the per-launch kernel durations of exactly those launches.
  * Returns the number of distinct kernels (<= max). */
+/* Profile mode: time only every `every`-th vpcc_gof_reconstruct (default 1 = all).  An event pair costs a few
+ * microseconds of stream time per launch; sampling keeps a back-to-back timed region undisturbed while its
+ * own launches are still the ones measured. */
+int vpcc_gof_profile_interval(vpcc_gof* gof, uint32_t every);
 int vpcc_gof_kernel_time_means(vpcc_gof* gof, uint32_t last_n, const char** names_out, float* mean_ms_out,
                                uint32_t* launches_out, int max);
 

@@ -8,166 +8,13 @@
 #include <cstdlib>
 #include <cstring>
 #include <fstream>
+#include <functional>
+#include <future>
 #include <memory>
 #include <sstream>
 #include <stdexcept>
 
 namespace tmc2rs {
-
-// ------------------------------------------------------------------ container (.vpccgof)
-//   header : "VPCCGOF1" | u32 version (1) | u32 gof_count
-//   gof    : u32 frame_count | frame*
-//   frame  : 16 x u32 { width, height, occupancy_resolution, occupancy_precision, map_count, absolute_d1,
-//                       attribute_count, flags, occ_w, occ_h, geo_w, geo_h, attr_w, attr_h, patch_count, 0 }
-//            vpcc_patch[patch_count] | occupancy u8[occ_w*occ_h] | geometry Y u16[geo_w*geo_h] x map_count
-//            | (Y u16[attr_w*attr_h], U, V u16[(attr_w/2)*((attr_h+1)/2)]) x map_count   (if attribute_count)
-//   every section is padded to a multiple of 8 bytes.
-namespace {
-struct Cursor {
-  const unsigned char* p;
-  size_t left;
-  bool take(size_t n, const unsigned char** out) {
-    const size_t padded = (n + 7) & ~size_t(7);
-    if (padded > left) return false;
-    *out = p;
-    p += padded;
-    left -= padded;
-    return true;
-  }
-};
-}  // namespace
-
-bool parse_container(const std::vector<unsigned char>& buf, std::vector<DecodedGof>* gofs, std::string* err) {
-  Cursor c{buf.data(), buf.size()};
-  const unsigned char* h;
-  if (!c.take(16, &h) || std::memcmp(h, "VPCCGOF1", 8) != 0) { *err = "not a .vpccgof container"; return false; }
-  uint32_t version, gof_count;
-  std::memcpy(&version, h + 8, 4);
-  std::memcpy(&gof_count, h + 12, 4);
-  if (version != 1) { *err = "unsupported container version"; return false; }
-  gofs->clear();
-  for (uint32_t g = 0; g < gof_count; ++g) {
-    const unsigned char* q;
-    if (!c.take(8, &q)) { *err = "truncated container"; return false; }
-    uint32_t frame_count;
-    std::memcpy(&frame_count, q, 4);
-    DecodedGof gof;
-    for (uint32_t f = 0; f < frame_count; ++f) {
-      if (!c.take(64, &q)) { *err = "truncated container"; return false; }
-      uint32_t w[16];
-      std::memcpy(w, q, 64);
-      vpcc_frame_desc d{};
-      d.width = w[0]; d.height = w[1]; d.occupancy_resolution = w[2]; d.occupancy_precision = w[3];
-      d.map_count = w[4]; d.absolute_d1 = w[5]; d.attribute_count = w[6]; d.flags = w[7];
-      const uint32_t occ_w = w[8], occ_h = w[9], geo_w = w[10], geo_h = w[11], attr_w = w[12], attr_h = w[13];
-      d.patch_count = w[14];
-      if (d.map_count < 1 || d.map_count > 2) { *err = "map_count out of range"; return false; }
-      if (!c.take(sizeof(vpcc_patch) * (size_t)d.patch_count, &q)) { *err = "truncated container"; return false; }
-      d.patches = d.patch_count ? reinterpret_cast<const vpcc_patch*>(q) : nullptr;
-      if (!c.take((size_t)occ_w * occ_h, &q)) { *err = "truncated container"; return false; }
-      d.occupancy = vpcc_image_u8{q, occ_w, occ_h, occ_w};
-      for (uint32_t m = 0; m < d.map_count; ++m) {
-        if (!c.take((size_t)geo_w * geo_h * 2, &q)) { *err = "truncated container"; return false; }
-        d.geometry[m] = vpcc_image_u16{reinterpret_cast<const uint16_t*>(q), nullptr, nullptr, geo_w, geo_h, geo_w, geo_w / 2};
-      }
-      if (d.attribute_count) {
-        const size_t cw = attr_w / 2, ch = (attr_h + 1) / 2;
-        for (uint32_t m = 0; m < d.map_count; ++m) {
-          const unsigned char *y, *u, *v;
-          if (!c.take((size_t)attr_w * attr_h * 2, &y) || !c.take(cw * ch * 2, &u) || !c.take(cw * ch * 2, &v)) {
-            *err = "truncated container";
-            return false;
-          }
-          d.attribute[m] = vpcc_image_u16{reinterpret_cast<const uint16_t*>(y), reinterpret_cast<const uint16_t*>(u),
-                                          reinterpret_cast<const uint16_t*>(v), attr_w, attr_h, attr_w, (uint32_t)cw};
-        }
-      }
-      gof.frames.push_back(d);
-    }
-    gofs->push_back(std::move(gof));
-  }
-  return true;
-}
-
-// ------------------------------------------------------------------ V3C sample stream + raw decoded video
-// The per-GOF driver of the reference (src/decoder.rs:82-314) with the three decompress() calls replaced by
-// raw planar files: frame f of a GOF uses occupancy frame f and geometry / attribute frames f*map_count + m
-// (src/codec.rs:317, 589-590).
-bool parse_v3c_with_raw_video(const std::vector<unsigned char>& bin, const unsigned char* occ, size_t occ_bytes,
-                              const unsigned char* geo, size_t geo_bytes, const unsigned char* attr, size_t attr_bytes,
-                              uint32_t occupancy_precision, std::vector<DecodedGof>* gofs, std::string* err, int* status) {
-  *status = VPCC_ERR_INVALID_ARG;
-  gofs->clear();
-  if (occupancy_precision == 0) { *err = "occupancy_precision is zero"; return false; }
-  std::vector<V3CUnit> units;
-  try {
-    Bitstream bs(std::vector<uint8_t>(bin.begin(), bin.end()));
-    size_t header = 0;
-    units = split_sample_stream(bs, &header);
-  } catch (const std::exception& e) {
-    *err = std::string("not a V3C sample stream: ") + e.what();
-    return false;
-  }
-  size_t next = 0, occ_off = 0, geo_off = 0, attr_off = 0;
-  while (next < units.size()) {                       // while ssvu.get_v3c_unit_count() > 0, src/lib.rs:118
-    GofSyntax syn;
-    std::vector<PatchFrame> frames;
-    GofParams gp;
-    try {
-      next = parse_gof(units, next, &syn);
-      gp = build_gof_params(syn);
-      frames = build_patch_frames(syn);
-    } catch (const SyntaxError& e) {
-      *err = e.what();
-      *status = e.status;
-      return false;
-    }
-    const uint32_t W = gp.frame_width, H = gp.frame_height;
-    if (W == 0 || H == 0 || W % occupancy_precision || H % occupancy_precision || (W & 1) || (H & 1)) {
-      *err = "frame size not divisible by the occupancy precision / not even";
-      return false;
-    }
-    if (gp.map_count > 2) { *err = "more than two maps"; *status = VPCC_ERR_UNSUPPORTED; return false; }
-    const uint32_t ow = W / occupancy_precision, oh = H / occupancy_precision;
-    const size_t occ_frame = (size_t)ow * oh + 2 * (size_t)((ow + 1) / 2) * ((oh + 1) / 2);
-    const size_t luma = (size_t)W * H * 2, chroma = (size_t)(W / 2) * (H / 2) * 2;
-    const size_t vid_frame = luma + 2 * chroma;
-    const bool has_attr = !syn.vps.ai.attributes.empty();
-    DecodedGof gof;
-    gof.patch_store.reserve(frames.size());
-    for (size_t f = 0; f < frames.size(); ++f) {
-      vpcc_frame_desc d{};
-      d.width = W; d.height = H;
-      d.occupancy_resolution = gp.occupancy_resolution;
-      d.occupancy_precision = occupancy_precision;
-      d.map_count = gp.map_count;
-      d.absolute_d1 = gp.absolute_d1 ? 1u : 0u;
-      d.attribute_count = has_attr ? 1u : 0u;
-      gof.patch_store.push_back(std::move(frames[f].patches));
-      d.patch_count = (uint32_t)gof.patch_store.back().size();
-      d.patches = d.patch_count ? gof.patch_store.back().data() : nullptr;
-      if (occ_off + occ_frame > occ_bytes) { *err = "occupancy video shorter than the atlas"; *status = VPCC_ERR_SHORT_VIDEO; return false; }
-      d.occupancy = vpcc_image_u8{occ + occ_off, ow, oh, ow};
-      occ_off += occ_frame;
-      for (uint32_t m = 0; m < gp.map_count; ++m) {
-        if (geo_off + vid_frame > geo_bytes) { *err = "geometry video shorter than the atlas"; *status = VPCC_ERR_SHORT_VIDEO; return false; }
-        d.geometry[m] = vpcc_image_u16{reinterpret_cast<const uint16_t*>(geo + geo_off), nullptr, nullptr, W, H, W, W / 2};
-        geo_off += vid_frame;
-        if (has_attr) {
-          if (attr_off + vid_frame > attr_bytes) { *err = "attribute video shorter than the atlas"; *status = VPCC_ERR_SHORT_VIDEO; return false; }
-          const unsigned char* a = attr + attr_off;
-          d.attribute[m] = vpcc_image_u16{reinterpret_cast<const uint16_t*>(a), reinterpret_cast<const uint16_t*>(a + luma),
-                                          reinterpret_cast<const uint16_t*>(a + luma + chroma), W, H, W, W / 2};
-          attr_off += vid_frame;
-        }
-      }
-      gof.frames.push_back(d);
-    }
-    gofs->push_back(std::move(gof));
-  }
-  *status = VPCC_OK;
-  return true;
-}
 
 // ------------------------------------------------------------------ PinnedPool
 PinnedPool::~PinnedPool() { detach(); }
@@ -194,7 +41,7 @@ PinnedBlock PinnedPool::get(size_t bytes) {
 
 void PinnedPool::put(void* ptr, size_t bytes) {
   std::lock_guard<std::mutex> lk(m_);
-  if (ctx_ && free_.size() < 8) free_.emplace_back(ptr, bytes);
+  if (ctx_ && free_.size() < 64) free_.emplace_back(ptr, bytes);
   else vpcc_host_free(ctx_, ptr);             // also after the context is gone (frames may outlive the decoder)
 }
 
@@ -252,129 +99,244 @@ std::optional<PointSet3> Decoder::recv_frame() { return chan_.recv(); }
 
 namespace {
 struct CtxDeleter { void operator()(vpcc_ctx* c) const { vpcc_ctx_destroy(c); } };
-struct GofDeleter { void operator()(vpcc_gof* g) const { vpcc_gof_destroy(g); } };
+
+// One lane per GPU: a thread that owns the device's vpcc_ctx and runs every call on it, in FIFO order.  A
+// vpcc_ctx is a single-thread object (include/vpcc_recon.h), and with one lane per device the host work of
+// a GOF — frame planning, vpcc_gof_create with its H2D enqueues, the result downloads — runs in parallel
+// across the devices instead of on one thread that would bound an 8-GPU node.
+class Lane {
+ public:
+  explicit Lane(int device) : device_(device), th_([this] { run(); }) {}
+  ~Lane() {
+    {
+      std::lock_guard<std::mutex> lk(m_);
+      stop_ = true;
+    }
+    cv_.notify_all();
+    th_.join();
+  }
+  std::future<int> post(std::function<int(vpcc_ctx*)> f) {
+    std::packaged_task<int(vpcc_ctx*)> t(std::move(f));
+    std::future<int> r = t.get_future();
+    {
+      std::lock_guard<std::mutex> lk(m_);
+      q_.push_back(std::move(t));
+    }
+    cv_.notify_all();
+    return r;
+  }
+
+ private:
+  void run() {
+    vpcc_ctx* c = nullptr;
+    create_status_ = vpcc_ctx_create(device_, &c);
+    ctx_.reset(c);
+    for (;;) {
+      std::packaged_task<int(vpcc_ctx*)> t;
+      {
+        std::unique_lock<std::mutex> lk(m_);
+        cv_.wait(lk, [&] { return stop_ || !q_.empty(); });
+        if (q_.empty()) break;                       // stop requested and everything posted has run
+        t = std::move(q_.front());
+        q_.pop_front();
+      }
+      t(ctx_.get());                                 // tasks see a null context when its creation failed
+    }
+    ctx_.reset();                                    // destroyed on the thread that used it
+  }
+  int device_;
+  std::mutex m_;
+  std::condition_variable cv_;
+  std::deque<std::packaged_task<int(vpcc_ctx*)>> q_;
+  bool stop_ = false;
+  std::unique_ptr<vpcc_ctx, CtxDeleter> ctx_;
+  int create_status_ = 0;
+  std::thread th_;                                   // last member: starts when everything above exists
+};
 }  // namespace
 
 void Decoder::worker() {
-  // one context per GPU; frames of a GOF are dealt round-robin (frame f -> device f % G) and delivered in
-  // presentation order — they are independent (src/decoder.rs:186), so no data moves between GPUs.
-  // Plane ingest: the container buffer is page-locked once, so every plane upload is an asynchronous
-  // DMA on the context's copy stream, and GOF k+1 is uploaded while GOF k is reconstructed and drained.
+  // One lane (thread + context) per GPU; frames of a GOF are dealt round-robin (frame f -> device f % G) and
+  // delivered in presentation order — they are independent (src/decoder.rs:186), so no data moves between
+  // GPUs.  Plane ingest: the container buffer is page-locked once (portable: every device DMAs from it), so
+  // every plane upload is an asynchronous DMA on its context's copy stream, and GOF k+1, k+2 are uploaded
+  // while GOF k is reconstructed and drained.
   const size_t G = params_.devices.empty() ? 1 : params_.devices.size();
-  std::vector<std::unique_ptr<vpcc_ctx, CtxDeleter>> ctxs(G);
-  for (size_t d = 0; d < G; ++d) {
-    vpcc_ctx* c = nullptr;
-    const int st = vpcc_ctx_create(params_.devices.empty() ? 0 : params_.devices[d], &c);
-    if (st) { error_ = std::string("vpcc_ctx_create: ") + vpcc_status_string(st); chan_.close_tx(); return; }
-    ctxs[d].reset(c);
-  }
-  auto pool = std::make_shared<PinnedPool>(ctxs[0].get());
+  std::vector<std::unique_ptr<Lane>> lanes;
+  for (size_t d = 0; d < G; ++d) lanes.push_back(std::make_unique<Lane>(params_.devices.empty() ? 0 : params_.devices[d]));
+  auto fail = [&](const std::string& why) { error_ = why; chan_.close_tx(); };
+  for (size_t d = 0; d < G; ++d)
+    if (lanes[d]->post([](vpcc_ctx* c) { return c ? 0 : 1; }).get()) { fail("vpcc_ctx_create failed: no usable gfx950 device (no CPU fallback)"); return; }
+
+  // the pool's blocks and the input registration are portable; they are made on lane 0's context
+  std::shared_ptr<PinnedPool> pool;
+  lanes[0]->post([&](vpcc_ctx* c) { pool = std::make_shared<PinnedPool>(c); return 0; }).get();
   struct Detach {
     std::shared_ptr<PinnedPool> p;
     ~Detach() { p->detach(); }              // frames the consumer still holds outlive the context safely
   } detach{pool};
-  const bool pinned = !file_.empty() && vpcc_host_pin(ctxs[0].get(), file_.data(), file_.size()) == VPCC_OK;
+  bool pinned = false;
+  if (!file_.empty())
+    pinned = lanes[0]->post([&](vpcc_ctx* c) { return vpcc_host_pin(c, file_.data(), file_.size()); }).get() == VPCC_OK;
   struct Unpin {
-    vpcc_ctx* c; const void* p; bool on;
-    ~Unpin() { if (on) vpcc_host_unpin(c, p); }
-  } unpin{ctxs[0].get(), file_.data(), pinned};
+    Lane* l; const void* p; bool on;
+    ~Unpin() { if (on) l->post([this](vpcc_ctx* c) { return vpcc_host_unpin(c, p); }).get(); }
+  } unpin{lanes[0].get(), file_.data(), pinned};
 
-  struct InFlight {                                   // one GOF, sharded over the devices
-    std::vector<std::vector<vpcc_frame_desc>> part;
-    std::vector<std::unique_ptr<vpcc_gof, GofDeleter>> dg;
-    bool ok = false;
+  struct Part {                                       // one device's share of one GOF
+    std::vector<vpcc_frame_desc> frames;
+    vpcc_gof* g = nullptr;
+    std::string err;
+    std::future<int> launched;
+    double launch_seconds = 0;
   };
-  auto launch = [&](const DecodedGof& gof, InFlight* f) -> bool {
-    f->part.assign(G, {});
-    f->dg.clear();
-    f->dg.resize(G);
-    for (size_t i = 0; i < gof.frames.size(); ++i) f->part[i % G].push_back(gof.frames[i]);
-    for (size_t d = 0; d < G; ++d) {
-      if (f->part[d].empty()) continue;
-      vpcc_gof* g = nullptr;
-      int st = vpcc_gof_create(ctxs[d].get(), f->part[d].data(), (uint32_t)f->part[d].size(), VPCC_MEM_HOST, 0,
-                               pinned ? VPCC_GOF_ASYNC_UPLOAD : 0u, &g);
-      if (st == VPCC_OK) {
-        f->dg[d].reset(g);
-        st = vpcc_gof_reconstruct(g, 0, (uint32_t)f->part[d].size(), nullptr);   // asynchronous: all GPUs run concurrently
-      }
-      if (st) {
-        error_ = std::string(vpcc_status_string(st)) + ": " + vpcc_last_error(ctxs[d].get());
-        return false;                                 // reference: panic in the worker -> consumer sees end-of-stream
-      }
-    }
-    f->ok = true;
-    return true;
-  };
-
-  // VPCC_DECODER_TRACE=1: where the worker's wall time goes (stderr, one line at the end of the stream)
-  const bool trace = std::getenv("VPCC_DECODER_TRACE") != nullptr;
-  double t_launch = 0, t_counts = 0, t_download = 0, t_send = 0;
+  struct InFlight { std::vector<Part> part; };
   auto now = [] { return std::chrono::steady_clock::now(); };
   auto secs = [](std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point b) {
     return std::chrono::duration<double>(b - a).count();
   };
-  struct Report {
-    const bool on; const double &a, &b, &c, &d;
-    ~Report() {
-      if (on) std::fprintf(stderr, "[vpcc decoder] launch(plan+enqueue) %.3f s, wait-for-counts %.3f s, download %.3f s, send %.3f s\n", a, b, c, d);
-    }
-  } report{trace, t_launch, t_counts, t_download, t_send};
-  // Two GOFs are kept queued behind the one being drained: the copy engine then always has the next
-  // upload waiting (with one GOF of look-ahead it idled while the worker downloaded the current GOF:
-  // 20 ms per 32-frame GOF instead of the 13.5 ms the 0.58 GB upload takes).
-  constexpr size_t kAhead = 2;
-  std::deque<InFlight> inflight;
-  size_t launched = 0, failed_at = gofs_.size();       // first GOF whose launch failed (none: past the end)
-  auto launch_more = [&](size_t upto) {
-    while (launched < gofs_.size() && launched <= upto && failed_at == gofs_.size()) {
-      inflight.emplace_back();
-      const auto t0 = now();
-      if (!launch(gofs_[launched], &inflight.back())) {
-        failed_at = launched;
-        inflight.pop_back();
-      } else {
-        ++launched;
-      }
-      t_launch += secs(t0, now());
+  // posts the planning + upload + launch of GOF `gof` to every lane; returns at once
+  auto launch = [&](const DecodedGof& gof, InFlight* f) {
+    f->part.clear();
+    f->part.resize(G);
+    for (size_t i = 0; i < gof.frames.size(); ++i) f->part[i % G].frames.push_back(gof.frames[i]);
+    for (size_t d = 0; d < G; ++d) {
+      Part* p = &f->part[d];
+      if (p->frames.empty()) continue;
+      p->launched = lanes[d]->post([p, pinned, now, secs](vpcc_ctx* c) {
+        const auto t0 = now();
+        int st = vpcc_gof_create(c, p->frames.data(), (uint32_t)p->frames.size(), VPCC_MEM_HOST, 0,
+                                 pinned ? VPCC_GOF_ASYNC_UPLOAD : 0u, &p->g);
+        if (st == VPCC_OK) st = vpcc_gof_reconstruct(p->g, 0, (uint32_t)p->frames.size(), nullptr);   // asynchronous
+        if (st) p->err = std::string(vpcc_status_string(st)) + ": " + vpcc_last_error(c);
+        p->launch_seconds = secs(t0, now());
+        return st;
+      });
     }
   };
+  auto destroy = [&](InFlight* f) {                   // on the lanes, behind whatever they still have queued for it
+    for (size_t d = 0; d < G; ++d)
+      if (f->part[d].launched.valid() || f->part[d].g) {
+        Part* p = &f->part[d];
+        if (p->launched.valid()) p->launched.wait();
+        lanes[d]->post([p](vpcc_ctx*) { vpcc_gof_destroy(p->g); p->g = nullptr; return 0; }).get();
+      }
+  };
+
+  // VPCC_DECODER_TRACE=1: where the wall time goes (stderr, one line at the end of the stream).  `launch` is
+  // the longest lane's planning + enqueue time per GOF, summed over GOFs: it must not grow with G.
+  const bool trace = std::getenv("VPCC_DECODER_TRACE") != nullptr;
+  double t_launch = 0, t_counts = 0, t_download = 0, t_send = 0;
+  struct Report {
+    const bool on; const size_t G; const double &a, &b, &c, &d;
+    ~Report() {
+      if (on) std::fprintf(stderr, "[vpcc decoder] %zu device(s): launch(plan+enqueue, slowest lane) %.3f s, wait-for-counts %.3f s, "
+                           "wait-for-downloads %.3f s, send %.3f s\n", G, a, b, c, d);
+    }
+  } report{trace, G, t_launch, t_counts, t_download, t_send};
+  // Two GOFs are kept queued behind the one being drained: the copy engines then always have the next
+  // upload waiting (with one GOF of look-ahead they idled while the current GOF was downloaded).
+  constexpr size_t kAhead = 2;
+  std::deque<InFlight> inflight;
+  struct Cleanup {                                    // early returns: nothing may outlive the lanes
+    std::deque<InFlight>& q; decltype(destroy)& destroy_fn;
+    ~Cleanup() { for (auto& f : q) destroy_fn(&f); }
+  } cleanup{inflight, destroy};
+  size_t launched = 0;
   for (size_t k = 0; k < gofs_.size(); ++k) {         // while ssvu.get_v3c_unit_count() > 0, src/lib.rs:118
-    launch_more(k + kAhead);                          // their ingest overlaps this GOF's work
-    if (k >= failed_at) break;                        // the stream ends where the failing GOF would have started
+    while (launched < gofs_.size() && launched <= k + kAhead) {   // their ingest overlaps this GOF's work
+      inflight.emplace_back();
+      launch(gofs_[launched], &inflight.back());
+      ++launched;
+    }
     const DecodedGof& gof = gofs_[k];
     InFlight& cur = inflight.front();
     const size_t n = gof.frames.size();
-    std::vector<std::vector<uint32_t>> counts(G);
+    double slowest = 0;
     for (size_t d = 0; d < G; ++d) {
-      if (!cur.dg[d]) continue;
-      counts[d].resize(cur.part[d].size());
-      const auto t0 = now();
-      const int st = vpcc_gof_point_counts(cur.dg[d].get(), counts[d].data());
-      t_counts += secs(t0, now());
-      if (st) { error_ = vpcc_last_error(ctxs[d].get()); chan_.close_tx(); return; }
+      if (!cur.part[d].launched.valid()) continue;
+      const int st = cur.part[d].launched.get();
+      slowest = std::max(slowest, cur.part[d].launch_seconds);
+      // reference: a panic in the worker -> the consumer sees end-of-stream where this GOF would have started
+      if (st) { fail(cur.part[d].err); return; }
     }
-    for (size_t f = 0; f < n; ++f) {                  // presentation order, src/decoder.rs:188
-      const size_t d = f % G, local = f / G;
-      PointSet3 ps;
-      ps.with_colors = gof.frames[f].attribute_count > 0;
-      const size_t np = counts[d][local];
-      PinnedBlock bx = pool->get(np * sizeof(vpcc_point3)), bc;
-      if (ps.with_colors) bc = pool->get(np * sizeof(vpcc_color3));
-      if (!bx.ptr || (ps.with_colors && !bc.ptr)) { error_ = "out of page-locked memory"; chan_.close_tx(); return; }
-      ps.positions.adopt(std::move(bx), np);
-      if (ps.with_colors) ps.colors.adopt(std::move(bc), np);
-      size_t got = 0;
+    t_launch += slowest;
+    std::vector<std::vector<uint32_t>> counts(G);
+    {
       const auto t0 = now();
-      const int st = vpcc_gof_download(cur.dg[d].get(), (uint32_t)local, ps.positions.data(),
-                                       ps.with_colors ? ps.colors.data() : nullptr, nullptr, np ? np : 1, &got);
+      std::vector<std::future<int>> fc(G);
+      std::vector<std::string> errs(G);
+      for (size_t d = 0; d < G; ++d) {
+        if (!cur.part[d].g) continue;
+        counts[d].resize(cur.part[d].frames.size());
+        Part* p = &cur.part[d];
+        uint32_t* out = counts[d].data();
+        std::string* e = &errs[d];
+        fc[d] = lanes[d]->post([p, out, e](vpcc_ctx* c) {
+          const int st = vpcc_gof_point_counts(p->g, out);
+          if (st) *e = vpcc_last_error(c);
+          return st;
+        });
+      }
+      for (size_t d = 0; d < G; ++d)
+        if (fc[d].valid() && fc[d].get()) { fail(errs[d]); return; }
+      t_counts += secs(t0, now());
+    }
+    // Downloads are posted a window of frames ahead of the hand-over — every lane works through its own
+    // frames while earlier ones are delivered in presentation order (src/decoder.rs:188) — but not the whole
+    // GOF at once: the page-locked result blocks come from a small pool and are recycled as the consumer
+    // drops frames (allocating and freeing pinned memory costs milliseconds).
+    const size_t window = std::max<size_t>(8, 4 * G);
+    std::vector<PointSet3> sets(n);
+    std::vector<std::future<int>> done(n);
+    std::vector<std::string> derr(n);
+    size_t posted = 0;
+    auto post_downloads = [&](size_t upto) -> bool {
+      for (; posted < n && posted < upto; ++posted) {
+        const size_t f = posted, d = f % G, local = f / G;
+        PointSet3& ps = sets[f];
+        ps.with_colors = gof.frames[f].attribute_count > 0;
+        const size_t np = counts[d][local];
+        PinnedBlock bx = pool->get(np * sizeof(vpcc_point3)), bc;
+        if (ps.with_colors) bc = pool->get(np * sizeof(vpcc_color3));
+        if (!bx.ptr || (ps.with_colors && !bc.ptr)) return false;
+        ps.positions.adopt(std::move(bx), np);
+        if (ps.with_colors) ps.colors.adopt(std::move(bc), np);
+        Part* p = &cur.part[d];
+        vpcc_point3* px = ps.positions.data();
+        vpcc_color3* pc = ps.with_colors ? ps.colors.data() : nullptr;
+        std::string* e = &derr[f];
+        done[f] = lanes[d]->post([p, local, px, pc, np, e](vpcc_ctx* c) {
+          size_t got = 0;
+          const int st = vpcc_gof_download(p->g, (uint32_t)local, px, pc, nullptr, np ? np : 1, &got);
+          if (st || got != np) { *e = st ? vpcc_last_error(c) : "point count changed between calls"; return st ? st : (int)VPCC_ERR_DEVICE; }
+          return 0;
+        });
+      }
+      return true;
+    };
+    auto settle = [&](size_t from) {                       // downloads in flight write into `sets`
+      for (size_t q = from; q < posted; ++q) done[q].wait();
+    };
+    for (size_t f = 0; f < n; ++f) {
+      if (!post_downloads(f + window)) { settle(f); fail("out of page-locked memory"); return; }
+      const auto t0 = now();
+      const int st = done[f].get();
       const auto t1 = now();
       t_download += secs(t0, t1);
-      if (st || got != np) { error_ = vpcc_last_error(ctxs[d].get()); chan_.close_tx(); return; }
-      const bool sent = chan_.send(std::move(ps));
-      t_send += secs(t1, now());
-      if (!sent) { chan_.close_tx(); return; }            // receiver dropped, src/decoder.rs:311-313
+      bool sent = false;
+      if (!st) {
+        sent = chan_.send(std::move(sets[f]));
+        t_send += secs(t1, now());
+      }
+      if (st || !sent) {                                   // device error, or receiver dropped (src/decoder.rs:311-313)
+        settle(f + 1);
+        if (st) error_ = derr[f];
+        chan_.close_tx();
+        return;
+      }
     }
+    destroy(&cur);
     inflight.pop_front();
   }
   chan_.close_tx();                                   // drop(tx), src/lib.rs:136

@@ -2,6 +2,7 @@
 // evaluated up front) and translation of the patch table into the kernels' work lists.
 #pragma once
 
+#include <stddef.h>
 #include <stdint.h>
 
 #include <vector>
@@ -37,6 +38,13 @@ int validate_frame(const vpcc_frame_desc* f);
 
 // Requires validate_frame(f) == VPCC_OK.
 void plan_frame(const vpcc_frame_desc& f, FramePlan* out);
+
+// Elements of a chroma plane that the reference's flat index (v/2)*cstride + (u/2) can reach (src/decoder.rs:977):
+// what the runtime uploads of a U or V plane.
+inline size_t chroma_elems(const vpcc_image_u16& a) {
+  if (a.width == 0 || a.height == 0) return 1;
+  return (size_t)((a.height - 1) / 2) * a.cstride + (a.width - 1) / 2 + 1;
+}
 
 // Alignment preconditions of the tile kernel's vector loads for the planes as the kernels will see
 // them (device pointers and strides): 8-B aligned luma rows, 4-B aligned chroma pairs.

@@ -72,6 +72,9 @@ struct vpcc_gof {
   hipStream_t last_stream = nullptr;
   std::vector<LaunchTimings> history;   // profile mode: ring of kProfileRing launches
   uint64_t launches_profiled = 0;       // slot of the current launch = (launches_profiled - 1) % kProfileRing
+  uint32_t profile_every = 1;           // profile mode: time every n-th reconstruct only (vpcc_gof_profile_interval)
+  uint64_t reconstructs = 0;
+  bool launch_is_timed = false;
   uint32_t generation = 0;             // launch counter of the tile kernel (tags look-back words)
   void* smooth_grid = nullptr;         // dense cell grids of the smoothing filters (scratch, on demand)
   size_t smooth_bytes = 0;
@@ -160,7 +163,8 @@ extern "C" void* vpcc_ctx_stream(const vpcc_ctx* ctx) { return ctx ? (void*)ctx-
 extern "C" int vpcc_host_pin(vpcc_ctx* ctx, const void* ptr, size_t bytes) {
   if (!ctx || !ptr || !bytes) return VPCC_ERR_INVALID_ARG;
   HIP_TRY(ctx, hipSetDevice(ctx->device));
-  HIP_TRY(ctx, hipHostRegister(const_cast<void*>(ptr), bytes, hipHostRegisterDefault));
+  // Portable: every device (every vpcc_ctx of the process) may DMA from it, not only ctx's
+  HIP_TRY(ctx, hipHostRegister(const_cast<void*>(ptr), bytes, hipHostRegisterPortable));
   return VPCC_OK;
 }
 
@@ -174,13 +178,15 @@ extern "C" int vpcc_host_unpin(vpcc_ctx* ctx, const void* ptr) {
 extern "C" int vpcc_host_alloc(vpcc_ctx* ctx, size_t bytes, void** out) {
   if (!ctx || !out || !bytes) return VPCC_ERR_INVALID_ARG;
   HIP_TRY(ctx, hipSetDevice(ctx->device));
-  HIP_TRY(ctx, hipHostMalloc(out, bytes, hipHostMallocDefault));
+  HIP_TRY(ctx, hipHostMalloc(out, bytes, hipHostMallocPortable));     // usable as a DMA target by every device
   return VPCC_OK;
 }
 
 extern "C" int vpcc_host_free(vpcc_ctx* ctx, void* ptr) {     // ctx may be NULL (context already destroyed)
+  (void)ctx;
   if (!ptr) return VPCC_ERR_INVALID_ARG;
-  if (ctx) HIP_TRY(ctx, hipSetDevice(ctx->device));
+  // no hipSetDevice: page-locked host memory is freed from any thread with any current device, and this is
+  // called from a consumer's thread when it drops a frame — it must not change that thread's device
   return hipHostFree(ptr) == hipSuccess ? VPCC_OK : VPCC_ERR_DEVICE;
 }
 
@@ -217,12 +223,6 @@ extern "C" void vpcc_gof_destroy(vpcc_gof* gof) {
 }
 
 namespace {
-
-// Elements of a chroma plane that the flat index (v/2)*cstride + (u/2) can reach.
-size_t chroma_elems(const vpcc_image_u16& a) {
-  if (a.width == 0 || a.height == 0) return 1;
-  return (size_t)((a.height - 1) / 2) * a.cstride + (a.width - 1) / 2 + 1;
-}
 
 // Copies a (possibly strided) host plane into a tight device plane.
 int copy_plane(vpcc_ctx* ctx, void* dst, const void* src, size_t elem, uint32_t width, uint32_t height,
@@ -467,6 +467,8 @@ struct Timer {
   LaunchTimings* slot = nullptr;
   // new_launch: a vpcc_gof_reconstruct opens the next ring slot; vpcc_gof_smooth appends to the current one
   Timer(vpcc_gof* g_, hipStream_t s_, bool new_launch) : g(g_), s(s_), on((g_->flags & VPCC_GOF_PROFILE) != 0) {
+    if (on && new_launch) g->launch_is_timed = (g->reconstructs++ % g->profile_every) == 0;
+    on = on && g->launch_is_timed;                         // a following vpcc_gof_smooth shares the decision
     if (!on) return;
     if (g->history.empty()) g->history.resize(kProfileRing);
     if (new_launch || g->launches_profiled == 0) {
@@ -503,6 +505,9 @@ extern "C" int vpcc_gof_reconstruct(vpcc_gof* g, uint32_t first, uint32_t count,
   HIP_TRY(ctx, hipSetDevice(ctx->device));
   hipStream_t s = hip_stream ? (hipStream_t)hip_stream : ctx->stream;
   HIP_TRY(ctx, hipStreamWaitEvent(s, g->upload_done, 0));        // the planes' H2D copies (copy stream) come first
+  // Launches on one gof are ordered: its ticket counters, look-back words and output arrays are reused by
+  // every launch.  A launch on another stream than the previous one waits for that one's kernels.
+  if (g->launched && g->last_stream != s) HIP_TRY(ctx, hipStreamWaitEvent(s, g->results_ready, 0));
   g->last_stream = s;
   g->counts_valid = false;
   Timer T(g, s, true);
@@ -644,6 +649,12 @@ extern "C" int vpcc_gof_kernel_times(vpcc_gof* g, const char** names_out, float*
     if (ms_out) ms_out[n] = ms;
   }
   return n;
+}
+
+extern "C" int vpcc_gof_profile_interval(vpcc_gof* g, uint32_t every) {
+  if (!g || every == 0) return VPCC_ERR_INVALID_ARG;
+  g->profile_every = every;
+  return VPCC_OK;
 }
 
 extern "C" int vpcc_gof_kernel_time_means(vpcc_gof* g, uint32_t last_n, const char** names_out, float* mean_ms_out,

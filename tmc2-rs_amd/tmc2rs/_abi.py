@@ -210,6 +210,7 @@ def load_library():
     lib.vpcc_gof_download.argtypes = [vp, u32, vp, vp, vp, sz, C.POINTER(sz)]
     lib.vpcc_gof_frame_status.argtypes = [vp, u32]
     lib.vpcc_gof_kernel_times.argtypes = [vp, C.POINTER(C.c_char_p), C.POINTER(C.c_float), C.c_int]
+    lib.vpcc_gof_profile_interval.argtypes = [vp, u32]
     lib.vpcc_gof_kernel_time_means.argtypes = [vp, u32, C.POINTER(C.c_char_p), C.POINTER(C.c_float),
                                                C.POINTER(u32), C.c_int]
     lib.vpcc_gof_algorithmic_bytes.argtypes = [vp, u32, C.POINTER(u64)]

@@ -194,6 +194,10 @@ class Gof:
         n = self.lib.vpcc_gof_kernel_times(self.h, names, ms, 16)
         return [(names[i].decode(), float(ms[i])) for i in range(n)]
 
+    def profile_interval(self, every):
+        """Profile mode: time only every `every`-th reconstruct."""
+        self.ctx._check(self.lib.vpcc_gof_profile_interval(self.h, int(every)), "vpcc_gof_profile_interval")
+
     def kernel_time_means(self, last_n=0):
         """({kernel name: mean ms over the last `last_n` profiled launches}, launches averaged)."""
         names = (C.c_char_p * 16)()
