@@ -106,3 +106,25 @@ def test_smoothing_needs_patch_index():
     assert e.value.status == _abi.VPCC_ERR_STATE
     g.close()
     ctx.close()
+
+
+@pytest.mark.gpu
+def test_repeated_smoothing_launches_leave_the_grid_clean():
+    """The dense grids are cleared cell by cell from the touched list, not by a memset: a second reconstruct +
+    smooth on the same gof — with another grid size, then the first again — must give the spec's result again."""
+    from tmc2rs import recon
+    fr = [cases.overlapping_3d_frame(i) for i in range(2)]
+    ctx = recon.Context(0)
+    g = ctx.gof(fr, flags=_abi.VPCC_GOF_WANT_PATCH_INDEX)
+    for grid, cgrid in ((8, 8), (4, 16), (8, 8), (8, 8)):
+        g.reconstruct()
+        before = [g.download(i, want_patch_index=True) for i in range(len(fr))]
+        g.smooth(10, grid_size=grid, threshold=1, color_grid_size=cgrid, color_threshold_smoothing=5,
+                 color_threshold_difference=80)
+        for i, b in enumerate(before):
+            after = g.download(i)
+            exp_xyz = ob.spec_smooth_geometry(b["xyz"], b["patch_index"], 10, grid, 1)
+            exp_rgb = ob.spec_smooth_color(exp_xyz, b["rgb"], b["patch_index"], 10, cgrid, 5, 80)
+            assert np.array_equal(after["xyz"], exp_xyz) and np.array_equal(after["rgb"], exp_rgb)
+    g.close()
+    ctx.close()

@@ -102,12 +102,31 @@ struct SmoothCell {
 };
 static_assert(sizeof(SmoothCell) == 24, "SmoothCell is 24 B");
 
-void launch_smooth_stats(const DevFrame* d_frames, uint32_t first, uint32_t count, uint32_t max_points, SmoothCell* grids,
+#if defined(__HIPCC__)
+#define VPCC_HD __host__ __device__
+#else
+#define VPCC_HD
+#endif
+// Scratch of the smoothing filters for a chunk of frames: per frame a dense grid of w^3 cells (all-zero between
+// launches) and the cell index of every point as the statistics kernel saw it (the geometry filter moves
+// points in place, so the cells to clear afterwards cannot be recomputed from the positions).
+struct SmoothGrid {
+  unsigned char* base;        // cells of frame slot j at base + j * slot_bytes (w^3 cells; this region is all-zero between launches)
+  size_t slot_bytes;
+  uint32_t* key_base;         // cell indices of frame slot j at key_base + j * key_stride (their own allocation: no zero invariant)
+  size_t key_stride;
+  VPCC_HD SmoothCell* cells(uint32_t j) const { return reinterpret_cast<SmoothCell*>(base + j * slot_bytes); }
+  VPCC_HD uint32_t* keys(uint32_t j) const { return key_base + j * key_stride; }
+};
+
+void launch_smooth_stats(const DevFrame* d_frames, uint32_t first, uint32_t count, uint32_t max_points, SmoothGrid sg,
                          uint32_t w, uint32_t G, uint32_t mode, void* stream);
 void launch_smooth_apply_geometry(const DevFrame* d_frames, uint32_t first, uint32_t count, uint32_t max_points,
-                                  const SmoothCell* grids, uint32_t w, uint32_t G, uint32_t T, void* stream);
+                                  SmoothGrid sg, uint32_t w, uint32_t G, uint32_t T, void* stream);
 void launch_smooth_apply_color(const DevFrame* d_frames, uint32_t first, uint32_t count, uint32_t max_points,
-                               const SmoothCell* grids, uint32_t w, uint32_t G, uint32_t Ts, uint32_t Td, void* stream);
+                               SmoothGrid sg, uint32_t w, uint32_t G, uint32_t Ts, uint32_t Td, void* stream);
+void launch_smooth_clear(const DevFrame* d_frames, uint32_t first, uint32_t count, uint32_t max_points, SmoothGrid sg,
+                         void* stream);
 
 // Kernel launchers (vpcc_kernels.hip).  All asynchronous on `stream`.
 void launch_block_owner(const DevFrame* d_frames, uint32_t first, uint32_t count, uint32_t max_vb,

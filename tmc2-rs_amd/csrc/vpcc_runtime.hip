@@ -76,8 +76,10 @@ struct vpcc_gof {
   uint64_t reconstructs = 0;
   bool launch_is_timed = false;
   uint32_t generation = 0;             // launch counter of the tile kernel (tags look-back words)
-  void* smooth_grid = nullptr;         // dense cell grids of the smoothing filters (scratch, on demand)
+  void* smooth_grid = nullptr;         // smoothing scratch (on demand): dense cell grids + touched lists + list lengths
   size_t smooth_bytes = 0;
+  bool smooth_clean = false;           // the scratch is all-zero (the invariant between launches)
+  void* smooth_keys = nullptr;         // cell index of every point of every frame (capacity words per frame)
 };
 
 namespace {
@@ -213,6 +215,7 @@ extern "C" void vpcc_gof_destroy(vpcc_gof* gof) {
   if (gof->upload_done) (void)hipEventDestroy(gof->upload_done);
   if (gof->results_ready) (void)hipEventDestroy(gof->results_ready);
   if (gof->smooth_grid) (void)hipFree(gof->smooth_grid);
+  if (gof->smooth_keys) (void)hipFree(gof->smooth_keys);
   if (gof->arena) {                                   // all work on it is complete (streams synchronised above)
     auto& cache = gof->ctx->arena_cache;
     if (cache.size() < 4) cache.emplace_back(gof->arena, gof->arena_bytes);
@@ -707,11 +710,14 @@ extern "C" int vpcc_gof_smooth(vpcc_gof* g, uint32_t first, uint32_t count, cons
   if ((p->flags & VPCC_SMOOTH_GEOMETRY) && p->grid_size < 2) return fail(ctx, VPCC_ERR_INVALID_ARG, "grid size");
   if ((p->flags & VPCC_SMOOTH_COLOR) && p->color_grid_size < 2) return fail(ctx, VPCC_ERR_INVALID_ARG, "colour grid size");
   HIP_TRY(ctx, hipSetDevice(ctx->device));
-  int st = fetch_counts(g);                               // synchronises: the point counts size the launches
-  if (st) return st;
+  if (!g->launched) return fail(ctx, VPCC_ERR_STATE, "no reconstruct issued");
   hipStream_t s = hip_stream ? (hipStream_t)hip_stream : ctx->stream;
+  if (g->last_stream != s) HIP_TRY(ctx, hipStreamWaitEvent(s, g->results_ready, 0));   // behind the reconstruction
   g->last_stream = s;
   Timer T(g, s, false);
+  // No host synchronisation: the kernels read every frame's point count from device memory; the launches are
+  // sized for the capacity and surplus workgroups leave at once.
+  const uint32_t max_points = (uint32_t)g->capacity;
   for (int pass = 0; pass < 2; ++pass) {
     const bool geo = pass == 0;
     if (!(p->flags & (geo ? VPCC_SMOOTH_GEOMETRY : VPCC_SMOOTH_COLOR))) continue;
@@ -725,34 +731,48 @@ extern "C" int vpcc_gof_smooth(vpcc_gof* g, uint32_t first, uint32_t count, cons
     const uint32_t G = geo ? p->grid_size : p->color_grid_size;
     const uint32_t w = ((1u << p->geometry_bitdepth_3d) + G - 1) / G;
     const size_t cells = (size_t)w * w * w;
-    // the dense grids live in a scratch arena of at most ~1 GiB: frames are smoothed in chunks
-    const size_t per_frame = cells * sizeof(SmoothCell);
-    const uint32_t chunk = (uint32_t)std::max<size_t>(1, std::min<size_t>(count, (size_t(1) << 30) / per_frame));
-    if (g->smooth_bytes < per_frame * chunk) {
+    // Scratch: per frame slot a dense grid (the cell index of every point has its own allocation).  At most
+    // ~16 GiB: a GOF whose grids need more is smoothed in chunks of frames.  The scratch is all-zero
+    // between launches (k_smooth_clear restores what a launch touched), so it is cleared only when it is
+    // (re)allocated or after a failed launch.
+    SmoothGrid sg{};
+    sg.slot_bytes = align_up(cells * sizeof(SmoothCell), 256);
+    sg.key_stride = g->capacity;
+    if (!g->smooth_keys) HIP_TRY(ctx, hipMalloc(&g->smooth_keys, sizeof(uint32_t) * g->capacity * g->n_frames));
+    sg.key_base = (uint32_t*)g->smooth_keys;
+    const uint32_t chunk = (uint32_t)std::max<size_t>(1, std::min<size_t>(count, (size_t(16) << 30) / sg.slot_bytes));
+    const size_t need = sg.slot_bytes * chunk;
+    if (g->smooth_bytes < need) {
       if (g->smooth_grid) HIP_TRY(ctx, hipFree(g->smooth_grid));
       g->smooth_grid = nullptr;
       g->smooth_bytes = 0;
-      HIP_TRY(ctx, hipMalloc(&g->smooth_grid, per_frame * chunk));
-      g->smooth_bytes = per_frame * chunk;
+      HIP_TRY(ctx, hipMalloc(&g->smooth_grid, need));
+      g->smooth_bytes = need;
+      g->smooth_clean = false;
     }
+    if (!g->smooth_clean) {
+      HIP_TRY(ctx, hipMemsetAsync(g->smooth_grid, 0, g->smooth_bytes, s));
+      g->smooth_clean = true;
+    }
+    sg.base = (unsigned char*)g->smooth_grid;
     for (uint32_t c0 = first; c0 < first + count; c0 += chunk) {
       const uint32_t c = std::min(chunk, first + count - c0);
-      uint32_t max_points = 0;
-      for (uint32_t i = c0; i < c0 + c; ++i) max_points = std::max(max_points, std::min<uint32_t>(g->h_counts[i], (uint32_t)g->capacity));
-      T.begin(geo ? "smooth_geometry_grid_clear" : "smooth_color_grid_clear");
-      HIP_TRY(ctx, hipMemsetAsync(g->smooth_grid, 0, per_frame * c, s));
-      T.end();
+      g->smooth_clean = false;                              // until the clearing kernel of this chunk is enqueued
       T.begin(geo ? "k_smooth_stats<geometry>" : "k_smooth_stats<color>");
-      launch_smooth_stats(g->d_frames, c0, c, max_points, (SmoothCell*)g->smooth_grid, w, G, geo ? 0u : 1u, s);
+      launch_smooth_stats(g->d_frames, c0, c, max_points, sg, w, G, geo ? 0u : 1u, s);
       T.end();
       T.begin(geo ? "k_smooth_apply_geometry" : "k_smooth_apply_color");
       if (geo)
-        launch_smooth_apply_geometry(g->d_frames, c0, c, max_points, (const SmoothCell*)g->smooth_grid, w, G, p->threshold, s);
+        launch_smooth_apply_geometry(g->d_frames, c0, c, max_points, sg, w, G, p->threshold, s);
       else
-        launch_smooth_apply_color(g->d_frames, c0, c, max_points, (const SmoothCell*)g->smooth_grid, w, G,
-                                  p->color_threshold_smoothing, p->color_threshold_difference, s);
+        launch_smooth_apply_color(g->d_frames, c0, c, max_points, sg, w, G, p->color_threshold_smoothing,
+                                  p->color_threshold_difference, s);
+      T.end();
+      T.begin(geo ? "k_smooth_clear<geometry>" : "k_smooth_clear<color>");
+      launch_smooth_clear(g->d_frames, c0, c, max_points, sg, s);
       T.end();
       HIP_TRY(ctx, hipGetLastError());
+      g->smooth_clean = true;
     }
   }
   HIP_TRY(ctx, hipEventRecord(g->results_ready, s));

@@ -4,11 +4,13 @@
 // src/codec.rs:498-500); the behaviour is this repository's own integer specification "gs1"/"cs1",
 // written down in oracle/vpcc_smoothing_spec.h and tested bit for bit against its CPU form.
 //
-// Two kernels per filter, both one thread per point, HBM-bound scatter/gather:
+// Three kernels per filter, one thread per point (the clearing kernel: per touched cell):
 //   k_smooth_stats : per occupied grid cell {count, 3 sums, max(65535 - patch), max(patch)} with atomics into
-//                    a dense w^3 grid (zeroed by one memset per launch);
-//   k_smooth_apply : 2x2x2 cell neighbourhood with integer trilinear weights -> centroid / mean,
-//                    thresholded replacement in place (a thread reads only its own point and the grid).
+//                    a dense w^3 grid that is all-zero between launches; records the cells it touches;
+//   k_smooth_apply : 2x2x2 cell neighbourhood -> stop unless a cell mixes patches -> integer trilinear
+//                    weights -> centroid / mean, thresholded replacement in place (a thread reads only its
+//                    own point and the grid);
+//   k_smooth_clear : zeroes exactly the touched cells again.
 #include <hip/hip_runtime.h>
 
 #include "vpcc_device.hpp"
@@ -42,36 +44,41 @@ __device__ __forceinline__ void axis_setup(uint32_t p, uint32_t G, uint32_t w, i
 
 }  // namespace
 
-// Wave-wide sum / max with DPP row shifts and row broadcasts (no LDS); the result is valid in lane 63.
-template <int kCtrl, int kRowMask, bool kMax>
+// Wave-wide sum / packed-16-bit max with DPP row shifts and row broadcasts (no LDS); the result is valid in lane 63.
+typedef uint16_t u16x2 __attribute__((ext_vector_type(2)));
+template <int kCtrl, int kRowMask, bool kPkMax>
 __device__ __forceinline__ uint32_t dpp_step(uint32_t v) {
   const uint32_t o = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, kCtrl, kRowMask, 0xF, kRowMask == 0xF);
-  return kMax ? (o > v ? o : v) : v + o;
+  if (kPkMax)
+    return __builtin_bit_cast(uint32_t, __builtin_elementwise_max(__builtin_bit_cast(u16x2, o), __builtin_bit_cast(u16x2, v)));
+  return v + o;
 }
-template <bool kMax>
+template <bool kPkMax>
 __device__ __forceinline__ uint32_t wave_reduce(uint32_t v) {
-  v = dpp_step<0x111, 0xF, kMax>(v);
-  v = dpp_step<0x112, 0xF, kMax>(v);
-  v = dpp_step<0x114, 0xF, kMax>(v);
-  v = dpp_step<0x118, 0xF, kMax>(v);
-  v = dpp_step<0x142, 0xA, kMax>(v);
-  v = dpp_step<0x143, 0xC, kMax>(v);
+  v = dpp_step<0x111, 0xF, kPkMax>(v);
+  v = dpp_step<0x112, 0xF, kPkMax>(v);
+  v = dpp_step<0x114, 0xF, kPkMax>(v);
+  v = dpp_step<0x118, 0xF, kPkMax>(v);
+  v = dpp_step<0x142, 0xA, kPkMax>(v);
+  v = dpp_step<0x143, 0xC, kPkMax>(v);
   return (uint32_t)__builtin_amdgcn_readlane((int)v, 63);
 }
 
 // mode 0: sums of coordinates (geometry); mode 1: sums of R,G,B (colour).
 // Points arrive in emission order, so the 64 points of a wave fall into a handful of cells (a block row of
-// 16 pixels spans two cells of size 8).  The wave therefore reduces its points per distinct cell first and
-// issues ONE set of atomics per cell: ~20x fewer atomics than one set per point, which had serialised on
-// the hot cells (3.9 ms per 20 frames before).
+// 16 pixels spans two cells of size 8).  The wave reduces its points per distinct cell first and issues ONE
+// set of atomics per cell (six lanes, one word each, nothing returned).  The grids are all-zero between
+// launches: every point's cell index is kept, and k_smooth_clear zeroes exactly those cells afterwards — no
+// dense memset (50 MB per frame at w = 128) per launch.  (A list of touched cells fed by the first adder of
+// each cell needs RETURNING atomics and one hot list counter per frame: 8.9 ms per 32 frames instead of 0.3.)
 __global__ __launch_bounds__(256) void k_smooth_stats(const DevFrame* __restrict__ frames, uint32_t first,
-                                                      SmoothCell* __restrict__ grids, uint32_t w, uint32_t G,
-                                                      uint32_t mode) {
+                                                      SmoothGrid sg, uint32_t w, uint32_t G, uint32_t mode) {
   const DevFrame& f = frames[first + blockIdx.y];
   const uint32_t n = min(*gl(f.n_points), f.capacity);
   const uint32_t i = blockIdx.x * 256u + threadIdx.x;
   if (blockIdx.x * 256u >= n) return;
   const bool active = i < n;
+  const uint32_t lane = threadIdx.x & 63u;
   uint32_t key = 0xFFFFFFFFu, v[3] = {0, 0, 0}, patch = 0;
   if (active) {
     const vpcc_point3 p = gload(f.out_xyz + i);
@@ -82,8 +89,9 @@ __global__ __launch_bounds__(256) void k_smooth_stats(const DevFrame* __restrict
       v[0] = col.r; v[1] = col.g; v[2] = col.b;
     }
     patch = gl(f.out_patch)[i];
+    sg.keys(blockIdx.y)[i] = key;
   }
-  SmoothCell* grid = grids + (size_t)blockIdx.y * w * w * w;
+  SmoothCell* grid = sg.cells(blockIdx.y);
   uint64_t todo = __ballot(active);
   while (todo) {                                           // one trip per distinct cell of the wave
     const uint32_t k = (uint32_t)__builtin_amdgcn_readlane((int)key, (int)__builtin_ctzll(todo));
@@ -91,49 +99,78 @@ __global__ __launch_bounds__(256) void k_smooth_stats(const DevFrame* __restrict
     const uint64_t mask = __ballot(in);
     const uint32_t s0 = wave_reduce<false>(in ? v[0] : 0u), s1 = wave_reduce<false>(in ? v[1] : 0u),
                    s2 = wave_reduce<false>(in ? v[2] : 0u);
-    const uint32_t nm = wave_reduce<true>(in ? 65535u - patch : 0u), mp = wave_reduce<true>(in ? patch : 0u);
-    if ((threadIdx.x & 63u) == 0) {
-      SmoothCell* c = grid + k;
-      atomicAdd(&c->count, (uint32_t)__builtin_popcountll(mask));
-      atomicAdd(&c->s[0], s0);
-      atomicAdd(&c->s[1], s1);
-      atomicAdd(&c->s[2], s2);
-      atomicMax(&c->negminp, nm);
-      atomicMax(&c->maxp, mp);
+    // {max(65535 - patch), max(patch)} in one packed-16 reduction
+    const uint32_t mm = wave_reduce<true>(in ? ((65535u - patch) << 16) | patch : 0u);
+    if (lane < 6u) {
+      uint32_t* word = &(grid + k)->count + lane;           // count, s[0..2], negminp, maxp
+      const uint32_t val = lane == 0 ? (uint32_t)__builtin_popcountll(mask) : lane == 1 ? s0 : lane == 2 ? s1 : lane == 3 ? s2
+                           : lane == 4 ? mm >> 16 : mm & 0xFFFFu;
+      if (lane < 4u) atomicAdd(word, val);
+      else atomicMax(word, val);
     }
     todo &= ~mask;
   }
 }
 
+// Restores the all-zero state of the cells this launch touched: one thread per point, the first lane of every
+// run of equal cell indices writes the zeros (several runs may clear one cell; that is harmless).
+__global__ __launch_bounds__(256) void k_smooth_clear(const DevFrame* __restrict__ frames, uint32_t first, SmoothGrid sg) {
+  const DevFrame& f = frames[first + blockIdx.y];
+  const uint32_t n = min(*gl(f.n_points), f.capacity);
+  const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+  if (i >= n) return;
+  const uint32_t key = sg.keys(blockIdx.y)[i];
+  const uint32_t prev = (uint32_t)__builtin_amdgcn_update_dpp((int)~key, (int)key, 0x111, 0xF, 0xF, false);   // row_shr:1
+  if (prev == key) return;
+  uint2* c = reinterpret_cast<uint2*>(sg.cells(blockIdx.y) + key);
+  c[0] = make_uint2(0u, 0u); c[1] = make_uint2(0u, 0u); c[2] = make_uint2(0u, 0u);
+}
+
+namespace {
+struct Hood {                  // the 2x2x2 cells around a point
+  SmoothCell c[8];
+  bool inside[8];
+};
+// Loads the neighbourhood and tells whether any of its cells holds points of more than one patch: only then
+// does a filter do anything (most points of a frame are far from a patch boundary and stop here).
+__device__ __forceinline__ bool load_hood(const SmoothCell* grid, const int32_t s[3], uint32_t w, Hood& h) {
+  bool mixed = false;
+#pragma unroll
+  for (int d = 0; d < 8; ++d) {
+    const int32_t cx = s[0] + (d & 1), cy = s[1] + ((d >> 1) & 1), cz = s[2] + (d >> 2);
+    h.inside[d] = !(cx < 0 || cy < 0 || cz < 0 || cx >= (int32_t)w || cy >= (int32_t)w || cz >= (int32_t)w);
+    h.c[d] = SmoothCell{};
+    if (h.inside[d]) h.c[d] = gload(grid + ((size_t)cz * w + cy) * w + cx);
+    mixed |= h.c[d].count != 0 && (65535u - h.c[d].negminp) != h.c[d].maxp;
+  }
+  return mixed;
+}
+}  // namespace
+
 __global__ __launch_bounds__(256) void k_smooth_apply_geometry(const DevFrame* __restrict__ frames, uint32_t first,
-                                                               const SmoothCell* __restrict__ grids, uint32_t w,
-                                                               uint32_t G, uint32_t T) {
+                                                               SmoothGrid sg, uint32_t w, uint32_t G, uint32_t T) {
   const DevFrame& f = frames[first + blockIdx.y];
   const uint32_t n = min(*gl(f.n_points), f.capacity);
   const uint32_t i = blockIdx.x * 256u + threadIdx.x;
   if (i >= n) return;
   const vpcc_point3 pt = gload(f.out_xyz + i);
   const uint32_t p[3] = {pt.x, pt.y, pt.z};
-  const SmoothCell* grid = grids + (size_t)blockIdx.y * w * w * w;
   int32_t s[3];
   int64_t wt[3][2];
 #pragma unroll
   for (int a = 0; a < 3; ++a) axis_setup(p[a], G, w, s[a], wt[a]);
+  Hood h;
+  if (!load_hood(sg.cells(blockIdx.y), s, w, h)) return;
   int64_t num[3] = {0, 0, 0}, den = 0;
-  bool mixed = false;
 #pragma unroll
   for (int d = 0; d < 8; ++d) {
-    const int dx = d & 1, dy = (d >> 1) & 1, dz = d >> 2;
-    const int32_t cx = s[0] + dx, cy = s[1] + dy, cz = s[2] + dz;
-    if (cx < 0 || cy < 0 || cz < 0 || cx >= (int32_t)w || cy >= (int32_t)w || cz >= (int32_t)w) continue;
-    const SmoothCell c = gload(grid + ((size_t)cz * w + cy) * w + cx);
+    const SmoothCell& c = h.c[d];
     if (!c.count) continue;
-    const int64_t W = wt[0][dx] * wt[1][dy] * wt[2][dz];
+    const int64_t W = wt[0][d & 1] * wt[1][(d >> 1) & 1] * wt[2][d >> 2];
     num[0] += W * c.s[0]; num[1] += W * c.s[1]; num[2] += W * c.s[2];
     den += W * c.count;
-    mixed |= (65535u - c.negminp) != c.maxp;
   }
-  if (!mixed || den <= 0) return;
+  if (den <= 0) return;
   int64_t C[3], d2 = 0;
 #pragma unroll
   for (int a = 0; a < 3; ++a) {
@@ -150,40 +187,41 @@ __global__ __launch_bounds__(256) void k_smooth_apply_geometry(const DevFrame* _
 }
 
 __global__ __launch_bounds__(256) void k_smooth_apply_color(const DevFrame* __restrict__ frames, uint32_t first,
-                                                            const SmoothCell* __restrict__ grids, uint32_t w, uint32_t G,
-                                                            uint32_t Ts, uint32_t Td) {
+                                                            SmoothGrid sg, uint32_t w, uint32_t G, uint32_t Ts, uint32_t Td) {
   const DevFrame& f = frames[first + blockIdx.y];
   const uint32_t n = min(*gl(f.n_points), f.capacity);
   const uint32_t i = blockIdx.x * 256u + threadIdx.x;
   if (i >= n) return;
   const vpcc_point3 pt = gload(f.out_xyz + i);
-  const vpcc_color3 col = gload(f.out_rgb + i);
   const uint32_t p[3] = {pt.x, pt.y, pt.z};
-  const int64_t cl[3] = {col.r, col.g, col.b};
-  const SmoothCell* grid = grids + (size_t)blockIdx.y * w * w * w;
   int32_t s[3];
   int64_t wt[3][2];
 #pragma unroll
   for (int a = 0; a < 3; ++a) axis_setup(p[a], G, w, s[a], wt[a]);
+  Hood h;
+  if (!load_hood(sg.cells(blockIdx.y), s, w, h)) return;
+  const vpcc_color3 col = gload(f.out_rgb + i);
+  const int64_t cl[3] = {col.r, col.g, col.b};
+  // the point's own cell is one of the eight: index of (q - s) per axis
   const int32_t qx = (int32_t)cell_coord(p[0], G, w), qy = (int32_t)cell_coord(p[1], G, w), qz = (int32_t)cell_coord(p[2], G, w);
-  const SmoothCell cc = gload(grid + ((size_t)qz * w + qy) * w + qx);
+  const int own = (qx - s[0]) | ((qy - s[1]) << 1) | ((qz - s[2]) << 2);
+  SmoothCell cc = h.c[0];
+#pragma unroll
+  for (int d = 1; d < 8; ++d) if (d == own) cc = h.c[d];
   const int64_t mc[3] = {cc.s[0] / cc.count, cc.s[1] / cc.count, cc.s[2] / cc.count};
   int64_t num[3] = {0, 0, 0}, den = 0;
   bool mixed = false;
 #pragma unroll
   for (int d = 0; d < 8; ++d) {
-    const int dx = d & 1, dy = (d >> 1) & 1, dz = d >> 2;
-    const int32_t cx = s[0] + dx, cy = s[1] + dy, cz = s[2] + dz;
-    if (cx < 0 || cy < 0 || cz < 0 || cx >= (int32_t)w || cy >= (int32_t)w || cz >= (int32_t)w) continue;
-    const SmoothCell c = gload(grid + ((size_t)cz * w + cy) * w + cx);
+    const SmoothCell& c = h.c[d];
     if (!c.count) continue;
-    if (!(cx == qx && cy == qy && cz == qz)) {
+    if (d != own) {
       int64_t diff = 0;
 #pragma unroll
       for (int a = 0; a < 3; ++a) { const int64_t m = (int64_t)(c.s[a] / c.count) - mc[a]; diff += m < 0 ? -m : m; }
       if (diff > (int64_t)Td) continue;
     }
-    const int64_t W = wt[0][dx] * wt[1][dy] * wt[2][dz];
+    const int64_t W = wt[0][d & 1] * wt[1][(d >> 1) & 1] * wt[2][d >> 2];
     num[0] += W * c.s[0]; num[1] += W * c.s[1]; num[2] += W * c.s[2];
     den += W * c.count;
     mixed |= (65535u - c.negminp) != c.maxp;
@@ -203,23 +241,29 @@ __global__ __launch_bounds__(256) void k_smooth_apply_color(const DevFrame* __re
   }
 }
 
-void launch_smooth_stats(const DevFrame* d_frames, uint32_t first, uint32_t count, uint32_t max_points, SmoothCell* grids,
+void launch_smooth_stats(const DevFrame* d_frames, uint32_t first, uint32_t count, uint32_t max_points, SmoothGrid sg,
                          uint32_t w, uint32_t G, uint32_t mode, void* stream) {
   if (!count || !max_points) return;
   hipLaunchKernelGGL(k_smooth_stats, dim3((max_points + 255) / 256, count), dim3(256), 0, (hipStream_t)stream, d_frames,
-                     first, grids, w, G, mode);
+                     first, sg, w, G, mode);
 }
 void launch_smooth_apply_geometry(const DevFrame* d_frames, uint32_t first, uint32_t count, uint32_t max_points,
-                                  const SmoothCell* grids, uint32_t w, uint32_t G, uint32_t T, void* stream) {
+                                  SmoothGrid sg, uint32_t w, uint32_t G, uint32_t T, void* stream) {
   if (!count || !max_points) return;
   hipLaunchKernelGGL(k_smooth_apply_geometry, dim3((max_points + 255) / 256, count), dim3(256), 0, (hipStream_t)stream,
-                     d_frames, first, grids, w, G, T);
+                     d_frames, first, sg, w, G, T);
 }
 void launch_smooth_apply_color(const DevFrame* d_frames, uint32_t first, uint32_t count, uint32_t max_points,
-                               const SmoothCell* grids, uint32_t w, uint32_t G, uint32_t Ts, uint32_t Td, void* stream) {
+                               SmoothGrid sg, uint32_t w, uint32_t G, uint32_t Ts, uint32_t Td, void* stream) {
   if (!count || !max_points) return;
   hipLaunchKernelGGL(k_smooth_apply_color, dim3((max_points + 255) / 256, count), dim3(256), 0, (hipStream_t)stream,
-                     d_frames, first, grids, w, G, Ts, Td);
+                     d_frames, first, sg, w, G, Ts, Td);
+}
+void launch_smooth_clear(const DevFrame* d_frames, uint32_t first, uint32_t count, uint32_t max_points, SmoothGrid sg,
+                         void* stream) {
+  if (!count || !max_points) return;
+  hipLaunchKernelGGL(k_smooth_clear, dim3((max_points + 255) / 256, count), dim3(256), 0, (hipStream_t)stream, d_frames,
+                     first, sg);
 }
 
 }  // namespace vpcc
