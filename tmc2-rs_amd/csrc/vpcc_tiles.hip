@@ -228,7 +228,7 @@ __device__ __forceinline__ void load_origin(const Item& it, uint32_t lane, uint3
 }
 template <bool kLastUse>
 __device__ __forceinline__ void load_geometry(const DevFrame& f, const Item& it, uint32_t lane, Samples& s) {
-  constexpr bool kS = kLastUse && (VPCC_TILES_NT & 4);
+  constexpr bool kS = (kLastUse && (VPCC_TILES_NT & 4)) || (!kLastUse && (VPCC_TILES_NT & 8));   // 8: the count phase's (only) read
   uint32_t px0, py0;
   load_origin(it, lane, s.occ, px0, py0);
   const uint32_t off = (__umul24(py0, f.geo_stride[0]) + px0) * 2u;                // both layers: one video, one row pitch
@@ -499,13 +499,22 @@ __device__ __forceinline__ void store_rgb(VPCC_GLOBAL unsigned char* base, uint3
 #define VPCC_TILES_WAVES_PER_EU 4
 #endif
 // 1: the loop over a wave's four items of a group is unrolled (no register rotation, no cur = nxt copies)
+// scope of the speculative look-back read: wavefront = plain cacheable load (may hit a stale L1 line, then the
+// look-back re-reads coherently), agent = sc1 load served by the L2
+#ifndef VPCC_TILES_EARLY_SCOPE
+#define VPCC_TILES_EARLY_SCOPE __HIP_MEMORY_SCOPE_WAVEFRONT
+#endif
+// 1: colours leave as one 12-byte store per four points (even lanes) instead of dword + short per two points
+#ifndef VPCC_TILES_RGB_QUADS
+#define VPCC_TILES_RGB_QUADS 1
+#endif
 #ifndef VPCC_TILES_UNROLL_ITEMS
 #define VPCC_TILES_UNROLL_ITEMS 1
 #endif
-// 1: pipelined (count group g+1, then emit group g; geometry read twice)   2: resident (all of a group's
-// samples in registers, every plane byte read once)
-//                                                   3: pipelined, the counted geometry stays in registers
-//                                                   4: structure 3 with wave-level tickets, no workgroup barriers
+// 1: pipelined (count group g+1, then emit group g), the emit phase reads the geometry again
+// 3: pipelined, the counted geometry stays in registers (default: every plane byte is requested once)
+// (Measured and dropped, see DESIGN.md: 2 = all samples of a group resident, no pipelining — least traffic,
+//  0.171 ms; 4 = structure 3 with wave-level tickets and no workgroup barrier — 0.136 vs 0.129 ms.)
 #ifndef VPCC_TILES_STRUCTURE
 #define VPCC_TILES_STRUCTURE 3
 #endif
@@ -572,14 +581,35 @@ __device__ __forceinline__ void emit_item(const DevFrame& f, const Item& it, con
         p1 = relative_point(it.axes & 3u, it.flags & kTileMode1, pack_point(pc, (rr.x & 0xFFFFu) | (rr.z & 0xFF0000u)), rr.z & 0xFFFFu);
     }
     if ((variant & 32u) && p0.x != 0xFFFFFFFEu) continue;               // ablation: all the arithmetic, no stores
+#if VPCC_TILES_RGB_QUADS
+    // Colours: 6 B per lane would take two interleaved store instructions (dword + short) that the L2 has to
+    // merge; instead an even lane stores the 12 B of FOUR points — its own two and its odd neighbour's,
+    // fetched with a quad permute — as one dwordx3, so every instruction writes a contiguous range.
+    const uint32_t c2 = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)rr.y, 0xF5, 0xF, 0xF, false);   // quad_perm:[1,1,3,3]
+    const uint32_t c3 = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)rr.w, 0xF5, 0xF, 0xF, false);
+    const bool odd = lane & 1u, quad = !odd && k + 3u < nw;
+#else
+    const bool odd = false, quad = false;
+#endif
     if (two) {
       store_xyz2(gx, (base + k) * 6u, p0, p1);
-      if (f.has_attr) store_rgb2(gc, (base + k) * 3u, rr.y, rr.w);
       if (gp) out_store<u32_a2>((VPCC_GLOBAL unsigned char*)gp + (base + k) * 2u, it.patch | (it.patch << 16));   // partition, codec.rs:452
     } else {
       store_xyz(gx, (base + k) * 6u, p0);
-      if (f.has_attr) store_rgb(gc, (base + k) * 3u, rr.y);
       if (gp) gp[base + k] = (uint16_t)it.patch;
+    }
+    if (f.has_attr) {
+#if VPCC_TILES_RGB_QUADS
+      if (quad) {
+        u32x3 o;
+        o.x = (rr.y & 0xFFFFFFu) | (rr.w << 24); o.y = ((rr.w >> 8) & 0xFFFFu) | (c2 << 16); o.z = ((c2 >> 16) & 0xFFu) | (c3 << 8);
+        out_store<u32x3_a2>(gc + (base + k) * 3u, o);
+      } else
+#endif
+      if (!(odd && two)) {                                 // (an odd lane with two points: its even neighbour stored them)
+        if (two) store_rgb2(gc, (base + k) * 3u, rr.y, rr.w);
+        else store_rgb(gc, (base + k) * 3u, rr.y);
+      }
     }
   }
   wave_sync();                                      // the next item overwrites the slots
@@ -653,7 +683,7 @@ void k_recon_tiles(const DevFrame* __restrict__ frames, uint32_t first,
       // EMPTY -> AGGREGATE -> PREFIX within a launch and carries the launch generation, so any older state
       // is safe to act on — a stale EMPTY just sends the lane to the coherent re-read in look_back_groups.
       if (have_cur && lane < g_cur)
-        early = __hip_atomic_load(gl(f.scan_state + (g_cur - 1u - lane)), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+        early = __hip_atomic_load(gl(f.scan_state + (g_cur - 1u - lane)), __ATOMIC_RELAXED, VPCC_TILES_EARLY_SCOPE);
     };
     VPCC_STAMP(0)
 
@@ -815,249 +845,6 @@ void k_recon_tiles(const DevFrame* __restrict__ frames, uint32_t first,
 }
 
 
-// ---------------------------------------------------------------------------------------------------
-// Structure 2 ("resident"): every plane byte is read ONCE.  A wave issues the loads of all four of its
-// items up front (occupancy, then geometry, the speculative look-back read, then the attributes: ~10 KB in
-// flight per wave instead of 2.5 KB), counts as soon as the geometry has landed, and emits the group
-// from registers.  No load is issued between or behind the output stores, so no wait for samples ever
-// covers stores (gfx9's single in-order vmcnt).  The look-back of group g waits only for the jitter between
-// workgroups: every predecessor drew its ticket — and issued its loads — earlier than this workgroup.
-template <bool kStamps>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(VPCC_TILES_WAVES_PER_EU, VPCC_TILES_WAVES_PER_EU)))
-void k_recon_tiles_resident(const DevFrame* __restrict__ frames, uint32_t first, uint32_t count, uint32_t groups_stride,
-                            uint32_t gen, uint32_t variant_arg) {
-  const uint32_t variant = kDiagnostic ? variant_arg : 0u;
-  const uint32_t xcd = blockIdx.x & 7u, slot = blockIdx.x >> 3;
-  const uint32_t frame_groups = (count + 7u) / 8u;
-  const uint32_t fi = xcd + 8u * (slot % frame_groups);
-  if (fi >= count) return;
-  const DevFrame& f = frames[first + fi];
-
-  __shared__ uint32_t s_group;
-  __shared__ uint32_t s_tot[kTileItemsPerGroup];
-  __shared__ __attribute__((aligned(16))) uint2 s_slots[4][kSlotsPerWave];
-
-  const uint32_t n_groups = (f.n_tiles + kTileItemsPerGroup - 1u) / kTileItemsPerGroup;
-  const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = lane_id();
-  constexpr uint32_t K = kTileItemsPerWave;
-  static_assert(K == 4, "four items per wave are kept in registers");
-  uint2* slots = s_slots[wave];
-
-  for (;;) {
-    // ---- 1. ticket (see k_recon_tiles: n_groups + groups_stride tickets per launch, the last re-arms) ----
-    if (threadIdx.x == 0) {
-      const uint32_t t = __hip_atomic_fetch_add(glw(f.ticket), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      if (t + 1u == n_groups + groups_stride)
-        __hip_atomic_store(glw(f.ticket), 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      s_group = t;
-    }
-    __syncthreads();
-    const uint32_t g = __builtin_amdgcn_readfirstlane(s_group);
-    if (g >= n_groups) break;
-
-    // ---- 2. all loads of the wave's four items -------------------------------------------------------
-    uint32_t idx[K];
-    Samples s[K];
-    {
-      Item it4[K];
-      uint32_t raw[K];
-#pragma unroll
-      for (uint32_t i = 0; i < K; ++i) {
-        idx[i] = g * kTileItemsPerGroup + item_in_group(wave, i);
-        it4[i] = load_item(f.tiles + (idx[i] < f.n_tiles ? idx[i] : 0u));
-      }
-#pragma unroll
-      for (uint32_t i = 0; i < K; ++i) raw[i] = load_occupancy_raw(f, it4[i], lane);
-#pragma unroll
-      for (uint32_t i = 0; i < K; ++i) {
-        s[i].occ = idx[i] < f.n_tiles ? occupancy_bits(f, raw[i]) : 0u;     // past the end: an empty copy of item 0
-        if (variant & 512u) { s[i].g0 = Px4{lane, 0u}; s[i].g1 = Px4{0u, lane}; }
-        else load_geometry<true>(f, it4[i], lane, s[i]);
-      }
-    }
-    // speculative look-back read behind the geometry (a cacheable load: an older state of a word is always
-    // safe to act on, see k_recon_tiles); it lands before the attributes
-    uint64_t early = 0;
-    if (lane < g)
-      early = __hip_atomic_load(gl(f.scan_state + (g - 1u - lane)), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
-#pragma unroll
-    for (uint32_t i = 0; i < K; ++i) {
-      const Item it = load_item(f.tiles + (idx[i] < f.n_tiles ? idx[i] : 0u));
-      s[i].y0 = s[i].y1 = Px4{0u, 0u};
-      s[i].u0 = s[i].v0 = s[i].u1 = s[i].v1 = 0u;
-      if (!(variant & 256u)) load_attributes(f, it, lane, s[i]);
-    }
-
-    // ---- 3. count (needs the geometry only) -----------------------------------------------------------
-    uint32_t dups = 0;
-#pragma unroll
-    for (uint32_t i = 0; i < K; ++i) {
-      const Item it = load_item(f.tiles + (idx[i] < f.n_tiles ? idx[i] : 0u));
-      const uint32_t dup = classify(f, it, s[i]) & s[i].occ;
-      dups |= dup << (4u * i);
-      const uint32_t cnt = wave_sum(2u * (uint32_t)__builtin_popcount(s[i].occ) - (uint32_t)__builtin_popcount(dup));
-      if (lane == 0) s_tot[item_in_group(wave, i)] = cnt;
-    }
-    __syncthreads();
-    uint32_t total = lane < kTileItemsPerGroup ? s_tot[lane] : 0u;
-    total = wave_sum(total);
-    if (wave == 0 && lane == 0 && g != 0)
-      st_store(f.scan_state + g, ((uint64_t)gen << kGenShift) | kAggregate | total);
-
-    // ---- 4. look back (every wave for itself), publish the inclusive prefix ----------------------------
-    uint32_t excl = (variant & 1u) ? g * 7000u : 0u;
-    if (g != 0 && !(variant & 1u)) excl = look_back_groups(f, g, gen, early);
-    if (wave == 0 && lane == 0) {
-      st_store(f.scan_state + g, ((uint64_t)gen << kGenShift) | kPrefix | (uint64_t)(excl + total));
-      if (g + 1u == n_groups)                                            // tile.total_number_of_regular_points
-        *glw(f.n_points) = (variant & 1u) ? (excl + total < f.capacity ? excl + total : f.capacity) : excl + total;
-    }
-
-    // ---- 5. emit the four items from registers ----------------------------------------------------------
-    uint32_t base = excl;
-    for (uint32_t k = 0; k < item_in_group(wave, 0); ++k) base += s_tot[k];
-#pragma unroll
-    for (uint32_t i = 0; i < K; ++i) {
-      const Item it = load_item(f.tiles + (idx[i] < f.n_tiles ? idx[i] : 0u));
-      emit_item(f, it, s[i], (dups >> (4u * i)) & 0xFu, s_tot[item_in_group(wave, i)], base, lane, slots, variant, [] {});
-      for (uint32_t k = item_in_group(wave, i); k < item_in_group(wave, i + 1u) && k < kTileItemsPerGroup; ++k) base += s_tot[k];
-    }
-  }
-}
-
-
-// ---------------------------------------------------------------------------------------------------
-// Structure 4 ("wave-autonomous"): the pipeline of structure 3, but every WAVE draws its own tickets
-// (4 consecutive items), publishes its own look-back word and computes its own output offsets.  No workgroup
-// barrier, no count exchange through LDS: in the workgroup-level structures the four waves of a group wait
-// at two barriers per step for the slowest of them (stamps: 15 % of a wave's life between the ticket
-// barrier and its release).  A workgroup is only a container of four independent waves here.
-template <bool kStamps>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(VPCC_TILES_WAVES_PER_EU, VPCC_TILES_WAVES_PER_EU)))
-void k_recon_tiles_wave(const DevFrame* __restrict__ frames, uint32_t first, uint32_t count, uint32_t waves_per_frame,
-                        uint32_t gen, uint32_t variant_arg) {
-  const uint32_t variant = kDiagnostic ? variant_arg : 0u;
-  const uint32_t xcd = blockIdx.x & 7u, slot = blockIdx.x >> 3;
-  const uint32_t frame_groups = (count + 7u) / 8u;
-  const uint32_t fi = xcd + 8u * (slot % frame_groups);
-  if (fi >= count) return;
-  const DevFrame& f = frames[first + fi];
-
-  __shared__ __attribute__((aligned(16))) uint2 s_slots[4][kSlotsPerWave];
-  constexpr uint32_t K = 4;                                  // items per ticket
-  static_assert(K == kTileScanGranule, "one look-back word per ticket");
-  const uint32_t n_tickets = (f.n_tiles + K - 1u) / K;
-  const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = lane_id();
-  uint2* slots = s_slots[wave];
-
-  uint32_t t_cur = 0, occ_cur = 0, dup_cur = 0, total_cur = 0;
-  uint32_t cnt_cur[K] = {0, 0, 0, 0};
-  bool have_cur = false;
-  Px4 gn0[K] = {}, gn1[K] = {}, gc0[K] = {}, gc1[K] = {};
-  for (;;) {
-    // ---- 1. the wave's next ticket.  Every wave of the frame stops at its first ticket past the end, so
-    // n_tickets + waves_per_frame tickets are drawn per launch: the last re-arms the counter.
-    uint32_t t = 0;
-    if (lane == 0) {
-      t = __hip_atomic_fetch_add(glw(f.ticket), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      if (t + 1u == n_tickets + waves_per_frame)
-        __hip_atomic_store(glw(f.ticket), 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    }
-    const uint32_t t_next = __builtin_amdgcn_readfirstlane(t);
-    const bool have_next = t_next < n_tickets;
-    uint64_t early = 0;
-    auto read_early = [&]() {                                  // see k_recon_tiles: any older state of a word is safe
-      if (have_cur && lane < t_cur)
-        early = __hip_atomic_load(gl(f.scan_state + (t_cur - 1u - lane)), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
-    };
-
-    // ---- 2. count the next ticket's items and publish their total ------------------------------------
-    uint32_t occ_next = 0, dup_next = 0, total_next = 0;
-    uint32_t cnt_next[K] = {0, 0, 0, 0};
-    if (have_next) {
-      uint32_t idx4[K];
-      Item it4[K];
-      Samples s4[K];
-      uint32_t raw[K];
-#pragma unroll
-      for (uint32_t i = 0; i < K; ++i) {
-        idx4[i] = t_next * K + i;
-        it4[i] = load_item(f.tiles + (idx4[i] < f.n_tiles ? idx4[i] : 0u));
-      }
-#pragma unroll
-      for (uint32_t i = 0; i < K; ++i) raw[i] = load_occupancy_raw(f, it4[i], lane);
-#pragma unroll
-      for (uint32_t i = 0; i < K; ++i) {
-        s4[i].occ = idx4[i] < f.n_tiles ? occupancy_bits(f, raw[i]) : 0u;   // past the end: an empty copy of item 0
-        if (variant & 512u) { s4[i].g0 = Px4{lane, 0u}; s4[i].g1 = Px4{0u, lane}; }
-        else load_geometry<false>(f, it4[i], lane, s4[i]);
-      }
-      read_early();
-#pragma unroll
-      for (uint32_t i = 0; i < K; ++i) {
-        const uint32_t dup = classify(f, it4[i], s4[i]) & s4[i].occ;
-        gn0[i] = s4[i].g0; gn1[i] = s4[i].g1;
-        occ_next |= s4[i].occ << (4u * i);
-        dup_next |= dup << (4u * i);
-        cnt_next[i] = wave_sum(2u * (uint32_t)__builtin_popcount(s4[i].occ) - (uint32_t)__builtin_popcount(dup));
-        total_next += cnt_next[i];
-      }
-      if (lane == 0)
-        st_store(f.scan_state + t_next, ((uint64_t)gen << kGenShift) | (t_next == 0 ? kPrefix : kAggregate) | total_next);
-    } else {
-      read_early();
-    }
-
-    // ---- 3. look back for and emit the current ticket --------------------------------------------------
-    if (have_cur) {
-      uint32_t excl = (variant & 1u) ? t_cur * 1750u : 0u;
-      if (t_cur != 0 && !(variant & 1u)) excl = look_back_groups(f, t_cur, gen, early);
-      Item it = load_item(f.tiles + (t_cur * K < f.n_tiles ? t_cur * K : 0u));
-      Samples cur = {};
-      cur.occ = occ_cur & 0xFu;
-      cur.g0 = gc0[0]; cur.g1 = gc1[0];
-      if (!(variant & 256u)) load_attributes(f, it, lane, cur);
-      if (lane == 0) {
-        if (t_cur != 0 && !(variant & 1u))
-          st_store(f.scan_state + t_cur, ((uint64_t)gen << kGenShift) | kPrefix | (uint64_t)(excl + total_cur));
-        if (t_cur + 1u == n_tickets)                                       // tile.total_number_of_regular_points
-          *glw(f.n_points) = (variant & 1u) ? (excl + total_cur < f.capacity ? excl + total_cur : f.capacity) : excl + total_cur;
-      }
-      uint32_t base = excl;
-      for (uint32_t i = 0; i < K; ++i) {
-        const uint32_t n = cnt_cur[0];
-        Item nit = it;
-        Samples nxt = {};
-        if (i + 1u < K) {
-          const uint32_t next_item = t_cur * K + i + 1u;
-          nit = load_item(f.tiles + (next_item < f.n_tiles ? next_item : 0u));
-          nxt.occ = (occ_cur >> (4u * (i + 1u))) & 0xFu;
-          nxt.g0 = gc0[1]; nxt.g1 = gc1[1];
-          if (!(variant & 256u)) load_attributes(f, nit, lane, nxt);
-        }
-        gc0[0] = gc0[1]; gc0[1] = gc0[2]; gc0[2] = gc0[3];                   // rotate: static register indices
-        gc1[0] = gc1[1]; gc1[1] = gc1[2]; gc1[2] = gc1[3];
-        cnt_cur[0] = cnt_cur[1]; cnt_cur[1] = cnt_cur[2]; cnt_cur[2] = cnt_cur[3];
-        emit_item(f, it, cur, (dup_cur >> (4u * i)) & 0xFu, n, base, lane, slots, variant, [&]() {
-          asm volatile("" : "+v"(nxt.y0.lo), "+v"(nxt.y0.hi), "+v"(nxt.y1.lo), "+v"(nxt.y1.hi));
-          asm volatile("" : "+v"(nxt.u0), "+v"(nxt.v0), "+v"(nxt.u1), "+v"(nxt.v1));
-        });
-        base += n;
-        it = nit;
-        cur = nxt;
-      }
-    }
-    if (!have_next) break;
-    t_cur = t_next;
-    occ_cur = occ_next;
-    dup_cur = dup_next;
-    total_cur = total_next;
-#pragma unroll
-    for (uint32_t i = 0; i < K; ++i) { gc0[i] = gn0[i]; gc1[i] = gn1[i]; cnt_cur[i] = cnt_next[i]; }
-    have_cur = true;
-  }
-}
-
 }  // namespace vpcc
 
 #ifdef VPCC_DIAGNOSTIC
@@ -1101,16 +888,8 @@ void launch_tiles(const DevFrame* d_frames, uint32_t first, uint32_t count, uint
     return;
   }
 #endif
-#if VPCC_TILES_STRUCTURE == 4
-  hipLaunchKernelGGL(k_recon_tiles_wave<false>, dim3(grid), dim3(256), 0, (hipStream_t)stream, d_frames, first, count,
-                     4u * wgs, gen, variant);
-#elif VPCC_TILES_STRUCTURE == 2
-  hipLaunchKernelGGL(k_recon_tiles_resident<false>, dim3(grid), dim3(256), 0, (hipStream_t)stream, d_frames, first, count,
-                     wgs, gen, variant);
-#else
   hipLaunchKernelGGL(k_recon_tiles<false>, dim3(grid), dim3(256), 0, (hipStream_t)stream, d_frames, first, count,
                      wgs, gen, variant);
-#endif
 }
 
 }  // namespace vpcc
