@@ -111,11 +111,13 @@ static_assert(sizeof(SmoothCell) == 24, "SmoothCell is 24 B");
 // launches) and the cell index of every point as the statistics kernel saw it (the geometry filter moves
 // points in place, so the cells to clear afterwards cannot be recomputed from the positions).
 struct SmoothGrid {
-  unsigned char* base;        // cells of frame slot j at base + j * slot_bytes (w^3 cells; this region is all-zero between launches)
+  unsigned char* base;        // frame slot j at base + j * slot_bytes: [w^3 cells | w^3 flag bytes], all-zero between launches
   size_t slot_bytes;
+  size_t flags_offset;        // bytes from the slot's start to its flags
   uint32_t* key_base;         // cell indices of frame slot j at key_base + j * key_stride (their own allocation: no zero invariant)
   size_t key_stride;
   VPCC_HD SmoothCell* cells(uint32_t j) const { return reinterpret_cast<SmoothCell*>(base + j * slot_bytes); }
+  VPCC_HD unsigned char* flags(uint32_t j) const { return base + j * slot_bytes + flags_offset; }
   VPCC_HD uint32_t* keys(uint32_t j) const { return key_base + j * key_stride; }
 };
 
@@ -125,8 +127,10 @@ void launch_smooth_apply_geometry(const DevFrame* d_frames, uint32_t first, uint
                                   SmoothGrid sg, uint32_t w, uint32_t G, uint32_t T, void* stream);
 void launch_smooth_apply_color(const DevFrame* d_frames, uint32_t first, uint32_t count, uint32_t max_points,
                                SmoothGrid sg, uint32_t w, uint32_t G, uint32_t Ts, uint32_t Td, void* stream);
+void launch_smooth_mark(const DevFrame* d_frames, uint32_t first, uint32_t count, uint32_t max_points, SmoothGrid sg,
+                        uint32_t w, void* stream);
 void launch_smooth_clear(const DevFrame* d_frames, uint32_t first, uint32_t count, uint32_t max_points, SmoothGrid sg,
-                         void* stream);
+                         uint32_t w, void* stream);
 
 // Kernel launchers (vpcc_kernels.hip).  All asynchronous on `stream`.
 void launch_block_owner(const DevFrame* d_frames, uint32_t first, uint32_t count, uint32_t max_vb,

@@ -736,7 +736,8 @@ extern "C" int vpcc_gof_smooth(vpcc_gof* g, uint32_t first, uint32_t count, cons
     // between launches (k_smooth_clear restores what a launch touched), so it is cleared only when it is
     // (re)allocated or after a failed launch.
     SmoothGrid sg{};
-    sg.slot_bytes = align_up(cells * sizeof(SmoothCell), 256);
+    sg.flags_offset = align_up(cells * sizeof(SmoothCell), 256);
+    sg.slot_bytes = align_up(sg.flags_offset + cells, 256);
     sg.key_stride = g->capacity;
     if (!g->smooth_keys) HIP_TRY(ctx, hipMalloc(&g->smooth_keys, sizeof(uint32_t) * g->capacity * g->n_frames));
     sg.key_base = (uint32_t*)g->smooth_keys;
@@ -761,6 +762,9 @@ extern "C" int vpcc_gof_smooth(vpcc_gof* g, uint32_t first, uint32_t count, cons
       T.begin(geo ? "k_smooth_stats<geometry>" : "k_smooth_stats<color>");
       launch_smooth_stats(g->d_frames, c0, c, max_points, sg, w, G, geo ? 0u : 1u, s);
       T.end();
+      T.begin(geo ? "k_smooth_mark<geometry>" : "k_smooth_mark<color>");
+      launch_smooth_mark(g->d_frames, c0, c, max_points, sg, w, s);
+      T.end();
       T.begin(geo ? "k_smooth_apply_geometry" : "k_smooth_apply_color");
       if (geo)
         launch_smooth_apply_geometry(g->d_frames, c0, c, max_points, sg, w, G, p->threshold, s);
@@ -769,7 +773,7 @@ extern "C" int vpcc_gof_smooth(vpcc_gof* g, uint32_t first, uint32_t count, cons
                                   p->color_threshold_difference, s);
       T.end();
       T.begin(geo ? "k_smooth_clear<geometry>" : "k_smooth_clear<color>");
-      launch_smooth_clear(g->d_frames, c0, c, max_points, sg, s);
+      launch_smooth_clear(g->d_frames, c0, c, max_points, sg, w, s);
       T.end();
       HIP_TRY(ctx, hipGetLastError());
       g->smooth_clean = true;

@@ -4,13 +4,14 @@
 // src/codec.rs:498-500); the behaviour is this repository's own integer specification "gs1"/"cs1",
 // written down in oracle/vpcc_smoothing_spec.h and tested bit for bit against its CPU form.
 //
-// Three kernels per filter, one thread per point (the clearing kernel: per touched cell):
+// Four kernels per filter, one thread per point:
 //   k_smooth_stats : per occupied grid cell {count, 3 sums, max(65535 - patch), max(patch)} with atomics into
-//                    a dense w^3 grid that is all-zero between launches; records the cells it touches;
-//   k_smooth_apply : 2x2x2 cell neighbourhood -> stop unless a cell mixes patches -> integer trilinear
-//                    weights -> centroid / mean, thresholded replacement in place (a thread reads only its
-//                    own point and the grid);
-//   k_smooth_clear : zeroes exactly the touched cells again.
+//                    a dense w^3 grid that is all-zero between launches; keeps every point's cell index;
+//   k_smooth_mark  : paints a byte flag around every cell that mixes patches;
+//   k_smooth_apply : one flag load; only flagged points read their 2x2x2 cells -> integer trilinear weights
+//                    -> centroid / mean, thresholded replacement in place (a thread reads only its own point
+//                    and the grid);
+//   k_smooth_clear : un-paints the flags and zeroes exactly the touched cells again.
 #include <hip/hip_runtime.h>
 
 #include "vpcc_device.hpp"
@@ -44,8 +45,14 @@ __device__ __forceinline__ void axis_setup(uint32_t p, uint32_t G, uint32_t w, i
 
 }  // namespace
 
-// Wave-wide sum / packed-16-bit max with DPP row shifts and row broadcasts (no LDS); the result is valid in lane 63.
 typedef uint16_t u16x2 __attribute__((ext_vector_type(2)));
+// value of lane - kShift within the lane's row of 16 (DPP row_shr); `outside` where there is no such lane
+template <int kShift>
+__device__ __forceinline__ uint32_t row_shr(uint32_t v, uint32_t outside) {
+  return (uint32_t)__builtin_amdgcn_update_dpp((int)outside, (int)v, 0x110 + kShift, 0xF, 0xF, false);
+}
+
+// Wave-wide sum / packed-16-bit max with DPP row shifts and row broadcasts (no LDS); the result is valid in lane 63.
 template <int kCtrl, int kRowMask, bool kPkMax>
 __device__ __forceinline__ uint32_t dpp_step(uint32_t v) {
   const uint32_t o = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, kCtrl, kRowMask, 0xF, kRowMask == 0xF);
@@ -69,8 +76,12 @@ __device__ __forceinline__ uint32_t wave_reduce(uint32_t v) {
 // 16 pixels spans two cells of size 8).  The wave reduces its points per distinct cell first and issues ONE
 // set of atomics per cell (six lanes, one word each, nothing returned).  The grids are all-zero between
 // launches: every point's cell index is kept, and k_smooth_clear zeroes exactly those cells afterwards — no
-// dense memset (50 MB per frame at w = 128) per launch.  (A list of touched cells fed by the first adder of
-// each cell needs RETURNING atomics and one hot list counter per frame: 8.9 ms per 32 frames instead of 0.3.)
+// dense memset (50 MB per frame at w = 128) per launch.
+// Measured alternatives, per 32 S-longdress frames (this form: 0.31 ms): one set of atomics per point 17.5 ms; a
+// list of touched cells fed by RETURNING atomics and one list counter per frame 8.9 ms; runs of equal cells
+// reduced by a segmented DPP scan inside rows of 16 lanes with six atomics per run 2.7 ms (30 M atomics: the L2
+// retires ~12 per ns); the same merged through an LDS table with ds_cmpst/ds_add per workgroup 0.62-0.70 ms
+// (LDS atomic time).
 __global__ __launch_bounds__(256) void k_smooth_stats(const DevFrame* __restrict__ frames, uint32_t first,
                                                       SmoothGrid sg, uint32_t w, uint32_t G, uint32_t mode) {
   const DevFrame& f = frames[first + blockIdx.y];
@@ -112,17 +123,47 @@ __global__ __launch_bounds__(256) void k_smooth_stats(const DevFrame* __restrict
   }
 }
 
-// Restores the all-zero state of the cells this launch touched: one thread per point, the first lane of every
-// run of equal cell indices writes the zeros (several runs may clear one cell; that is harmless).
-__global__ __launch_bounds__(256) void k_smooth_clear(const DevFrame* __restrict__ frames, uint32_t first, SmoothGrid sg) {
+namespace {
+__device__ __forceinline__ bool cell_mixed(const SmoothCell& c) { return c.count != 0 && (65535u - c.negminp) != c.maxp; }
+
+// Writes `value` into the flag of every cell of the 3x3x3 block around cell `key` (clipped to the grid).
+__device__ __forceinline__ void paint_flags(unsigned char* flags, uint32_t key, uint32_t w, unsigned char value) {
+  const int32_t cx = (int32_t)(key % w), cy = (int32_t)((key / w) % w), cz = (int32_t)(key / (w * w));
+  for (int32_t z = max(cz - 1, 0); z <= min(cz + 1, (int32_t)w - 1); ++z)
+    for (int32_t y = max(cy - 1, 0); y <= min(cy + 1, (int32_t)w - 1); ++y)
+      for (int32_t x = max(cx - 1, 0); x <= min(cx + 1, (int32_t)w - 1); ++x)
+        flags[((size_t)z * w + y) * w + x] = value;
+}
+}  // namespace
+
+// A filter changes a point only if one of the 2x2x2 cells around it holds points of more than one patch
+// ("mixed"), and those eight cells always lie in the 3x3x3 block around the point's own cell.  This pass
+// paints a byte flag on the 3x3x3 block around every mixed cell, so that the filter kernels decide with ONE
+// byte load whether a point needs its eight 24-byte cells at all (few do: patch boundaries).
+__global__ __launch_bounds__(256) void k_smooth_mark(const DevFrame* __restrict__ frames, uint32_t first, SmoothGrid sg,
+                                                     uint32_t w) {
   const DevFrame& f = frames[first + blockIdx.y];
   const uint32_t n = min(*gl(f.n_points), f.capacity);
   const uint32_t i = blockIdx.x * 256u + threadIdx.x;
   if (i >= n) return;
   const uint32_t key = sg.keys(blockIdx.y)[i];
-  const uint32_t prev = (uint32_t)__builtin_amdgcn_update_dpp((int)~key, (int)key, 0x111, 0xF, 0xF, false);   // row_shr:1
-  if (prev == key) return;
-  uint2* c = reinterpret_cast<uint2*>(sg.cells(blockIdx.y) + key);
+  if (row_shr<1>(key, ~key) == key) return;                 // one lane per run of equal cells is enough
+  if (cell_mixed(gload(sg.cells(blockIdx.y) + key))) paint_flags(sg.flags(blockIdx.y), key, w, 1);
+}
+
+// Restores the all-zero state: the first lane of every run of equal cell indices un-paints the flags of a mixed
+// cell and zeroes the cell (several runs may clear one cell; the first to read it still sees it mixed).
+__global__ __launch_bounds__(256) void k_smooth_clear(const DevFrame* __restrict__ frames, uint32_t first, SmoothGrid sg,
+                                                      uint32_t w) {
+  const DevFrame& f = frames[first + blockIdx.y];
+  const uint32_t n = min(*gl(f.n_points), f.capacity);
+  const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+  if (i >= n) return;
+  const uint32_t key = sg.keys(blockIdx.y)[i];
+  if (row_shr<1>(key, ~key) == key) return;
+  SmoothCell* cell = sg.cells(blockIdx.y) + key;
+  if (cell_mixed(gload(cell))) paint_flags(sg.flags(blockIdx.y), key, w, 0);
+  uint2* c = reinterpret_cast<uint2*>(cell);
   c[0] = make_uint2(0u, 0u); c[1] = make_uint2(0u, 0u); c[2] = make_uint2(0u, 0u);
 }
 
@@ -153,6 +194,7 @@ __global__ __launch_bounds__(256) void k_smooth_apply_geometry(const DevFrame* _
   const uint32_t n = min(*gl(f.n_points), f.capacity);
   const uint32_t i = blockIdx.x * 256u + threadIdx.x;
   if (i >= n) return;
+  if (!sg.flags(blockIdx.y)[sg.keys(blockIdx.y)[i]]) return;        // no mixed cell anywhere near this point (k_smooth_mark)
   const vpcc_point3 pt = gload(f.out_xyz + i);
   const uint32_t p[3] = {pt.x, pt.y, pt.z};
   int32_t s[3];
@@ -192,6 +234,7 @@ __global__ __launch_bounds__(256) void k_smooth_apply_color(const DevFrame* __re
   const uint32_t n = min(*gl(f.n_points), f.capacity);
   const uint32_t i = blockIdx.x * 256u + threadIdx.x;
   if (i >= n) return;
+  if (!sg.flags(blockIdx.y)[sg.keys(blockIdx.y)[i]]) return;        // no mixed cell anywhere near this point (k_smooth_mark)
   const vpcc_point3 pt = gload(f.out_xyz + i);
   const uint32_t p[3] = {pt.x, pt.y, pt.z};
   int32_t s[3];
@@ -259,11 +302,17 @@ void launch_smooth_apply_color(const DevFrame* d_frames, uint32_t first, uint32_
   hipLaunchKernelGGL(k_smooth_apply_color, dim3((max_points + 255) / 256, count), dim3(256), 0, (hipStream_t)stream,
                      d_frames, first, sg, w, G, Ts, Td);
 }
+void launch_smooth_mark(const DevFrame* d_frames, uint32_t first, uint32_t count, uint32_t max_points, SmoothGrid sg,
+                        uint32_t w, void* stream) {
+  if (!count || !max_points) return;
+  hipLaunchKernelGGL(k_smooth_mark, dim3((max_points + 255) / 256, count), dim3(256), 0, (hipStream_t)stream, d_frames,
+                     first, sg, w);
+}
 void launch_smooth_clear(const DevFrame* d_frames, uint32_t first, uint32_t count, uint32_t max_points, SmoothGrid sg,
-                         void* stream) {
+                         uint32_t w, void* stream) {
   if (!count || !max_points) return;
   hipLaunchKernelGGL(k_smooth_clear, dim3((max_points + 255) / 256, count), dim3(256), 0, (hipStream_t)stream, d_frames,
-                     first, sg);
+                     first, sg, w);
 }
 
 }  // namespace vpcc
