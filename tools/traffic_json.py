@@ -1,37 +1,59 @@
 #!/usr/bin/env python3
-"""Builds profiles/rNN/traffic.json from a tools/profile_round.sh output directory.
-Usage: tools/traffic_json.py <profile_round_outdir> <round> > profiles/rNN/traffic.json"""
-import csv, glob, json, os, sys
-root, rnd = sys.argv[1], int(sys.argv[2])
+"""Builds profiles/rNN/traffic*.json from a tools/profile_round.sh output directory.
+Usage: tools/traffic_json.py <profile_round_outdir> <round> <kernel substring> "<workload text>" > profiles/rNN/traffic.json"""
+import collections, csv, glob, json, os, sys
+root, rnd, kernel, workload = sys.argv[1], int(sys.argv[2]), sys.argv[3], sys.argv[4]
 
 
-def mean_counter(sub, counter, kernel, first_only=False):
-    vals = []
+def means(sub, kern):
+    acc = collections.defaultdict(list)
     for f in glob.glob(os.path.join(root, sub, "**", "*counter_collection.csv"), recursive=True):
         for r in csv.DictReader(open(f)):
-            if r["Kernel_Name"].startswith(kernel) and r["Counter_Name"] == counter:
-                vals.append(float(r["Counter_Value"]))
-    if first_only:                 # the micro-benchmark's first dispatch is the calibration case (feat 0)
-        vals = vals[:1]
-    return sum(vals) / len(vals), len(vals)
+            if kern in r["Kernel_Name"]:
+                acc[r["Counter_Name"]].append(float(r["Counter_Value"]))
+    return {k: sum(v) / len(v) for k, v in acc.items()}, {k: len(v) for k, v in acc.items()}
 
 
-fetch, nf = mean_counter("pmc_FETCH_SIZE", "FETCH_SIZE", "void vpcc::k_recon_tiles")
-write, nw = mean_counter("pmc_WRITE_SIZE", "WRITE_SIZE", "void vpcc::k_recon_tiles")
-cal_f, _ = mean_counter("cal_FETCH_SIZE", "FETCH_SIZE", "k(", True)
-cal_w, _ = mean_counter("cal_WRITE_SIZE", "WRITE_SIZE", "k(", True)
-READ_KNOWN, WRITE_KNOWN = 576716800, 519045120          # tools/micro/tile_feat.hip, feat 0
-fr, wr = cal_f * 1024 / READ_KNOWN, cal_w * 1024 / WRITE_KNOWN
-corr = round(1.0 / fr)
-rd, wrb = int(fetch * 1024 * corr), int(write * 1024)
+f, nf = means("pmc_FETCH_SIZE", kernel)
+w, nw = means("pmc_WRITE_SIZE", kernel)
+rd, nrd = means("pmc_rd", kernel)
+wr, _ = means("pmc_wr", kernel)
+exact_rd = 32 * rd.get("TCC_EA0_RDREQ_32B_sum", 0) + 64 * rd.get("TCC_EA0_RDREQ_64B_sum", 0) + 128 * rd.get("TCC_EA0_RDREQ_128B_sum", 0)
+w64 = wr.get("TCC_EA0_WRREQ_64B_sum", 0)
+exact_wr = 64 * w64 + 32 * (wr.get("TCC_EA0_WRREQ_sum", 0) - w64)
+fetch_b, write_b = f.get("FETCH_SIZE", 0) * 1024, w.get("WRITE_SIZE", 0) * 1024
+# calibration: sparse_read reads K of every 4 tiles of each 128-B line; whole lines arrive whatever K is
+cal = []
+per = collections.defaultdict(dict)
+for p in glob.glob(os.path.join(root, "sparse_rd", "**", "*counter_collection.csv"), recursive=True):
+    for r in csv.DictReader(open(p)):
+        if "k_sparse" in r["Kernel_Name"]:
+            per[int(r["Dispatch_Id"])][r["Counter_Name"]] = float(r["Counter_Value"])
+fs = {}
+for p in glob.glob(os.path.join(root, "sparse_FETCH_SIZE", "**", "*counter_collection.csv"), recursive=True):
+    for r in csv.DictReader(open(p)):
+        if "k_sparse" in r["Kernel_Name"] and r["Counter_Name"] == "FETCH_SIZE":
+            fs[int(r["Dispatch_Id"])] = float(r["Counter_Value"]) * 1024
+cfg = [(4, 0), (2, 0), (1, 0), (3, 0), (4, 1), (1, 1)]
+tiles, frames, planes = 80 * 88, 32, 5
+ids, fids = sorted(per), sorted(fs)
+for i, (K, rs) in enumerate(cfg):
+    if 3 * i < len(ids):
+        c = per[ids[3 * i]]
+        cal.append({"tiles_read_of_4_per_line": K, "even_rows_only": bool(rs),
+                    "requested_bytes": tiles / 4 * K * frames * planes * 512 / (2 if rs else 1),
+                    "distinct_128B_line_bytes": tiles / 4 * frames * planes * 16 / (2 if rs else 1) * 128,
+                    "counted_read_bytes": 32 * c.get("TCC_EA0_RDREQ_32B_sum", 0) + 64 * c.get("TCC_EA0_RDREQ_64B_sum", 0) + 128 * c.get("TCC_EA0_RDREQ_128B_sum", 0),
+                    "FETCH_SIZE_bytes": fs.get(fids[3 * i]) if 3 * i < len(fids) else None})
 print(json.dumps({
-    "round": rnd, "kernel": "vpcc::k_recon_tiles<false>", "workload": "S-longdress, 32 frames per launch",
-    "command": "tools/profile_round.sh: rocprofv3 --kernel-trace --pmc FETCH_SIZE | WRITE_SIZE (separate passes) -- python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline --profile-steps 1",
-    "launches_averaged": [nf, nw],
-    "FETCH_SIZE_KB_raw_mean": fetch, "WRITE_SIZE_KB_mean": write,
-    "calibration": {"binary": "tools/micro/bin/tile_feat (feat 0: one 16x16 u16 tile per wave, 8 B/lane, known byte counts)",
-                    "read_bytes_known": READ_KNOWN, "FETCH_SIZE_KB": cal_f, "fetch_ratio": fr,
-                    "write_bytes_known": WRITE_KNOWN, "WRITE_SIZE_KB": cal_w, "write_ratio": wr,
-                    "note": "FETCH_SIZE reports one half of the bytes for this access pattern (MI355X_MICROARCH.md: gfx950 tallies 128-B requests at 64 B); WRITE_SIZE is exact"},
-    "fetch_correction": corr, "hbm_read_bytes_per_launch": rd, "hbm_write_bytes_per_launch": wrb,
-    "hbm_bytes_per_launch": rd + wrb}, indent=1))
+    "round": rnd, "kernel": kernel, "workload": workload,
+    "source": "rocprofv3 --kernel-trace --pmc, separate passes (tools/profile_round.sh); reads = 2 x FETCH_SIZE as "
+              "MI355X_MICROARCH.md prescribes for gfx950, cross-checked by the exact request-size counters; writes = WRITE_SIZE",
+    "launches_averaged": {"FETCH_SIZE": nf.get("FETCH_SIZE", 0), "WRITE_SIZE": nw.get("WRITE_SIZE", 0), "request_counters": max(nrd.values()) if nrd else 0},
+    "FETCH_SIZE_bytes_raw": fetch_b, "fetch_correction": 2, "WRITE_SIZE_bytes": write_b,
+    "exact_read_bytes": exact_rd, "exact_write_bytes": exact_wr,
+    "read_requests": rd, "write_requests": wr,
+    "l2_hit_rate": (wr.get("TCC_HIT_sum", 0) / (wr.get("TCC_HIT_sum", 0) + wr.get("TCC_MISS_sum", 1))) if wr else None,
+    "hbm_read_bytes_per_launch": int(2 * fetch_b), "hbm_write_bytes_per_launch": int(write_b),
+    "hbm_bytes_per_launch": int(2 * fetch_b + write_b),
+    "calibration_sparse_read": cal}, indent=1))
