@@ -88,3 +88,14 @@ def test_capacity_bound():
     lib = _abi.load_library()
     d, keep = _abi.host_frame_desc(synth.small_frame(0))
     assert lib.vpcc_frame_capacity_bound(C.byref(d)) == 2 * 64 * 64
+
+
+def test_product_library_has_no_diagnostic_switches():
+    """The timing ablations / in-kernel stamps of the tile kernel exist in libvpcc_recon_diag.so only
+    (make diag, -DVPCC_DIAGNOSTIC): the product neither exports the diagnostic entry point nor knows the
+    environment variables that select an ablation."""
+    lib = _abi.load_library()
+    assert not hasattr(lib, "vpcc_debug_read_stamps")
+    blob = open(_abi.LIB_PATH, "rb").read()
+    for name in (b"VPCC_TILES_VARIANT", b"VPCC_TILES_DEPTH"):
+        assert name not in blob, name
