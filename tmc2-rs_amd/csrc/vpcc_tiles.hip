@@ -482,7 +482,7 @@ __device__ __forceinline__ void store_rgb(VPCC_GLOBAL unsigned char* base, uint3
 }  // namespace
 
 // `variant_arg`: ignored by the product build.  Diagnostic build (VPCC_TILES_VARIANT): timing/traffic-only
-// ablation bits: 1 skip look-back wait, 8 skip colour conversion, 16 skip the lane<->point loop, 32 skip only its
+// ablation bits: 1 skip look-back wait, 2 look back but place the outputs as ablation 1 does, 8 skip colour conversion, 16 skip the lane<->point loop, 32 skip only its
 // stores, 64 in-kernel stamps, 128 no geometry re-read in the emit phase, 256 no attribute loads, 512 no
 // count-phase geometry loads.  Outputs of an ablated run are wrong by construction.
 //
@@ -492,9 +492,8 @@ __device__ __forceinline__ void store_rgb(VPCC_GLOBAL unsigned char* base, uint3
 // its total was published, when the totals of the earlier tickets have long arrived: the wait that
 // cost a quarter of the kernel in the count -> look back -> emit form is gone, and the plane loads
 // of the next group overlap the stores of the current one across the waves of a CU.
-// Register budget: 4 waves per SIMD.  Measured (tools/waves.sh): 3..5 waves per SIMD are within 3 % of each
-// other, 4 is marginally best (fewer workgroups in flight keep more of the twice-read geometry in the L2),
-// 6 and more spill.
+// Register budget: 4 waves per SIMD.  Measured (tools/ab.sh): 3 waves 0.139, 4 waves 0.126, 5 waves (spills)
+// 0.143 ms.
 #ifndef VPCC_TILES_WAVES_PER_EU
 #define VPCC_TILES_WAVES_PER_EU 4
 #endif
@@ -750,6 +749,8 @@ void k_recon_tiles(const DevFrame* __restrict__ frames, uint32_t first,
       // delivery of them here waits for nothing.
       uint32_t excl = (variant & 1u) ? g_cur * 7000u : 0u;   // ablation: no wait, outputs still spread over the frame
       if (g_cur != 0 && !(variant & 1u)) excl = look_back_groups(f, g_cur, gen, early);
+      // ablation 2: the look-back runs (all its waits), but the outputs go to the spread positions of ablation 1
+      if (variant & 2u) { asm volatile("" :: "v"(excl)); excl = g_cur * 7000u; }
       // the speculative read is complete on EVERY path from here on (group 0 never looks at it): a pending
       // load into registers the item loop reuses would cost a vmcnt(0) — a wait for the output stores — per item
       asm volatile("" : "+v"(early));
@@ -766,7 +767,7 @@ void k_recon_tiles(const DevFrame* __restrict__ frames, uint32_t first,
         if (g_cur != 0 && !(variant & 1u))
           st_store(f.scan_state + g_cur, ((uint64_t)gen << kGenShift) | kPrefix | (uint64_t)(excl + total_cur));
         if (g_cur + 1u == n_groups)                                        // tile.total_number_of_regular_points
-          *glw(f.n_points) = (variant & 1u) ? (excl + total_cur < f.capacity ? excl + total_cur : f.capacity) : excl + total_cur;
+          *glw(f.n_points) = (variant & 3u) ? (excl + total_cur < f.capacity ? excl + total_cur : f.capacity) : excl + total_cur;
       }
       VPCC_STAMP(4)
       uint32_t base = excl;
