@@ -484,7 +484,8 @@ __device__ __forceinline__ void store_rgb(VPCC_GLOBAL unsigned char* base, uint3
 // `variant_arg`: ignored by the product build.  Diagnostic build (VPCC_TILES_VARIANT): timing/traffic-only
 // ablation bits: 1 skip look-back wait, 2 look back but place the outputs as ablation 1 does, 8 skip colour conversion, 16 skip the lane<->point loop, 32 skip only its
 // stores, 64 in-kernel stamps, 128 no geometry re-read in the emit phase, 256 no attribute loads, 512 no
-// count-phase geometry loads.  Outputs of an ablated run are wrong by construction.
+// count-phase geometry loads, 1024 memory skeleton (all loads, waits and stores, none of the per-item arithmetic
+// or LDS traffic).  Outputs of an ablated run are wrong by construction.
 //
 // Every workgroup is a short pipeline over the groups of ONE frame: it draws a ticket, counts that
 // group and publishes the group total BEFORE it looks back for and emits the group it counted one
@@ -538,6 +539,31 @@ __device__ __forceinline__ void emit_item(const DevFrame& f, const Item& it, con
     // Same counter state on both paths: were the prefetched samples still pending here, the compiler would
     // have to wait for vmcnt(0) where the paths join — i.e. for this wave's output stores, after every item.
     before_stores();
+    return;
+  }
+  if (variant & 1024u) {
+    // Diagnostic "memory skeleton": the item's loads were issued and are waited for, its stores go to the same
+    // addresses with the same instructions — but no ranks, colours, records or back-projection.  What this
+    // build takes is what the kernel's memory behaviour and control flow cost on their own.
+    asm volatile("" ::"v"(cur.y0.lo), "v"(cur.y0.hi), "v"(cur.y1.lo), "v"(cur.y1.hi), "v"(cur.u0), "v"(cur.v0), "v"(cur.u1), "v"(cur.v1),
+                 "v"(cur.g0.lo), "v"(cur.g1.lo));
+    before_stores();
+    const uint32_t room = base < f.capacity ? f.capacity - base : 0u, nw = n < room ? n : room;
+    for (uint32_t k = 2u * lane; k < nw; k += 128u) {
+      const uint2 p0 = make_uint2(k, lane), p1 = make_uint2(lane, k);
+      if (k + 1u < nw) {
+        store_xyz2(gx, (base + k) * 6u, p0, p1);
+        if (f.has_attr) {
+          if (!(lane & 1u) && k + 3u < nw) {
+            u32x3 o; o.x = k; o.y = lane; o.z = k;
+            out_store<u32x3_a2>(gc + (base + k) * 3u, o);
+          } else if (!((lane & 1u) && k + 1u < nw)) store_rgb2(gc, (base + k) * 3u, k, lane);
+        }
+      } else {
+        store_xyz(gx, (base + k) * 6u, p0);
+        if (f.has_attr) store_rgb(gc, (base + k) * 3u, k);
+      }
+    }
     return;
   }
   uint32_t rk[4];
