@@ -145,3 +145,51 @@ def test_parser_reads_the_hand_assembled_stream():
             assert getattr(got, k) == v, (k, getattr(got, k), v)
     assert s.next_gof() is None
     s.close()
+
+
+# ---------------------------------------------------------------- prefix SEI (geometry smoothing) and a second frame
+SEI_BITS = "".join([
+    u(66, 8),                               # payload type GeometrySmoothing = 66, one byte < 0xff     :1379-1386, enum :1362
+    u(5, 8),                                # payload size (read and ignored)                          :1388-1394
+    u(1, 1), u(0, 1), u(1, 8),              # persistence 1, reset 0, instances_updated 1              :1470-1473
+    u(0, 8), u(0, 1),                       # instance index 0, cancel flag 0                          :1486-1488
+    ue(1),                                  # method type 1 (grid smoothing)                           :1492
+    u(0, 1), u(6, 7), u(64, 8),             # filter_eom_points 0, grid_size_minus_2 6, threshold 64   :1494-1496
+])                                          # byte_align(), then ONE more byte is read                 :1410-1411
+SEI_HEX = "4205804008190200"      # 42 05 | 1 0 00000001 00000000 0 010 0 0000110 01000000 | 1 + padding | the extra byte
+
+TILE2_BITS = "".join([                      # NAL type TRAIL_R (1): no no_output_of_prior_atlas_frames_flag
+    ue(0), ue(0), ue(1),                    # afps id, aaps id, tile type I                            :1586-1603
+    u(1, 4),                                # atlas_frame_order_cnt_lsb = 1: the second frame          :1610-1611
+    u(1, 1), u(2, 5), u(0, 5),              # list from the ASPS, quantizers as in the first tile      :1612-1661
+])
+DATA2_BITS = "".join([ue(0), ue(3), ue(0), ue(0), ue(0), u(1, 10), u(2, 10), u(3, 8), u(0, 3), u(0, 3)]) + ue(14)
+
+
+def test_hand_assembled_sei_and_second_frame():
+    assert pack(SEI_BITS).hex() + "00" == SEI_HEX            # + the extra byte the reference consumes after byte_align
+    # 1 1 010 | 0001 | 1 | 00010 | 00000 | trailing 1 -> 1101 0000 1100 0100 0000 1000
+    assert pack(TILE2_BITS).hex() == "d0c408"
+
+    def sized(payload):
+        return len(payload).to_bytes(4, "big") + payload
+    atl1 = nal_header(23) + bytes.fromhex(TILE_HEX) + bytes.fromhex(DATA_HEX)
+    atl2 = nal_header(1) + pack(TILE2_BITS) + pack(DATA2_BITS)
+    ad = (AD_HEADER + NAL_STREAM_HEADER + sized(nal_header(36) + bytes.fromhex(ASPS_HEX)) +
+          sized(nal_header(37) + bytes.fromhex(AFPS_HEX)) + sized(nal_header(43) + bytes.fromhex(SEI_HEX)) +     # PREFIX_NSEI = 43
+          sized(atl1) + sized(atl2))
+    ovd = pack(u(2, 5) + u(0, 4) + u(0, 6) + u(0, 17), trailing=False) + b"o"
+    gvd = pack(u(3, 5) + u(0, 4) + u(0, 6) + u(0, 4) + u(0, 1) + u(0, 12), trailing=False) + b"g"
+    avd = pack(u(4, 5) + u(0, 4) + u(0, 6) + u(0, 7) + u(0, 5) + u(0, 4) + u(0, 1), trailing=False) + b"a"
+    data = pack(u(3, 3) + u(0, 5), trailing=False) + b"".join(sized(x) for x in (bytes.fromhex(VPS_HEX), ad, ovd, gvd, avd))
+    s = recon.V3cStream(data)
+    info = s.next_gof()
+    assert info["frame_count"] == 2
+    assert info["geometry_smoothing_sei"] == 1 and info["smoothing_grid_size"] == 8 and info["smoothing_threshold"] == 64
+    fi0, p0 = s.frame_patches(0)
+    fi1, p1 = s.frame_patches(1)
+    assert (fi0, len(p0)) == (0, 2) and (fi1, len(p1)) == (1, 1)
+    g = p1[0]                                                # projection 0: axes (0, 2, 1), mode 0, d1 = 3 * 4
+    assert (g.u0, g.v0, g.size_u0, g.size_v0, g.u1, g.v1, g.d1) == (3, 0, 1, 1, 1, 2, 12)
+    assert (g.normal_axis, g.tangent_axis, g.bitangent_axis, g.projection_mode, g.orientation) == (0, 2, 1, 0, 0)
+    s.close()
