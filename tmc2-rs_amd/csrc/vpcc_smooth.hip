@@ -80,8 +80,10 @@ __device__ __forceinline__ uint32_t wave_reduce(uint32_t v) {
 // Measured alternatives, per 32 S-longdress frames (this form: 0.31 ms): one set of atomics per point 17.5 ms; a
 // list of touched cells fed by RETURNING atomics and one list counter per frame 8.9 ms; runs of equal cells
 // reduced by a segmented DPP scan inside rows of 16 lanes with six atomics per run 2.7 ms (30 M atomics: the L2
-// retires ~12 per ns); the same merged through an LDS table with ds_cmpst/ds_add per workgroup 0.62-0.70 ms
-// (LDS atomic time).
+// retires ~12 per ns); the same merged through an LDS table with ds_cmpst/ds_add per workgroup 0.62-0.70 ms;
+// every point added with LDS atomics into an 8x8x8-cell window of the grid held in LDS, occupied cells flushed
+// with six global atomics each 1.19 ms (lanes of one instruction that hit the same LDS word are served one at a
+// time, ~4 cycles each).
 __global__ __launch_bounds__(256) void k_smooth_stats(const DevFrame* __restrict__ frames, uint32_t first,
                                                       SmoothGrid sg, uint32_t w, uint32_t G, uint32_t mode) {
   const DevFrame& f = frames[first + blockIdx.y];
