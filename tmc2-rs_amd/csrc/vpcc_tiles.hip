@@ -508,6 +508,12 @@ __device__ __forceinline__ void store_rgb(VPCC_GLOBAL unsigned char* base, uint3
 #ifndef VPCC_TILES_RGB_QUADS
 #define VPCC_TILES_RGB_QUADS 1
 #endif
+// Static wave priorities (s_setprio) for the phases that feed the memory pipeline or that other workgroups wait
+// for: 1 the store loop, 2 count + publication of the group total, 4 the issue of the next item's loads.  Each is
+// worth 0.7-1.4 % (tools/ab.sh), together 2.5 %; holding the priority through the look-back as well costs 5 %.
+#ifndef VPCC_TILES_SETPRIO
+#define VPCC_TILES_SETPRIO 7
+#endif
 #ifndef VPCC_TILES_UNROLL_ITEMS
 #define VPCC_TILES_UNROLL_ITEMS 1
 #endif
@@ -585,6 +591,9 @@ __device__ __forceinline__ void emit_item(const DevFrame& f, const Item& it, con
   put_records<3>(cur, dup, pix0 + 3u * pstep, rk[3], dump, rgb0, rgb1, slots);
   wave_sync();                                      // records written by other lanes are read below
   before_stores();
+#if VPCC_TILES_SETPRIO & 1
+  __builtin_amdgcn_s_setprio(1);                    // the store loop feeds the memory pipeline: issue it ahead of arithmetic waves
+#endif
 
   const uint32_t room = base < f.capacity ? f.capacity - base : 0u;   // never write past the caller's arrays
   const uint32_t nw = (variant & 16u) ? 0u : (n < room ? n : room);
@@ -637,6 +646,9 @@ __device__ __forceinline__ void emit_item(const DevFrame& f, const Item& it, con
       }
     }
   }
+#if VPCC_TILES_SETPRIO & 1
+  __builtin_amdgcn_s_setprio(0);
+#endif
   wave_sync();                                      // the next item overwrites the slots
 }
 
@@ -716,6 +728,9 @@ void k_recon_tiles(const DevFrame* __restrict__ frames, uint32_t first,
     // Geometry registers are transient (the per-item loop re-reads its samples, L2-hot); kept are the
     // occupancy nibbles (occ_next) and the duplicate nibbles (dup_next), one nibble per item.
     uint32_t occ_next = 0, dup_next = 0;
+#if VPCC_TILES_SETPRIO & 2
+    __builtin_amdgcn_s_setprio(2);                          // count + publish: other workgroups' look-backs wait for it
+#endif
     if (have_next) {
 #pragma unroll
       for (uint32_t c0 = 0; c0 < K; c0 += 4u) {            // four items' loads in flight at a time
@@ -769,6 +784,9 @@ void k_recon_tiles(const DevFrame* __restrict__ frames, uint32_t first,
         st_store(f.scan_state + g_next, ((uint64_t)gen << kGenShift) | (g_next == 0 ? kPrefix : kAggregate) | total_next);
     }
     VPCC_STAMP(3)
+#if VPCC_TILES_SETPRIO & 2
+    __builtin_amdgcn_s_setprio(0);
+#endif
 
     if (have_cur) {
       // The look-back words were read before the count phase, whose loads have all been consumed: taking
@@ -809,6 +827,9 @@ void k_recon_tiles(const DevFrame* __restrict__ frames, uint32_t first,
         // its first item of the NEXT group (counted above), so that no step begins with an exposed load.
         // The loads are unconditional (at the very end of the frame they re-read the current item): one
         // counter state on every path.  Nothing here depends on an outstanding vector load.
+#if VPCC_TILES_SETPRIO & 4
+        __builtin_amdgcn_s_setprio(1);                      // get the next item's loads out before this item's arithmetic
+#endif
         const bool within = i + 1u < K;
         uint32_t next_item = within ? g_cur * kTileItemsPerGroup + item_in_group(wave, i + 1u)
                                     : g_next * kTileItemsPerGroup + item_in_group(wave, 0);
@@ -832,6 +853,9 @@ void k_recon_tiles(const DevFrame* __restrict__ frames, uint32_t first,
         if (!(variant & 256u)) load_attributes(f, nit, lane, nxt);
         else { nxt.y0 = nxt.y1 = Px4{0u, 0u}; nxt.u0 = nxt.v0 = nxt.u1 = nxt.v1 = 0u; }
 
+#if VPCC_TILES_SETPRIO & 4
+        __builtin_amdgcn_s_setprio(0);
+#endif
         {
           const uint32_t dup = (dup_cur >> (4u * i)) & 0xFu;                 // from the count phase
           // Take delivery of the prefetched samples before this item's stores are issued: waited for
