@@ -738,8 +738,8 @@ extern "C" int vpcc_gof_smooth(vpcc_gof* g, uint32_t first, uint32_t count, cons
     SmoothGrid sg{};
     sg.flags_offset = align_up(cells * sizeof(SmoothCell), 256);
     sg.slot_bytes = align_up(sg.flags_offset + cells, 256);
-    sg.key_stride = g->capacity;
-    if (!g->smooth_keys) HIP_TRY(ctx, hipMalloc(&g->smooth_keys, sizeof(uint32_t) * g->capacity * g->n_frames));
+    sg.key_stride = align_up(g->capacity, 4);                // 16-byte loads of four cell indices
+    if (!g->smooth_keys) HIP_TRY(ctx, hipMalloc(&g->smooth_keys, sizeof(uint32_t) * sg.key_stride * g->n_frames));
     sg.key_base = (uint32_t*)g->smooth_keys;
     const uint32_t chunk = (uint32_t)std::max<size_t>(1, std::min<size_t>(count, (size_t(16) << 30) / sg.slot_bytes));
     const size_t need = sg.slot_bytes * chunk;

@@ -142,31 +142,60 @@ __device__ __forceinline__ void paint_flags(unsigned char* flags, uint32_t key, 
 // ("mixed"), and those eight cells always lie in the 3x3x3 block around the point's own cell.  This pass
 // paints a byte flag on the 3x3x3 block around every mixed cell, so that the filter kernels decide with ONE
 // byte load whether a point needs its eight 24-byte cells at all (few do: patch boundaries).
+// Four consecutive points per thread (one 16-byte load of their cell indices): a quarter of the workgroups of a
+// thread-per-point launch, which for these light passes was bound by workgroup dispatch (0.08 -> 0.0x ms).
+// leader bit j: key j starts a run of equal cell indices (differs from the key before it; the first key of a row
+// of 16 lanes always leads).  Keys beyond n read as 0xFFFFFFFF and lead nothing.
+__device__ __forceinline__ uint32_t load_keys4(const uint32_t* keys, uint32_t i4, uint32_t n, uint32_t k[4]) {
+  if (i4 + 3u < n) {
+    const uint4 v = *reinterpret_cast<const uint4*>(keys + i4);
+    k[0] = v.x; k[1] = v.y; k[2] = v.z; k[3] = v.w;
+  } else {
+#pragma unroll
+    for (uint32_t j = 0; j < 4; ++j) k[j] = i4 + j < n ? keys[i4 + j] : 0xFFFFFFFFu;
+  }
+  const uint32_t before = row_shr<1>(k[3], ~k[0]);           // the previous thread's last key
+  uint32_t lead = before != k[0] ? 1u : 0u;
+#pragma unroll
+  for (uint32_t j = 1; j < 4; ++j) lead |= (k[j] != k[j - 1u] ? 1u : 0u) << j;
+#pragma unroll
+  for (uint32_t j = 0; j < 4; ++j) if (k[j] == 0xFFFFFFFFu) lead &= ~(1u << j);
+  return lead;
+}
+
 __global__ __launch_bounds__(256) void k_smooth_mark(const DevFrame* __restrict__ frames, uint32_t first, SmoothGrid sg,
                                                      uint32_t w) {
   const DevFrame& f = frames[first + blockIdx.y];
   const uint32_t n = min(*gl(f.n_points), f.capacity);
-  const uint32_t i = blockIdx.x * 256u + threadIdx.x;
-  if (i >= n) return;
-  const uint32_t key = sg.keys(blockIdx.y)[i];
-  if (row_shr<1>(key, ~key) == key) return;                 // one lane per run of equal cells is enough
-  if (cell_mixed(gload(sg.cells(blockIdx.y) + key))) paint_flags(sg.flags(blockIdx.y), key, w, 1);
+  const uint32_t i4 = (blockIdx.x * 256u + threadIdx.x) * 4u;
+  if (blockIdx.x * 1024u >= n) return;
+  uint32_t k[4];
+  const uint32_t lead = load_keys4(sg.keys(blockIdx.y), i4, n, k);
+#pragma unroll
+  for (uint32_t j = 0; j < 4; ++j)
+    if (((lead >> j) & 1u) && cell_mixed(gload(sg.cells(blockIdx.y) + k[j]))) paint_flags(sg.flags(blockIdx.y), k[j], w, 1);
 }
 
-// Restores the all-zero state: the first lane of every run of equal cell indices un-paints the flags of a mixed
+// Restores the all-zero state: the first point of every run of equal cell indices un-paints the flags of a mixed
 // cell and zeroes the cell (several runs may clear one cell; the first to read it still sees it mixed).
 __global__ __launch_bounds__(256) void k_smooth_clear(const DevFrame* __restrict__ frames, uint32_t first, SmoothGrid sg,
                                                       uint32_t w) {
   const DevFrame& f = frames[first + blockIdx.y];
   const uint32_t n = min(*gl(f.n_points), f.capacity);
-  const uint32_t i = blockIdx.x * 256u + threadIdx.x;
-  if (i >= n) return;
-  const uint32_t key = sg.keys(blockIdx.y)[i];
-  if (row_shr<1>(key, ~key) == key) return;
-  SmoothCell* cell = sg.cells(blockIdx.y) + key;
-  if (cell_mixed(gload(cell))) paint_flags(sg.flags(blockIdx.y), key, w, 0);
-  uint2* c = reinterpret_cast<uint2*>(cell);
-  c[0] = make_uint2(0u, 0u); c[1] = make_uint2(0u, 0u); c[2] = make_uint2(0u, 0u);
+  const uint32_t i4 = (blockIdx.x * 256u + threadIdx.x) * 4u;
+  if (blockIdx.x * 1024u >= n) return;
+  uint32_t k[4];
+  const uint32_t lead = load_keys4(sg.keys(blockIdx.y), i4, n, k);
+#pragma unroll
+  for (uint32_t j = 0; j < 4; ++j) {
+    if (!((lead >> j) & 1u)) continue;
+    SmoothCell* cell = sg.cells(blockIdx.y) + k[j];
+    const SmoothCell seen = gload(cell);
+    if (seen.count == 0) continue;                            // an earlier run of the same cell has cleared it
+    if (cell_mixed(seen)) paint_flags(sg.flags(blockIdx.y), k[j], w, 0);
+    uint2* c = reinterpret_cast<uint2*>(cell);
+    c[0] = make_uint2(0u, 0u); c[1] = make_uint2(0u, 0u); c[2] = make_uint2(0u, 0u);
+  }
 }
 
 namespace {
@@ -307,13 +336,13 @@ void launch_smooth_apply_color(const DevFrame* d_frames, uint32_t first, uint32_
 void launch_smooth_mark(const DevFrame* d_frames, uint32_t first, uint32_t count, uint32_t max_points, SmoothGrid sg,
                         uint32_t w, void* stream) {
   if (!count || !max_points) return;
-  hipLaunchKernelGGL(k_smooth_mark, dim3((max_points + 255) / 256, count), dim3(256), 0, (hipStream_t)stream, d_frames,
+  hipLaunchKernelGGL(k_smooth_mark, dim3((max_points + 1023) / 1024, count), dim3(256), 0, (hipStream_t)stream, d_frames,
                      first, sg, w);
 }
 void launch_smooth_clear(const DevFrame* d_frames, uint32_t first, uint32_t count, uint32_t max_points, SmoothGrid sg,
                          uint32_t w, void* stream) {
   if (!count || !max_points) return;
-  hipLaunchKernelGGL(k_smooth_clear, dim3((max_points + 255) / 256, count), dim3(256), 0, (hipStream_t)stream, d_frames,
+  hipLaunchKernelGGL(k_smooth_clear, dim3((max_points + 1023) / 1024, count), dim3(256), 0, (hipStream_t)stream, d_frames,
                      first, sg, w);
 }
 
