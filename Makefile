@@ -14,8 +14,11 @@ PROJ       := tmc2-rs_amd
 CSRC       := $(PROJ)/csrc
 OBJ        := build/obj
 
+# -amdgpu-atomic-optimizer-strategy=None: the optimizer turns the one-lane ticket fetch-add of the tile kernel into
+# "aggregate over the wave, then read the result back at once" — a vmcnt(0) right behind the atomic, which is
+# exactly the round trip the kernel issues a step ahead to hide.  No kernel here has a many-lane atomic to gain.
 HIPFLAGS   := --offload-arch=$(ARCH) -O3 -std=c++17 -fPIC -ffp-contract=off -Wall -Wno-unused-function \
-              -Iinclude -I$(CSRC) $(EXTRA)
+              -mllvm -amdgpu-atomic-optimizer-strategy=None -Iinclude -I$(CSRC) $(EXTRA)
 PRODUCT_SO := $(PROJ)/libvpcc_recon.so
 DIAG_SO    := $(PROJ)/libvpcc_recon_diag.so
 HIP_SRC    := $(wildcard $(CSRC)/*.hip)

@@ -48,6 +48,15 @@ namespace {
 
 // Look-back word: {generation:30 | status:2 | value:32}.  The generation is the launch counter of the
 // gof: words written by earlier launches read as EMPTY, so nothing has to be cleared between launches.
+// Ablation switches and in-kernel stamps exist in the DIAGNOSTIC build only (`make diag`:
+// -DVPCC_DIAGNOSTIC, libvpcc_recon_diag.so, used by tools/ — never by tests, bench.py or the
+// product): in the product build `variant` is the constant 0 and every switch folds away.
+#ifdef VPCC_DIAGNOSTIC
+constexpr bool kDiagnostic = true;
+#else
+constexpr bool kDiagnostic = false;
+#endif
+
 constexpr uint64_t kStatusShift = 32;
 constexpr uint64_t kGenShift = 34;
 constexpr uint64_t kAggregate = 1ull << kStatusShift;
@@ -128,6 +137,15 @@ __device__ __forceinline__ void wave_sync() {
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
+// Workgroup barrier that orders LDS only: the waves of a workgroup hand each other nothing through global memory,
+// and __syncthreads() — a fence over ALL address spaces — makes every wave wait for its outstanding output stores
+// (s_waitcnt vmcnt(0)) at each step.
+__device__ __forceinline__ void wg_sync_lds() {
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
+  __builtin_amdgcn_s_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
+}
+
 struct Px4 { uint32_t lo, hi; };   // four u16 samples, pixel j in bits 16*(j&1) of (j<2 ? lo : hi)
 
 template <int J>
@@ -200,13 +218,19 @@ __device__ __forceinline__ void lane_origin(const Item& it, uint32_t lane, uint3
 // lane needs 4 / 2 / 1 consecutive bytes for occupancy_precision 1 / 2 / >= 4 (a power of two); they
 // lie inside one aligned dword (tile_planes_aligned), which is what is loaded — an aligned dword
 // that contains a valid byte never leaves the allocation's pages.
-__device__ __forceinline__ uint32_t load_occupancy_raw(const DevFrame& f, const Item& it, uint32_t lane) {
+// Returns the aligned dword; `shift` is the bit position of the lane's first byte inside it.
+__device__ __forceinline__ uint32_t load_occupancy_word(const DevFrame& f, const Item& it, uint32_t lane, uint32_t& shift) {
   uint32_t px0, py0;
   lane_origin(it, lane, px0, py0);
   const uint32_t off = __umul24(py0 >> f.prec_shift, f.occ_stride) + (px0 >> f.prec_shift);
   const uint32_t mis = ((uint32_t)(uintptr_t)f.occ + off) & 3u;            // position inside the aligned dword
-  const uint32_t w = *reinterpret_cast<const VPCC_GLOBAL uint32_t*>((const VPCC_GLOBAL unsigned char*)f.occ + (off - mis));
-  return w >> (8u * mis);
+  shift = 8u * mis;
+  return *reinterpret_cast<const VPCC_GLOBAL uint32_t*>((const VPCC_GLOBAL unsigned char*)f.occ + (off - mis));
+}
+__device__ __forceinline__ uint32_t load_occupancy_raw(const DevFrame& f, const Item& it, uint32_t lane) {
+  uint32_t shift;
+  const uint32_t w = load_occupancy_word(f, it, lane, shift);
+  return w >> shift;
 }
 // bit j: pixel j of the lane is occupied; pixel j reads byte j >> prec_shift (byte 0 for precision >= 4)
 __device__ __forceinline__ uint32_t occupancy_bits(const DevFrame& f, uint32_t raw) {
@@ -238,13 +262,24 @@ __device__ __forceinline__ void load_geometry(const DevFrame& f, const Item& it,
 
 // Attribute samples; chroma is nearest-neighbour (src/decoder.rs:977): pixels 0,1 of the lane use
 // chroma sample px0/2, pixels 2,3 the next one.
-__device__ __forceinline__ void load_attributes(const DevFrame& f, const Item& it, uint32_t lane, Samples& s) {
+__device__ __forceinline__ void load_attributes(const DevFrame& f, const Item& it, uint32_t lane, Samples& s,
+                                                uint32_t variant = 0) {
   uint32_t px0, py0;
   load_origin(it, lane, s.occ, px0, py0);
   // both layers come from one video: one row pitch (tile_planes_aligned), one offset per plane kind
   const uint32_t c0 = (__umul24(py0 >> 1, f.attr_cstride[0]) + (px0 >> 1)) * 2u;
   const uint32_t y0 = (__umul24(py0, f.attr_stride[0]) + px0) * 2u;
   constexpr bool kS = VPCC_TILES_NT & 2;
+  if (kDiagnostic && (variant & 6144u)) {                  // ablations: 2048 no chroma loads, 4096 no luma loads
+    s.y0 = s.y1 = Px4{lane, 0u};
+    s.u0 = s.v0 = s.u1 = s.v1 = lane;
+    if (!(variant & 4096u)) { s.y0 = load4_row<kS>(f.attr_y[0], y0); s.y1 = load4_row<kS>(f.attr_y[1], y0); }
+    if (!(variant & 2048u)) {
+      s.u0 = load2<kS>(f.attr_u[0], c0); s.v0 = load2<kS>(f.attr_v[0], c0);
+      s.u1 = load2<kS>(f.attr_u[1], c0); s.v1 = load2<kS>(f.attr_v[1], c0);
+    }
+    return;
+  }
   s.y0 = load4_row<kS>(f.attr_y[0], y0);   // absent planes alias present ones
   s.u0 = load2<kS>(f.attr_u[0], c0);
   s.v0 = load2<kS>(f.attr_v[0], c0);
@@ -411,15 +446,6 @@ __device__ __forceinline__ void pixel_ranks(const Item& it, const Samples& s, ui
   wave_sync();                                                             // scratch is overwritten by records next
 }
 
-// Ablation switches and in-kernel stamps exist in the DIAGNOSTIC build only (`make diag`:
-// -DVPCC_DIAGNOSTIC, libvpcc_recon_diag.so, used by tools/ — never by tests, bench.py or the
-// product): in the product build `variant` is the constant 0 and every switch folds away.
-#ifdef VPCC_DIAGNOSTIC
-constexpr bool kDiagnostic = true;
-#else
-constexpr bool kDiagnostic = false;
-#endif
-
 // Diagnostic build only (variant bit 64): per-phase cycle sums of waves 0 and 8 of every group.
 // Never read by the kernel; fetched with vpcc_debug_read_stamps().
 #ifdef VPCC_DIAGNOSTIC
@@ -517,6 +543,10 @@ __device__ __forceinline__ void store_rgb(VPCC_GLOBAL unsigned char* base, uint3
 #ifndef VPCC_TILES_UNROLL_ITEMS
 #define VPCC_TILES_UNROLL_ITEMS 1
 #endif
+// 1: the ticket of the step after next is drawn before the item loop
+#ifndef VPCC_TILES_TICKET_AHEAD
+#define VPCC_TILES_TICKET_AHEAD 1
+#endif
 // 1: pipelined (count group g+1, then emit group g), the emit phase reads the geometry again
 // 3: pipelined, the counted geometry stays in registers (default: every plane byte is requested once)
 // (Measured and dropped, see DESIGN.md: 2 = all samples of a group resident, no pipelining — least traffic,
@@ -541,19 +571,41 @@ __device__ __forceinline__ void emit_item(const DevFrame& f, const Item& it, con
   VPCC_GLOBAL unsigned char* const gx = (VPCC_GLOBAL unsigned char*)f.out_xyz;
   VPCC_GLOBAL unsigned char* const gc = (VPCC_GLOBAL unsigned char*)f.out_rgb;
   VPCC_GLOBAL uint16_t* const gp = glw(f.out_patch);
-  if (n == 0) {                                             // wave-uniform
-    // Same counter state on both paths: were the prefetched samples still pending here, the compiler would
-    // have to wait for vmcnt(0) where the paths join — i.e. for this wave's output stores, after every item.
-    before_stores();
-    return;
-  }
-  if (variant & 1024u) {
+  // An empty item (n == 0, wave-uniform) skips both halves.  The hook sits on the joined path between them, not
+  // in either branch: the compiler's branch lowering leaves bypass edges that never run ("exec == 0") around
+  // conditional code, and a delivery that such an edge skips counts as missing — the price is a vmcnt(0), a wait
+  // for this wave's output stores, wherever the registers are next written (the loop latch: once per step).
+  const bool skeleton = kDiagnostic && (variant & 1024u);
+  if (n != 0 && skeleton) {
     // Diagnostic "memory skeleton": the item's loads were issued and are waited for, its stores go to the same
     // addresses with the same instructions — but no ranks, colours, records or back-projection.  What this
     // build takes is what the kernel's memory behaviour and control flow cost on their own.
     asm volatile("" ::"v"(cur.y0.lo), "v"(cur.y0.hi), "v"(cur.y1.lo), "v"(cur.y1.hi), "v"(cur.u0), "v"(cur.v0), "v"(cur.u1), "v"(cur.v1),
                  "v"(cur.g0.lo), "v"(cur.g1.lo));
-    before_stores();
+  }
+  if (n != 0 && !skeleton) {
+    uint32_t rk[4];
+    const uint32_t cnt = 2u * (uint32_t)__builtin_popcount(cur.occ) - (uint32_t)__builtin_popcount(dup);
+    pixel_ranks(it, cur, dup, cnt, lane, reinterpret_cast<unsigned char*>(slots), rk);
+    uint32_t rgb0[4] = {0, 0, 0, 0}, rgb1[4] = {0, 0, 0, 0};
+    if (f.has_attr && !(variant & 8u)) {
+      colours4(cur.y0, cur.u0, cur.v0, rgb0);
+      if (f.map_count > 1) colours4(cur.y1, cur.u1, cur.v1, rgb1);
+    }
+    // patch-local offsets of the lane's pixels: Default (du, dv) = (4q + j, r); Swap (du, dv) = (r, 4q + j)
+    const uint32_t q4 = 4u * (lane & 3u), r = lane >> 2;
+    const bool swap = it.flags & kTileSwap;
+    const uint32_t pix0 = swap ? q4 * 16u + r : r * 16u + q4, pstep = swap ? 16u : 1u;
+    const uint32_t dump = 512u + lane;
+    put_records<0>(cur, dup, pix0, rk[0], dump, rgb0, rgb1, slots);
+    put_records<1>(cur, dup, pix0 + pstep, rk[1], dump, rgb0, rgb1, slots);
+    put_records<2>(cur, dup, pix0 + 2u * pstep, rk[2], dump, rgb0, rgb1, slots);
+    put_records<3>(cur, dup, pix0 + 3u * pstep, rk[3], dump, rgb0, rgb1, slots);
+    wave_sync();                                      // records written by other lanes are read below
+  }
+  before_stores();
+  if (n == 0) return;
+  if (skeleton) {
     const uint32_t room = base < f.capacity ? f.capacity - base : 0u, nw = n < room ? n : room;
     for (uint32_t k = 2u * lane; k < nw; k += 128u) {
       const uint2 p0 = make_uint2(k, lane), p1 = make_uint2(lane, k);
@@ -572,25 +624,6 @@ __device__ __forceinline__ void emit_item(const DevFrame& f, const Item& it, con
     }
     return;
   }
-  uint32_t rk[4];
-  const uint32_t cnt = 2u * (uint32_t)__builtin_popcount(cur.occ) - (uint32_t)__builtin_popcount(dup);
-  pixel_ranks(it, cur, dup, cnt, lane, reinterpret_cast<unsigned char*>(slots), rk);
-  uint32_t rgb0[4] = {0, 0, 0, 0}, rgb1[4] = {0, 0, 0, 0};
-  if (f.has_attr && !(variant & 8u)) {
-    colours4(cur.y0, cur.u0, cur.v0, rgb0);
-    if (f.map_count > 1) colours4(cur.y1, cur.u1, cur.v1, rgb1);
-  }
-  // patch-local offsets of the lane's pixels: Default (du, dv) = (4q + j, r); Swap (du, dv) = (r, 4q + j)
-  const uint32_t q4 = 4u * (lane & 3u), r = lane >> 2;
-  const bool swap = it.flags & kTileSwap;
-  const uint32_t pix0 = swap ? q4 * 16u + r : r * 16u + q4, pstep = swap ? 16u : 1u;
-  const uint32_t dump = 512u + lane;
-  put_records<0>(cur, dup, pix0, rk[0], dump, rgb0, rgb1, slots);
-  put_records<1>(cur, dup, pix0 + pstep, rk[1], dump, rgb0, rgb1, slots);
-  put_records<2>(cur, dup, pix0 + 2u * pstep, rk[2], dump, rgb0, rgb1, slots);
-  put_records<3>(cur, dup, pix0 + 3u * pstep, rk[3], dump, rgb0, rgb1, slots);
-  wave_sync();                                      // records written by other lanes are read below
-  before_stores();
 #if VPCC_TILES_SETPRIO & 1
   __builtin_amdgcn_s_setprio(1);                    // the store loop feeds the memory pipeline: issue it ahead of arithmetic waves
 #endif
@@ -696,20 +729,28 @@ void k_recon_tiles(const DevFrame* __restrict__ frames, uint32_t first,
   // later (16 VGPRs per group in flight) instead of being read again: the re-read missed the L2 almost
   // always (23 us and ~60 MB of output per XCD lie between the two reads; profiles/r02).
   constexpr bool kGeoResident = VPCC_TILES_STRUCTURE == 3;
+  constexpr bool kHandOverEarly = kGeoResident && VPCC_TILES_UNROLL_ITEMS;
   Px4 gn0[4] = {}, gn1[4] = {}, gc0[4] = {}, gc1[4] = {};
   Samples a_first = {};                // attribute samples of the wave's first item of the current group,
                                        // prefetched during the previous step
+  uint32_t t_ahead = 0;
+  if (VPCC_TILES_TICKET_AHEAD && threadIdx.x == 0)
+    t_ahead = __hip_atomic_fetch_add(glw(f.ticket), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  if (VPCC_TILES_TICKET_AHEAD) asm volatile("" : "+v"(t_ahead));   // delivered on every path into the loop: no wait at its top
   for (;;) {
     // ---- 1. draw the NEXT group of this frame.  Every workgroup of the frame stops at its first ticket
     // past the end, so exactly n_groups + groups_stride tickets are drawn per launch: the last re-arms
     // the counter (nothing to clear between launches).
+    // The ticket itself was drawn a step earlier (VPCC_TILES_TICKET_AHEAD): the round trip of the atomic is hidden
+    // behind the previous group's item loop instead of being waited for by all four waves at this barrier.
     if (threadIdx.x == 0) {
-      const uint32_t t = __hip_atomic_fetch_add(glw(f.ticket), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      const uint32_t t = VPCC_TILES_TICKET_AHEAD ? t_ahead
+                                                 : __hip_atomic_fetch_add(glw(f.ticket), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       if (t + 1u == n_groups + groups_stride)
         __hip_atomic_store(glw(f.ticket), 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       s_group = t;
     }
-    __syncthreads();
+    wg_sync_lds();
     const uint32_t g_next = __builtin_amdgcn_readfirstlane(s_group);
     const bool have_next = g_next < n_groups;
     // Speculative read of the current group's look-back words.  It is issued BEHIND the count phase's plane
@@ -742,8 +783,14 @@ void k_recon_tiles(const DevFrame* __restrict__ frames, uint32_t first,
         uint32_t raw[4];
 #pragma unroll
         for (int i = 0; i < 4; ++i) it4[i] = load_item(f.tiles + (idx4[i] < f.n_tiles ? idx4[i] : 0u));
+        uint32_t raw_shift[4];
 #pragma unroll
-        for (int i = 0; i < 4; ++i) raw[i] = load_occupancy_raw(f, it4[i], lane);
+        for (int i = 0; i < 4; ++i) raw[i] = load_occupancy_word(f, it4[i], lane, raw_shift[i]);
+        // complete on EVERY path (a group's items past the end of the frame never look at theirs): a load the
+        // compiler believes pending at the top of the next step costs a vmcnt(0) there — a wait for the stores
+        asm volatile("" : "+v"(raw[0]), "+v"(raw[1]), "+v"(raw[2]), "+v"(raw[3]));
+#pragma unroll
+        for (int i = 0; i < 4; ++i) raw[i] >>= raw_shift[i];
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
           s4[i].occ = idx4[i] < f.n_tiles ? occupancy_bits(f, raw[i]) : 0u;   // past the end: an empty copy of item 0
@@ -770,7 +817,7 @@ void k_recon_tiles(const DevFrame* __restrict__ frames, uint32_t first,
     }
     if (!have_next) read_early();
     VPCC_STAMP(1)
-    __syncthreads();
+    wg_sync_lds();
     VPCC_STAMP(2)
 
     // ---- 3. wave 0 publishes the next group's total.  Then EVERY wave looks back for the current group
@@ -783,18 +830,24 @@ void k_recon_tiles(const DevFrame* __restrict__ frames, uint32_t first,
       if (lane == 0)
         st_store(f.scan_state + g_next, ((uint64_t)gen << kGenShift) | (g_next == 0 ? kPrefix : kAggregate) | total_next);
     }
+    if (VPCC_TILES_TICKET_AHEAD && threadIdx.x == 0 && have_next)   // a workgroup that saw the end draws no more
+      t_ahead = __hip_atomic_fetch_add(glw(f.ticket), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     VPCC_STAMP(3)
 #if VPCC_TILES_SETPRIO & 2
     __builtin_amdgcn_s_setprio(0);
 #endif
 
+    // The speculative read is complete on EVERY path from here on (group 0 and a workgroup's first step never look
+    // at it; all paths, the exit included, meet again in the loop's single latch): a load that the compiler
+    // believes pending there costs a vmcnt(0) — a wait for the output stores — at the top of every step.
+    asm volatile("" : "+v"(early));
     if (have_cur) {
       // The look-back words were read before the count phase, whose loads have all been consumed: taking
       // delivery of them here waits for nothing.
-      uint32_t excl = (variant & 1u) ? g_cur * 7000u : 0u;   // ablation: no wait, outputs still spread over the frame
+      uint32_t excl = (variant & 1u) ? g_cur * (f.capacity / n_groups) : 0u;   // ablation: no wait, outputs still spread over the frame
       if (g_cur != 0 && !(variant & 1u)) excl = look_back_groups(f, g_cur, gen, early);
       // ablation 2: the look-back runs (all its waits), but the outputs go to the spread positions of ablation 1
-      if (variant & 2u) { asm volatile("" :: "v"(excl)); excl = g_cur * 7000u; }
+      if (variant & 2u) { asm volatile("" :: "v"(excl)); excl = g_cur * (f.capacity / n_groups); }
       // the speculative read is complete on EVERY path from here on (group 0 never looks at it): a pending
       // load into registers the item loop reuses would cost a vmcnt(0) — a wait for the output stores — per item
       asm volatile("" : "+v"(early));
@@ -822,7 +875,9 @@ void k_recon_tiles(const DevFrame* __restrict__ frames, uint32_t first,
 #pragma unroll
 #endif
       for (uint32_t i = 0; i < K; ++i) {
-        const uint32_t n = s_tot[cb][item_in_group(wave, i)];
+        // scalar on purpose: a branch on a VGPR value is lowered with exec masks and an "exec == 0" bypass edge —
+        // a path that never runs, but along which the compiler sees this item's prefetch loads undelivered
+        const uint32_t n = __builtin_amdgcn_readfirstlane(s_tot[cb][item_in_group(wave, i)]);
         // Prefetch the attribute samples of the wave's next item — after its last item of this group, of
         // its first item of the NEXT group (counted above), so that no step begins with an exposed load.
         // The loads are unconditional (at the very end of the frame they re-read the current item): one
@@ -850,7 +905,7 @@ void k_recon_tiles(const DevFrame* __restrict__ frames, uint32_t first,
         } else if (!(variant & 128u)) {
           load_geometry<true>(f, nit, lane, nxt);
         }
-        if (!(variant & 256u)) load_attributes(f, nit, lane, nxt);
+        if (!(variant & 256u)) load_attributes(f, nit, lane, nxt, variant);
         else { nxt.y0 = nxt.y1 = Px4{0u, 0u}; nxt.u0 = nxt.v0 = nxt.u1 = nxt.v1 = 0u; }
 
 #if VPCC_TILES_SETPRIO & 4
@@ -860,14 +915,29 @@ void k_recon_tiles(const DevFrame* __restrict__ frames, uint32_t first,
           const uint32_t dup = (dup_cur >> (4u * i)) & 0xFu;                 // from the count phase
           // Take delivery of the prefetched samples before this item's stores are issued: waited for
           // later, the in-order vmcnt would make that wait cover the stores as well.
-          emit_item(f, it, cur, dup, n, base, lane, slots, variant, [&]() { take_delivery(nxt); });
+          emit_item(f, it, cur, dup, n, base, lane, slots, variant, [&]() {
+            take_delivery(nxt);
+            if (VPCC_TILES_TICKET_AHEAD) asm volatile("" : "+v"(t_ahead));
+            if (kHandOverEarly && i + 1u == K) {
+              // Hand the loop-carried registers over BEFORE the last item's stores: register copies made in
+              // the loop latch, behind those stores, are preceded by a vmcnt(0) (with loads and stores both in
+              // flight the compiler cannot count, and any register it believes pending costs a full wait).
+#pragma unroll
+              for (int j = 0; j < 4; ++j) {
+                gc0[j] = gn0[j]; gc1[j] = gn1[j];
+                asm volatile("" : "+v"(gc0[j].lo), "+v"(gc0[j].hi), "+v"(gc1[j].lo), "+v"(gc1[j].hi));
+              }
+              a_first = nxt;
+              take_delivery(a_first);
+            }
+          });
         }
         // the items between this one and the wave's next one (the other waves' when interleaved)
         for (uint32_t k = item_in_group(wave, i); k < item_in_group(wave, i + 1u) && k < kTileItemsPerGroup; ++k) base += s_tot[cb][k];
         it = nit;
         cur = nxt;
       }
-      a_first = cur;
+      if (!kHandOverEarly) a_first = cur;
       VPCC_STAMP(5)
     } else if (have_next) {
       // first step of the workgroup: nothing to emit yet; fetch the attributes of the first item just counted
@@ -875,15 +945,21 @@ void k_recon_tiles(const DevFrame* __restrict__ frames, uint32_t first,
       const Item nit = load_item(f.tiles + (next_item < f.n_tiles ? next_item : 0u));
       a_first.occ = occ_next & 0xFu;
       a_first.g0 = gn0[0]; a_first.g1 = gn1[0];
-      if (!(variant & 256u)) load_attributes(f, nit, lane, a_first);
+      if (!(variant & 256u)) load_attributes(f, nit, lane, a_first, variant);
       take_delivery(a_first);                                // once per workgroup: keeps the item loop free of waits on `cur`
+      if (kHandOverEarly) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { gc0[j] = gn0[j]; gc1[j] = gn1[j]; }
+      }
+      asm volatile("" : "+v"(early));                        // (never read on this path, but pending in the compiler's books)
+      if (VPCC_TILES_TICKET_AHEAD) asm volatile("" : "+v"(t_ahead));
     }
     if (!have_next) break;
     g_cur = g_next;
     occ_cur = occ_next;
     dup_cur = dup_next;
     total_cur = total_next;
-    if (kGeoResident) {
+    if (kGeoResident && !kHandOverEarly) {
 #pragma unroll
       for (int i = 0; i < 4; ++i) { gc0[i] = gn0[i]; gc1[i] = gn1[i]; }
     }
