@@ -141,6 +141,8 @@ def main():
     kw = {}
     if os.environ.get("VPCC_BENCH_SWAP_PROB"):          # diagnostic only: share of Swap-oriented patches
         kw["swap_prob"] = float(os.environ["VPCC_BENCH_SWAP_PROB"])
+    if os.environ.get("VPCC_BENCH_ALIGN"):              # diagnostic only: patch x positions / widths in multiples of N blocks
+        kw["align"] = int(os.environ["VPCC_BENCH_ALIGN"])
     frames = [make(rank * args.frames + i, **kw) for i in range(args.frames)]
     cap = 1_000_000 if args.workload == "longdress" else 2_400_000
 

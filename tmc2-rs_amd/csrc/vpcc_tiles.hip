@@ -450,8 +450,16 @@ __device__ __forceinline__ void pixel_ranks(const Item& it, const Samples& s, ui
 // Never read by the kernel; fetched with vpcc_debug_read_stamps().
 #ifdef VPCC_DIAGNOSTIC
 __device__ unsigned long long g_stamps[16];
+// Variant bit 8192: {start, first ticket past the end seen, exit} of every workgroup (s_memtime), for the occupancy-over-time curve
+// of a launch (tools/wg_timeline.py).
+__device__ unsigned long long g_wg_times[8192][3];
 #endif
 
+__device__ __forceinline__ unsigned long long stamp_time() {      // constant 100 MHz clock, comparable across CUs
+  unsigned long long t;
+  asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t)::"memory");
+  return t;
+}
 __device__ __forceinline__ unsigned long long stamp() {
   unsigned long long t;
   asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t)::"memory");
@@ -709,6 +717,10 @@ void k_recon_tiles(const DevFrame* __restrict__ frames, uint32_t first,
   const uint32_t fi = xcd + 8u * (slot % frame_groups);   // (spreading a frame over all XCDs instead: 0.147 -> 0.164 ms)
   if (fi >= count) return;
   const DevFrame& f = frames[first + fi];
+#ifdef VPCC_DIAGNOSTIC
+  const unsigned long long wg_t0 = (variant & 8192u) ? stamp_time() : 0ull;
+  unsigned long long wg_steps = 0;
+#endif
 
   __shared__ uint32_t s_group;
   __shared__ uint32_t s_tot[2][kTileItemsPerGroup];                     // point counts of the two groups in flight
@@ -955,6 +967,9 @@ void k_recon_tiles(const DevFrame* __restrict__ frames, uint32_t first,
       if (VPCC_TILES_TICKET_AHEAD) asm volatile("" : "+v"(t_ahead));
     }
     if (!have_next) break;
+#ifdef VPCC_DIAGNOSTIC
+    ++wg_steps;
+#endif
     g_cur = g_next;
     occ_cur = occ_next;
     dup_cur = dup_next;
@@ -966,6 +981,16 @@ void k_recon_tiles(const DevFrame* __restrict__ frames, uint32_t first,
     cb ^= 1u;
     have_cur = true;
   }
+#ifdef VPCC_DIAGNOSTIC
+  if ((variant & 8192u) && blockIdx.x < 8192u) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // the workgroup's stores have left
+    if (threadIdx.x == 0) {
+      g_wg_times[blockIdx.x][0] = wg_t0;
+      g_wg_times[blockIdx.x][1] = wg_steps;
+      g_wg_times[blockIdx.x][2] = stamp_time();
+    }
+  }
+#endif
   if constexpr (kStamps) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   VPCC_STAMP(6)
   VPCC_STAMP_FLUSH()
@@ -975,6 +1000,9 @@ void k_recon_tiles(const DevFrame* __restrict__ frames, uint32_t first,
 }  // namespace vpcc
 
 #ifdef VPCC_DIAGNOSTIC
+extern "C" int vpcc_debug_read_wg_times(unsigned long long* out, int n_wgs) {
+  return hipMemcpyFromSymbol(out, HIP_SYMBOL(vpcc::g_wg_times), sizeof(unsigned long long) * 3 * (size_t)n_wgs) != hipSuccess;
+}
 extern "C" int vpcc_debug_read_stamps(unsigned long long* out16, int reset) {
   if (hipMemcpyFromSymbol(out16, HIP_SYMBOL(vpcc::g_stamps), sizeof(unsigned long long) * 16) != hipSuccess) return 1;
   if (reset) {

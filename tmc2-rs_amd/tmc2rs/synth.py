@@ -72,7 +72,7 @@ def _new_patch(rs, x, y, cw, ch, swap, R, max_coord, depth_span):
 
 
 def _pack_patches(seed, bw, bh, R, coord_bits, cover_target, max_side, max_patches, swap_prob,
-                  overlap_prob, size_skew=8.0):
+                  overlap_prob, size_skew=8.0, align=1):
     """TMC2-style packer in block units: bounding boxes sorted by area (largest
     first = lowest patch index), each placed at the first raster position where
     it collides with nothing.  Returns a PATCH_DTYPE array."""
@@ -83,6 +83,8 @@ def _pack_patches(seed, bw, bh, R, coord_bits, cover_target, max_side, max_patch
     while len(sizes) < max_patches and covered < cover_target * bw * bh:
         cw = min(2 + int((max_side - 1) * rs.u() ** size_skew), bw)
         ch = min(2 + int((max_side - 1) * rs.u() ** size_skew), bh)
+        if align > 1:                            # diagnostic layouts only: widths and x positions in whole cache lines
+            cw = min(-(-cw // align) * align, bw // align * align)
         sizes.append((cw, ch))
         covered += cw * ch
     sizes.sort(key=lambda s: -(s[0] * s[1]))
@@ -92,7 +94,10 @@ def _pack_patches(seed, bw, bh, R, coord_bits, cover_target, max_side, max_patch
         sat = np.zeros((bh + 1, bw + 1), dtype=np.int32)
         sat[1:, 1:] = used.cumsum(0).cumsum(1)
         win = sat[ch:, cw:] - sat[:-ch, cw:] - sat[ch:, :-cw] + sat[:-ch, :-cw]   # (bh-ch+1, bw-cw+1)
-        free = np.flatnonzero(win.reshape(-1) == 0)
+        ok = win == 0
+        if align > 1:
+            ok[:, np.arange(ok.shape[1]) % align != 0] = False
+        free = np.flatnonzero(ok.reshape(-1))
         if len(free) == 0:
             continue
         y, x = divmod(int(free[0]), win.shape[1])
@@ -122,7 +127,7 @@ def canvas_bbox_blocks(p):
 
 def make_frame(width=1280, height=1408, precision=4, resolution=16, seed=0x5EED0000, coord_bits=10,
                cover_target=0.42, ellipse_scale=0.86, max_side=24, max_patches=400, swap_prob=0.3,
-               overlap_prob=0.12, occupancy_values="one", dup_prob=0.15, patches=None, size_skew=8.0):
+               overlap_prob=0.12, occupancy_values="one", dup_prob=0.15, patches=None, size_skew=8.0, align=1):
     """One synthetic atlas frame with its decoded planes.
 
     Returns a dict: width, height, occupancy_resolution, occupancy_precision,
@@ -135,7 +140,7 @@ def make_frame(width=1280, height=1408, precision=4, resolution=16, seed=0x5EED0
     ow, oh = width // prec, height // prec
     if patches is None:
         patches = _pack_patches(seed, bw, bh, R, coord_bits, cover_target, max_side, max_patches,
-                                swap_prob, overlap_prob, size_skew)
+                                swap_prob, overlap_prob, size_skew, align)
 
     # occupancy: one ellipse per patch bounding box, at occupancy-sample granularity
     occ = np.zeros((oh, ow), dtype=np.uint8)
