@@ -28,7 +28,7 @@ def read_bytes(m):
 
 
 rows = []
-names = {0: "production kernel", 128: "no emit-phase geometry re-read", 256: "no attribute loads",
+names = {0: "production kernel", 128: "no emit-phase geometry re-read", 256: "no attribute loads", 2048: "no chroma loads", 4096: "no luma loads",
          512: "no count-phase geometry loads", 640: "no geometry loads at all (128+512)",
          896: "occupancy only (128+256+512)", 32: "no output stores", 384: "count-phase geometry only (128+256)"}
 out = {"variants": {}}
