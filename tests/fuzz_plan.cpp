@@ -65,6 +65,38 @@ int main(int argc, char** argv) {
       ++items;
     }
   }
+  // Shares of the resident workgroups per frame (plan_tile_launch): every frame with tiles gets at least one
+  // workgroup, the table's per-slot share equals the number of slots the frame really has (the kernel re-arms a
+  // frame's ticket counter after exactly that many workgroups have left it), no slot names a frame outside the launch.
+  long maps = 0, equal_split = 0;
+  for (long it = 0; it < iterations; ++it) {
+    const uint32_t count = 1 + below(below(8) == 0 ? 2100 : 70);
+    std::vector<uint32_t> tiles(count);
+    const uint32_t scale = 1 + below(9000);
+    for (uint32_t& t : tiles) t = below(6) == 0 ? 0 : below(scale) + (below(3) == 0 ? below(40) : 0);
+    const uint32_t resident = below(10) == 0 ? below(300) : 128, depth = 1 + below(6);
+    vpcc::TileLaunchMap map;
+    vpcc::plan_tile_launch(tiles.data(), count, resident, depth, map);
+    if (!map.slots) { ++equal_split; continue; }
+    ++maps;
+    if (map.slots > vpcc::kTileMapSlots) { std::fprintf(stderr, "slots\n"); return 1; }
+    for (uint32_t x = 0; x < 8; ++x) {
+      std::vector<uint32_t> have((count + 7) / 8, 0);
+      for (uint32_t s = 0; s < vpcc::kTileMapSlots; ++s) {
+        const uint32_t v = map.frame_of_slot[x][s];
+        if (v == 0xFF) continue;
+        if (s >= map.slots || x + 8u * v >= count) { std::fprintf(stderr, "slot names a frame outside the launch\n"); return 1; }
+        ++have[v];
+      }
+      for (uint32_t s = 0; s < map.slots; ++s) {
+        const uint32_t v = map.frame_of_slot[x][s];
+        if (v != 0xFF && map.wgs_of_slot[x][s] != have[v]) { std::fprintf(stderr, "share != slots of the frame\n"); return 1; }
+      }
+      for (uint32_t i = x; i < count; i += 8)
+        if ((tiles[i] != 0) != (have[i / 8] != 0)) { std::fprintf(stderr, "frame %u tiles %u workgroups %u\n", i, tiles[i], have[i / 8]); return 1; }
+    }
+  }
+  std::printf("launch maps %ld, equal split %ld\n", maps, equal_split);
   std::printf("iterations %ld accepted %ld rejected %ld tile items %ld\n", iterations, accepted, rejected, items);
   return accepted > 0 && rejected > 0 ? 0 : 1;
 }

@@ -1,5 +1,6 @@
 """Host-side frame validation + planning (tmc2-rs_amd/csrc/vpcc_host.cpp) under AddressSanitizer + UBSan with random
-and adversarial patch tables: rejected, or planned into work lists that stay inside the canvas."""
+and adversarial patch tables: rejected, or planned into work lists that stay inside the canvas; and the shares of the
+resident workgroups per frame of a launch (plan_tile_launch) keep their invariants for random frame sizes."""
 import os
 import subprocess
 
@@ -16,3 +17,5 @@ def test_validate_and_plan_survive_random_patch_tables(tmp_path):
     out = subprocess.run([str(exe), "4000"], capture_output=True, text=True, timeout=600)
     assert out.returncode == 0, out.stdout + out.stderr
     assert "iterations 4000" in out.stdout, out.stdout
+    maps = [l for l in out.stdout.splitlines() if l.startswith("launch maps")]
+    assert maps and int(maps[0].split()[2].rstrip(",")) > 1000, out.stdout        # the share tables were exercised

@@ -138,7 +138,20 @@ void launch_block_owner(const DevFrame* d_frames, uint32_t first, uint32_t count
 void launch_count(const DevFrame* d_frames, uint32_t first, uint32_t count, uint32_t max_vb, void* stream);
 void launch_scan(const DevFrame* d_frames, uint32_t first, uint32_t count, void* stream);
 void launch_emit(const DevFrame* d_frames, uint32_t first, uint32_t count, uint32_t max_vb, void* stream);
+// Where the workgroups of one tile-kernel launch start (kernel argument, by value).  A workgroup stays with its
+// frame; frames differ in size (S-longdress +-5 %, S-owlii +-11 % between the largest frame and the mean), so the
+// resident workgroups of an XCD are shared out among its frames in proportion to their tile counts instead of
+// equally — with an equal split the largest frame sets the launch time.
+constexpr uint32_t kTileMapSlots = 128;   // resident workgroups per XCD on MI355X (32 CUs x 4)
+struct TileLaunchMap {
+  uint8_t frame_of_slot[8][kTileMapSlots];   // frame = xcd + 8 * value (relative to the launch's first frame); 0xFF: none
+  uint8_t wgs_of_slot[8][kTileMapSlots];     // workgroups that frame gets in this launch (what re-arms its ticket counter)
+  uint32_t slots;                            // slots per XCD in use; 0: equal split over max_groups / depth workgroups per frame
+};
+// weights[i]: tiles of frame first + i.  resident_per_xcd: workgroups of this kernel an XCD holds at a time.
+void plan_tile_launch(const uint32_t* tiles, uint32_t count, uint32_t resident_per_xcd, uint32_t depth, TileLaunchMap& map);
 void launch_tiles(const DevFrame* d_frames, uint32_t first, uint32_t count, uint32_t max_groups, uint32_t gen,
+                  const TileLaunchMap& map,
                   void* stream);
 void launch_upsample_occupancy(const DevFrame* d_frames, uint32_t frame, uint8_t* d_out, uint32_t width,
                                uint32_t height, void* stream);

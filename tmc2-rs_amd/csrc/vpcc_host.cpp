@@ -2,6 +2,7 @@
 #include "vpcc_host.hpp"
 
 #include <algorithm>
+#include <cstring>
 
 namespace vpcc {
 
@@ -215,5 +216,82 @@ bool tile_planes_aligned(const DevFrame& d) {
   }
   return true;
 }
+
+// Largest-remainder shares of `resident_per_xcd` workgroups among the frames of each XCD label, at most
+// ceil(groups / depth) per frame (a workgroup should have a few groups to pipeline), handed out in a smooth weighted
+// round-robin so that the workgroups of one frame start a few slots apart.
+void plan_tile_launch(const uint32_t* tiles, uint32_t count, uint32_t resident_per_xcd, uint32_t depth, TileLaunchMap& map) {
+  std::memset(&map, 0xFF, sizeof(map));
+  map.slots = 0;
+  const uint32_t R = resident_per_xcd < kTileMapSlots ? resident_per_xcd : kTileMapSlots;
+  if (!R || !count || (count + 7u) / 8u > 254u || (count + 7u) / 8u > R) return;   // equal split
+  for (uint32_t x = 0; x < 8; ++x) {
+    std::vector<uint32_t> idx, cap, share;
+    std::vector<double> want;
+    double total = 0;
+    for (uint32_t i = x; i < count; i += 8) {
+      const uint32_t groups = (tiles[i] + kTileItemsPerGroup - 1u) / kTileItemsPerGroup;
+      idx.push_back(i / 8u);
+      cap.push_back(groups ? (groups + depth - 1u) / depth : 0u);
+      total += tiles[i];
+    }
+    if (idx.empty() || total == 0) continue;
+    share.assign(idx.size(), 0);
+    want.assign(idx.size(), 0.0);
+    uint32_t left = R;
+    // shares; frames that hit their cap give their surplus back to the others
+    std::vector<bool> fixed(idx.size(), false);
+    for (int pass = 0; pass < 4 && left; ++pass) {
+      double open_total = 0;
+      for (size_t j = 0; j < idx.size(); ++j) if (!fixed[j]) open_total += tiles[x + 8u * j];
+      if (open_total == 0) break;
+      bool capped = false;
+      for (size_t j = 0; j < idx.size(); ++j) {
+        if (fixed[j]) continue;
+        want[j] = left * (double)tiles[x + 8u * j] / open_total;
+        if (want[j] >= cap[j]) { share[j] = cap[j]; fixed[j] = true; capped = true; }
+      }
+      if (!capped) break;
+      left = R;
+      for (size_t j = 0; j < idx.size(); ++j) if (fixed[j]) left -= share[j] < left ? share[j] : left;
+    }
+    uint32_t given = 0;
+    for (size_t j = 0; j < idx.size(); ++j) if (fixed[j]) given += share[j];
+    if (given < R) {
+      uint32_t open_left = R - given, floor_sum = 0;
+      for (size_t j = 0; j < idx.size(); ++j) if (!fixed[j]) { share[j] = (uint32_t)want[j]; floor_sum += share[j]; }
+      for (uint32_t extra = open_left > floor_sum ? open_left - floor_sum : 0; extra; --extra) {   // largest remainders
+        size_t best = idx.size();
+        double best_rem = -1;
+        for (size_t j = 0; j < idx.size(); ++j)
+          if (!fixed[j] && share[j] < cap[j] && want[j] - share[j] > best_rem) { best_rem = want[j] - share[j]; best = j; }
+        if (best == idx.size()) break;
+        ++share[best];
+      }
+    }
+    for (size_t j = 0; j < idx.size(); ++j) if (!share[j] && cap[j]) share[j] = 1;                // nobody is left out
+    // smooth weighted round-robin
+    std::vector<uint32_t> placed(idx.size(), 0);
+    uint32_t s = 0;
+    for (; s < kTileMapSlots; ++s) {
+      size_t best = idx.size();
+      double best_frac = 0;
+      for (size_t j = 0; j < idx.size(); ++j) {
+        if (placed[j] >= share[j]) continue;
+        const double frac = (double)(share[j] - placed[j]) / share[j];
+        if (frac > best_frac) { best_frac = frac; best = j; }
+      }
+      if (best == idx.size()) break;
+      ++placed[best];
+      map.frame_of_slot[x][s] = (uint8_t)idx[best];
+      map.wgs_of_slot[x][s] = (uint8_t)share[best];
+    }
+    bool all = true;
+    for (size_t j = 0; j < idx.size(); ++j) all = all && placed[j] == share[j];
+    if (!all) { std::memset(&map, 0xFF, sizeof(map)); map.slots = 0; return; }                    // (more shares than slots)
+    if (s > map.slots) map.slots = s;
+  }
+}
+
 
 }  // namespace vpcc

@@ -25,6 +25,7 @@ struct vpcc_ctx {
   hipStream_t d2h_stream = nullptr;    // result downloads: wait for ONE gof's kernels only (results_ready), not for
                                        // whatever else has been queued behind them on the compute stream
   std::string last_error;
+  uint32_t resident_tile_wgs_per_xcd = 128;   // workgroups of the tile kernel an XCD holds at a time (4 per CU)
   // Arenas of destroyed GOFs are kept for the next GOF of the same shape: hipMalloc/hipFree cost
   // milliseconds and hipFree synchronises the whole device, which would stall a GOF pipeline.
   std::vector<std::pair<void*, size_t>> arena_cache;
@@ -76,6 +77,9 @@ struct vpcc_gof {
   uint64_t reconstructs = 0;
   bool launch_is_timed = false;
   uint32_t generation = 0;             // launch counter of the tile kernel (tags look-back words)
+  TileLaunchMap tile_map;              // shares of the resident workgroups per frame, for the last (first, count) launched
+  uint32_t tile_map_first = 0, tile_map_count = 0;
+  bool tile_map_valid = false;
   void* smooth_grid = nullptr;         // smoothing scratch (on demand): dense cell grids + touched lists + list lengths
   size_t smooth_bytes = 0;
   bool smooth_clean = false;           // the scratch is all-zero (the invariant between launches)
@@ -138,6 +142,7 @@ extern "C" int vpcc_ctx_create(int device_id, vpcc_ctx** out) {
   if (hipSetDevice(device_id) != hipSuccess) return VPCC_ERR_NO_DEVICE;
   vpcc_ctx* ctx = new vpcc_ctx();
   ctx->device = device_id;
+  ctx->resident_tile_wgs_per_xcd = (uint32_t)std::max(1, prop.multiProcessorCount / 8) * 4u;
   if (hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) != hipSuccess ||
       hipStreamCreateWithFlags(&ctx->copy_stream, hipStreamNonBlocking) != hipSuccess ||
       hipStreamCreateWithFlags(&ctx->d2h_stream, hipStreamNonBlocking) != hipSuccess) {
@@ -525,7 +530,13 @@ extern "C" int vpcc_gof_reconstruct(vpcc_gof* g, uint32_t first, uint32_t count,
     // (a frame without tiles keeps the zero written at creation).
     g->generation = (g->generation % 0x3FFFFFFFu) + 1u;
     T.begin("k_recon_tiles");
-    launch_tiles(g->d_frames, first, count, max_groups, g->generation, s);
+    if (!g->tile_map_valid || g->tile_map_first != first || g->tile_map_count != count) {
+      std::vector<uint32_t> tiles(count);
+      for (uint32_t i = 0; i < count; ++i) tiles[i] = (uint32_t)g->plans[first + i].tiles.size();
+      plan_tile_launch(tiles.data(), count, ctx->resident_tile_wgs_per_xcd, 3, g->tile_map);
+      g->tile_map_first = first; g->tile_map_count = count; g->tile_map_valid = true;
+    }
+    launch_tiles(g->d_frames, first, count, max_groups, g->generation, g->tile_map, s);
     T.end();
     HIP_TRY(ctx, hipGetLastError());
     HIP_TRY(ctx, hipEventRecord(g->results_ready, s));

@@ -707,14 +707,22 @@ __device__ __forceinline__ uint32_t item_in_group(uint32_t wave, uint32_t i) {
 template <bool kStamps>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(VPCC_TILES_WAVES_PER_EU, VPCC_TILES_WAVES_PER_EU)))
 void k_recon_tiles(const DevFrame* __restrict__ frames, uint32_t first,
-                                                     uint32_t count, uint32_t groups_stride, uint32_t gen,
-                                                     uint32_t variant_arg) {
+                                                     uint32_t count, uint32_t groups_stride_arg, uint32_t gen,
+                                                     uint32_t variant_arg, const TileLaunchMap map) {
   const uint32_t variant = kDiagnostic ? variant_arg : 0u;
   // XCD-aware placement (speed only): ids equal mod 8 share an XCD/L2; a frame stays on one label.
   // The frames of one label are interleaved, so the workgroups of ONE frame start a few slots apart.
   const uint32_t xcd = blockIdx.x & 7u, slot = blockIdx.x >> 3;
   const uint32_t frame_groups = (count + 7u) / 8u;
-  const uint32_t fi = xcd + 8u * (slot % frame_groups);   // (spreading a frame over all XCDs instead: 0.147 -> 0.164 ms)
+  uint32_t fi = xcd + 8u * (slot % frame_groups);         // (spreading a frame over all XCDs instead: 0.147 -> 0.164 ms)
+  uint32_t groups_stride = groups_stride_arg;              // workgroups of this frame in the launch
+  if (map.slots) {                                          // shares in proportion to the frames' sizes (TileLaunchMap)
+    if (slot >= map.slots) return;
+    const uint32_t v = map.frame_of_slot[xcd][slot];
+    if (v == 0xFFu) return;
+    fi = xcd + 8u * v;
+    groups_stride = map.wgs_of_slot[xcd][slot];
+  }
   if (fi >= count) return;
   const DevFrame& f = frames[first + fi];
 #ifdef VPCC_DIAGNOSTIC
@@ -1016,7 +1024,7 @@ extern "C" int vpcc_debug_read_stamps(unsigned long long* out16, int reset) {
 namespace vpcc {
 
 void launch_tiles(const DevFrame* d_frames, uint32_t first, uint32_t count, uint32_t max_groups, uint32_t gen,
-                  void* stream) {
+                  const TileLaunchMap& map, void* stream) {
   if (!count || !max_groups) return;
   // groups each workgroup is expected to pipeline (tickets are drawn dynamically; this only sizes the grid)
   uint32_t depth = 3, variant = 0;
@@ -1035,16 +1043,16 @@ void launch_tiles(const DevFrame* d_frames, uint32_t first, uint32_t count, uint
 #endif
   const uint32_t frame_groups = (count + 7u) / 8u;
   const uint32_t wgs = (max_groups + depth - 1u) / depth;     // workgroups per frame
-  const uint32_t grid = 8u * frame_groups * wgs;
+  const uint32_t grid = map.slots ? 8u * map.slots : 8u * frame_groups * wgs;
 #ifdef VPCC_DIAGNOSTIC
   if (variant & 64u) {
     hipLaunchKernelGGL(k_recon_tiles<true>, dim3(grid), dim3(256), 0, (hipStream_t)stream, d_frames, first, count,
-                       wgs, gen, variant);
+                       wgs, gen, variant, map);
     return;
   }
 #endif
   hipLaunchKernelGGL(k_recon_tiles<false>, dim3(grid), dim3(256), 0, (hipStream_t)stream, d_frames, first, count,
-                     wgs, gen, variant);
+                     wgs, gen, variant, map);
 }
 
 }  // namespace vpcc

@@ -9,8 +9,9 @@ REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(REPO, "tmc2-rs_amd"))
 from tmc2rs import recon, synth, _abi
 ctx = recon.Context(0)
-frames = [synth.longdress_frame(i) for i in range(32)]
-g = ctx.gof(frames, capacity=1_000_000)
+owlii = os.environ.get("VPCC_WORKLOAD") == "owlii"
+frames = [(synth.owlii_frame if owlii else synth.longdress_frame)(i) for i in range(32)]
+g = ctx.gof(frames, capacity=2_400_000 if owlii else 1_000_000)
 lib = _abi.load_library()
 for _ in range(3):
     g.reconstruct()
