@@ -106,20 +106,35 @@ __global__ __launch_bounds__(256) void k_smooth_stats(const DevFrame* __restrict
   }
   SmoothCell* grid = sg.cells(blockIdx.y);
   uint64_t todo = __ballot(active);
+  // Two of the three sums share one reduction when no value of the wave exceeds 1023 (64 x 1023 < 2^16): always for
+  // colours, and for coordinates of 10-bit content.
+  const bool pack = __ballot((v[0] | v[1]) > 1023u) == 0;
+  const uint32_t v01 = v[0] | (v[1] << 16);
   while (todo) {                                           // one trip per distinct cell of the wave
     const uint32_t k = (uint32_t)__builtin_amdgcn_readlane((int)key, (int)__builtin_ctzll(todo));
     const bool in = active && key == k;
     const uint64_t mask = __ballot(in);
-    const uint32_t s0 = wave_reduce<false>(in ? v[0] : 0u), s1 = wave_reduce<false>(in ? v[1] : 0u),
-                   s2 = wave_reduce<false>(in ? v[2] : 0u);
+    uint32_t s0, s1;
+    if (pack) {
+      const uint32_t s01 = wave_reduce<false>(in ? v01 : 0u);
+      s0 = s01 & 0xFFFFu; s1 = s01 >> 16;
+    } else {
+      s0 = wave_reduce<false>(in ? v[0] : 0u); s1 = wave_reduce<false>(in ? v[1] : 0u);
+    }
+    const uint32_t s2 = wave_reduce<false>(in ? v[2] : 0u);
     // {max(65535 - patch), max(patch)} in one packed-16 reduction
     const uint32_t mm = wave_reduce<true>(in ? ((65535u - patch) << 16) | patch : 0u);
-    if (lane < 6u) {
-      uint32_t* word = &(grid + k)->count + lane;           // count, s[0..2], negminp, maxp
-      const uint32_t val = lane == 0 ? (uint32_t)__builtin_popcountll(mask) : lane == 1 ? s0 : lane == 2 ? s1 : lane == 3 ? s2
-                           : lane == 4 ? mm >> 16 : mm & 0xFFFFu;
-      if (lane < 4u) atomicAdd(word, val);
-      else atomicMax(word, val);
+    // Four L2 operations per cell instead of six: {count, s[0]} and {s[1], s[2]} are 8-byte aligned pairs (a cell is
+    // 24 B) and go as two 64-bit adds — no carry crosses the halves, the low word of each pair stays below 2^32.
+    if (lane < 4u) {
+      uint32_t* word = &(grid + k)->count;                  // count, s[0..2], negminp, maxp
+      if (lane < 2u) {
+        const uint64_t val = lane == 0 ? (uint64_t)(uint32_t)__builtin_popcountll(mask) | ((uint64_t)s0 << 32)
+                                       : (uint64_t)s1 | ((uint64_t)s2 << 32);
+        atomicAdd(reinterpret_cast<unsigned long long*>(word) + lane, (unsigned long long)val);
+      } else {
+        atomicMax(word + 2u + lane, lane == 2 ? mm >> 16 : mm & 0xFFFFu);
+      }
     }
     todo &= ~mask;
   }

@@ -1,0 +1,27 @@
+#!/bin/bash
+# Counters of the smoothing kernels (run on the GPU box): instruction mix, wave occupancy, L2 atomics.
+# Usage: tools/pmc_smooth.sh <outdir>
+out=$1; mkdir -p "$out"; out=$(cd "$out" && pwd)
+R=$GRAFT_REPO_ROOT
+cd /tmp; export TMPDIR=/tmp
+pass() { name=$1; shift
+  rocprofv3 --kernel-trace --pmc "$@" --output-format csv -d "$out/$name" -- python3 $R/bench.py --smooth --steps 3 --warmup 1 --ramp-ms 0 --min-seconds 0 --no-cpu-baseline --no-verify --no-end-to-end > "$out/$name.log" 2>&1 || echo "pass $name failed"; }
+pass a SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_VMEM_WR SQ_INSTS_VMEM_RD SQ_WAVES
+pass b SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_SCA SQ_WAIT_INST_ANY
+pass c TCC_ATOMIC_sum TCC_REQ_sum TCC_EA0_WRREQ_sum TCC_EA0_RDREQ_sum
+pass d SQ_INSTS_LDS SQ_INST_CYCLES_SALU SQ_THREAD_CYCLES_VALU GRBM_GUI_ACTIVE
+python3 - "$out" <<'PY'
+import csv, glob, sys, collections
+out = sys.argv[1]
+acc = collections.defaultdict(lambda: collections.defaultdict(list))
+for f in glob.glob(out + "/*/**/*counter_collection.csv", recursive=True):
+    for r in csv.DictReader(open(f)):
+        k = r["Kernel_Name"].split("(")[0].replace("void vpcc::", "")
+        if "smooth" in k:
+            acc[k][r["Counter_Name"]].append(float(r["Counter_Value"]))
+for k in sorted(acc):
+    print(k)
+    for c in sorted(acc[k]):
+        v = acc[k][c]
+        print(f"   {c:26s} {sum(v)/len(v):14.0f}   (n={len(v)})")
+PY
