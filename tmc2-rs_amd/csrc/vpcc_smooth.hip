@@ -84,12 +84,14 @@ __device__ __forceinline__ uint32_t wave_reduce(uint32_t v) {
 // every point added with LDS atomics into an 8x8x8-cell window of the grid held in LDS, occupied cells flushed
 // with six global atomics each 1.19 ms (lanes of one instruction that hit the same LDS word are served one at a
 // time, ~4 cycles each).
-__global__ __launch_bounds__(256) void k_smooth_stats(const DevFrame* __restrict__ frames, uint32_t first,
-                                                      SmoothGrid sg, uint32_t w, uint32_t G, uint32_t mode) {
-  const DevFrame& f = frames[first + blockIdx.y];
-  const uint32_t n = min(*gl(f.n_points), f.capacity);
-  const uint32_t i = blockIdx.x * 256u + threadIdx.x;
-  if (blockIdx.x * 256u >= n) return;
+// Every workgroup handles kSmoothChunks chunks of 256 consecutive points: with one chunk per workgroup these
+// kernels were bound by the rate at which workgroups can be launched (1.3-1.7 resident waves per SIMD on average,
+// VALU 23 % busy — tools/pmc_smooth.sh), not by anything they do.
+constexpr uint32_t kSmoothChunks = 4;
+__device__ __forceinline__ void smooth_stats_chunk(const DevFrame& f, uint32_t frame, uint32_t chunk, uint32_t n,
+                                                   SmoothGrid sg, uint32_t w, uint32_t G, uint32_t mode) {
+  const uint32_t i = chunk * 256u + threadIdx.x;
+  if (chunk * 256u >= n) return;
   const bool active = i < n;
   const uint32_t lane = threadIdx.x & 63u;
   uint32_t key = 0xFFFFFFFFu, v[3] = {0, 0, 0}, patch = 0;
@@ -102,9 +104,9 @@ __global__ __launch_bounds__(256) void k_smooth_stats(const DevFrame* __restrict
       v[0] = col.r; v[1] = col.g; v[2] = col.b;
     }
     patch = gl(f.out_patch)[i];
-    sg.keys(blockIdx.y)[i] = key;
+    sg.keys(frame)[i] = key;
   }
-  SmoothCell* grid = sg.cells(blockIdx.y);
+  SmoothCell* grid = sg.cells(frame);
   uint64_t todo = __ballot(active);
   // Two of the three sums share one reduction when no value of the wave exceeds 1023 (64 x 1023 < 2^16): always for
   // colours, and for coordinates of 10-bit content.
@@ -138,6 +140,14 @@ __global__ __launch_bounds__(256) void k_smooth_stats(const DevFrame* __restrict
     }
     todo &= ~mask;
   }
+}
+
+__global__ __launch_bounds__(256) void k_smooth_stats(const DevFrame* __restrict__ frames, uint32_t first,
+                                                      SmoothGrid sg, uint32_t w, uint32_t G, uint32_t mode) {
+  const DevFrame& f = frames[first + blockIdx.y];
+  const uint32_t n = min(*gl(f.n_points), f.capacity);
+#pragma unroll 1
+  for (uint32_t c = 0; c < kSmoothChunks; ++c) smooth_stats_chunk(f, blockIdx.y, blockIdx.x * kSmoothChunks + c, n, sg, w, G, mode);
 }
 
 namespace {
@@ -234,13 +244,10 @@ __device__ __forceinline__ bool load_hood(const SmoothCell* grid, const int32_t 
 }
 }  // namespace
 
-__global__ __launch_bounds__(256) void k_smooth_apply_geometry(const DevFrame* __restrict__ frames, uint32_t first,
-                                                               SmoothGrid sg, uint32_t w, uint32_t G, uint32_t T) {
-  const DevFrame& f = frames[first + blockIdx.y];
-  const uint32_t n = min(*gl(f.n_points), f.capacity);
-  const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+__device__ __forceinline__ void smooth_apply_geometry_point(const DevFrame& f, uint32_t frame, uint32_t i, uint32_t n,
+                                                            SmoothGrid sg, uint32_t w, uint32_t G, uint32_t T) {
   if (i >= n) return;
-  if (!sg.flags(blockIdx.y)[sg.keys(blockIdx.y)[i]]) return;        // no mixed cell anywhere near this point (k_smooth_mark)
+  if (!sg.flags(frame)[sg.keys(frame)[i]]) return;        // no mixed cell anywhere near this point (k_smooth_mark)
   const vpcc_point3 pt = gload(f.out_xyz + i);
   const uint32_t p[3] = {pt.x, pt.y, pt.z};
   int32_t s[3];
@@ -248,7 +255,7 @@ __global__ __launch_bounds__(256) void k_smooth_apply_geometry(const DevFrame* _
 #pragma unroll
   for (int a = 0; a < 3; ++a) axis_setup(p[a], G, w, s[a], wt[a]);
   Hood h;
-  if (!load_hood(sg.cells(blockIdx.y), s, w, h)) return;
+  if (!load_hood(sg.cells(frame), s, w, h)) return;
   int64_t num[3] = {0, 0, 0}, den = 0;
 #pragma unroll
   for (int d = 0; d < 8; ++d) {
@@ -274,13 +281,19 @@ __global__ __launch_bounds__(256) void k_smooth_apply_geometry(const DevFrame* _
   }
 }
 
-__global__ __launch_bounds__(256) void k_smooth_apply_color(const DevFrame* __restrict__ frames, uint32_t first,
-                                                            SmoothGrid sg, uint32_t w, uint32_t G, uint32_t Ts, uint32_t Td) {
+__global__ __launch_bounds__(256) void k_smooth_apply_geometry(const DevFrame* __restrict__ frames, uint32_t first,
+                                                               SmoothGrid sg, uint32_t w, uint32_t G, uint32_t T) {
   const DevFrame& f = frames[first + blockIdx.y];
   const uint32_t n = min(*gl(f.n_points), f.capacity);
-  const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+#pragma unroll 1
+  for (uint32_t c = 0; c < kSmoothChunks; ++c)
+    smooth_apply_geometry_point(f, blockIdx.y, (blockIdx.x * kSmoothChunks + c) * 256u + threadIdx.x, n, sg, w, G, T);
+}
+
+__device__ __forceinline__ void smooth_apply_color_point(const DevFrame& f, uint32_t frame, uint32_t i, uint32_t n,
+                                                         SmoothGrid sg, uint32_t w, uint32_t G, uint32_t Ts, uint32_t Td) {
   if (i >= n) return;
-  if (!sg.flags(blockIdx.y)[sg.keys(blockIdx.y)[i]]) return;        // no mixed cell anywhere near this point (k_smooth_mark)
+  if (!sg.flags(frame)[sg.keys(frame)[i]]) return;        // no mixed cell anywhere near this point (k_smooth_mark)
   const vpcc_point3 pt = gload(f.out_xyz + i);
   const uint32_t p[3] = {pt.x, pt.y, pt.z};
   int32_t s[3];
@@ -288,7 +301,7 @@ __global__ __launch_bounds__(256) void k_smooth_apply_color(const DevFrame* __re
 #pragma unroll
   for (int a = 0; a < 3; ++a) axis_setup(p[a], G, w, s[a], wt[a]);
   Hood h;
-  if (!load_hood(sg.cells(blockIdx.y), s, w, h)) return;
+  if (!load_hood(sg.cells(frame), s, w, h)) return;
   const vpcc_color3 col = gload(f.out_rgb + i);
   const int64_t cl[3] = {col.r, col.g, col.b};
   // the point's own cell is one of the eight: index of (q - s) per axis
@@ -330,23 +343,33 @@ __global__ __launch_bounds__(256) void k_smooth_apply_color(const DevFrame* __re
   }
 }
 
+__global__ __launch_bounds__(256) void k_smooth_apply_color(const DevFrame* __restrict__ frames, uint32_t first,
+                                                            SmoothGrid sg, uint32_t w, uint32_t G, uint32_t Ts, uint32_t Td) {
+  const DevFrame& f = frames[first + blockIdx.y];
+  const uint32_t n = min(*gl(f.n_points), f.capacity);
+#pragma unroll 1
+  for (uint32_t c = 0; c < kSmoothChunks; ++c)
+    smooth_apply_color_point(f, blockIdx.y, (blockIdx.x * kSmoothChunks + c) * 256u + threadIdx.x, n, sg, w, G, Ts, Td);
+}
+
+
 void launch_smooth_stats(const DevFrame* d_frames, uint32_t first, uint32_t count, uint32_t max_points, SmoothGrid sg,
                          uint32_t w, uint32_t G, uint32_t mode, void* stream) {
   if (!count || !max_points) return;
-  hipLaunchKernelGGL(k_smooth_stats, dim3((max_points + 255) / 256, count), dim3(256), 0, (hipStream_t)stream, d_frames,
-                     first, sg, w, G, mode);
+  hipLaunchKernelGGL(k_smooth_stats, dim3((max_points + 256 * kSmoothChunks - 1) / (256 * kSmoothChunks), count), dim3(256), 0,
+                     (hipStream_t)stream, d_frames, first, sg, w, G, mode);
 }
 void launch_smooth_apply_geometry(const DevFrame* d_frames, uint32_t first, uint32_t count, uint32_t max_points,
                                   SmoothGrid sg, uint32_t w, uint32_t G, uint32_t T, void* stream) {
   if (!count || !max_points) return;
-  hipLaunchKernelGGL(k_smooth_apply_geometry, dim3((max_points + 255) / 256, count), dim3(256), 0, (hipStream_t)stream,
-                     d_frames, first, sg, w, G, T);
+  hipLaunchKernelGGL(k_smooth_apply_geometry, dim3((max_points + 256 * kSmoothChunks - 1) / (256 * kSmoothChunks), count), dim3(256),
+                     0, (hipStream_t)stream, d_frames, first, sg, w, G, T);
 }
 void launch_smooth_apply_color(const DevFrame* d_frames, uint32_t first, uint32_t count, uint32_t max_points,
                                SmoothGrid sg, uint32_t w, uint32_t G, uint32_t Ts, uint32_t Td, void* stream) {
   if (!count || !max_points) return;
-  hipLaunchKernelGGL(k_smooth_apply_color, dim3((max_points + 255) / 256, count), dim3(256), 0, (hipStream_t)stream,
-                     d_frames, first, sg, w, G, Ts, Td);
+  hipLaunchKernelGGL(k_smooth_apply_color, dim3((max_points + 256 * kSmoothChunks - 1) / (256 * kSmoothChunks), count), dim3(256), 0,
+                     (hipStream_t)stream, d_frames, first, sg, w, G, Ts, Td);
 }
 void launch_smooth_mark(const DevFrame* d_frames, uint32_t first, uint32_t count, uint32_t max_points, SmoothGrid sg,
                         uint32_t w, void* stream) {
