@@ -88,7 +88,7 @@ def parse():
 def smoothing_algorithmic_bytes(gof, n_frames, bitdepth, grid, cgrid):
     """Algorithmic bytes of one smoothing pass pair over the GOF: per point read
     xyz 6 + rgb 3 + patch index 2 B and write 9 B; per occupied grid cell 24 B written and read once,
-    for the geometry grid and for the colour grid."""
+    for the geometry grid and for the colour grid (the verdict's figure; the kernels' cells are 32 B)."""
     import numpy as np
     total = 0
     for i in range(n_frames):

@@ -94,13 +94,19 @@ struct DevFrame {
 };
 
 // One grid cell of the smoothing filters (oracle/vpcc_smoothing_spec.h): all-zero = empty.
+// Every field is a SUM, so that a wave updates a cell with ONE atomic instruction (four 64-bit adds: {count, s0},
+// {s1, s2}, sp2, {sp, 0}; no carry crosses a pair's halves): the statistics kernel is bound by the number of atomic
+// instructions a CU can issue, not by their lanes.  "The cell holds points of more than one patch" (the spec's
+// min patch index != max patch index) is count * sp2 != sp * sp — equality in Cauchy-Schwarz holds exactly when all
+// patch indices are equal; count < 2^22, index < 2^16: both sides stay below 2^60.
 struct SmoothCell {
   uint32_t count;
   uint32_t s[3];        // coordinate sums (geometry) or R,G,B sums (colour)
-  uint32_t negminp;     // max over points of (65535 - patch index): lets a zeroed cell take atomicMax
-  uint32_t maxp;        // max patch index
+  uint64_t sp2;         // sum of squared patch indices
+  uint32_t sp;          // sum of patch indices
+  uint32_t mixed;       // set by k_smooth_mark on the cells that hold more than one patch (the statistics kernel adds 0 here)
 };
-static_assert(sizeof(SmoothCell) == 24, "SmoothCell is 24 B");
+static_assert(sizeof(SmoothCell) == 32, "SmoothCell is 32 B");
 
 #if defined(__HIPCC__)
 #define VPCC_HD __host__ __device__

@@ -74,7 +74,7 @@ __device__ __forceinline__ uint32_t wave_reduce(uint32_t v) {
 // mode 0: sums of coordinates (geometry); mode 1: sums of R,G,B (colour).
 // Points arrive in emission order, so the 64 points of a wave fall into a handful of cells (a block row of
 // 16 pixels spans two cells of size 8).  The wave reduces its points per distinct cell first and issues ONE
-// set of atomics per cell (six lanes, one word each, nothing returned).  The grids are all-zero between
+// atomic instruction per cell (four 64-bit adds, nothing returned: every field of a cell is a sum).  The grids are all-zero between
 // launches: every point's cell index is kept, and k_smooth_clear zeroes exactly those cells afterwards — no
 // dense memset (50 MB per frame at w = 128) per launch.
 // Measured alternatives, per 32 S-longdress frames (this form: 0.31 ms): one set of atomics per point 17.5 ms; a
@@ -83,7 +83,9 @@ __device__ __forceinline__ uint32_t wave_reduce(uint32_t v) {
 // retires ~12 per ns); the same merged through an LDS table with ds_cmpst/ds_add per workgroup 0.62-0.70 ms;
 // every point added with LDS atomics into an 8x8x8-cell window of the grid held in LDS, occupied cells flushed
 // with six global atomics each 1.19 ms (lanes of one instruction that hit the same LDS word are served one at a
-// time, ~4 cycles each).
+// time, ~4 cycles each).  With {max(65535 - patch), max(patch)} as two 32-bit max operations next to the adds (two
+// atomic instructions per cell) 0.29-0.30 ms, with all-sum cells (one instruction) 0.245; collecting up to 16 cells of a
+// wave into ONE atomic instruction changed nothing further, nor did removing reductions from the loop.
 // Every workgroup handles kSmoothChunks chunks of 256 consecutive points: with one chunk per workgroup these
 // kernels were bound by the rate at which workgroups can be launched (1.3-1.7 resident waves per SIMD on average,
 // VALU 23 % busy — tools/pmc_smooth.sh), not by anything they do.
@@ -124,19 +126,23 @@ __device__ __forceinline__ void smooth_stats_chunk(const DevFrame& f, uint32_t f
       s0 = wave_reduce<false>(in ? v[0] : 0u); s1 = wave_reduce<false>(in ? v[1] : 0u);
     }
     const uint32_t s2 = wave_reduce<false>(in ? v[2] : 0u);
-    // {max(65535 - patch), max(patch)} in one packed-16 reduction
-    const uint32_t mm = wave_reduce<true>(in ? ((65535u - patch) << 16) | patch : 0u);
-    // Four L2 operations per cell instead of six: {count, s[0]} and {s[1], s[2]} are 8-byte aligned pairs (a cell is
-    // 24 B) and go as two 64-bit adds — no carry crosses the halves, the low word of each pair stays below 2^32.
+    // sums of the patch indices and of their squares: the points a wave has in one cell nearly always belong to ONE
+    // patch — then both follow from the count; else two more reductions
+    const uint32_t cnt = (uint32_t)__builtin_popcountll(mask);
+    const uint32_t pl = (uint32_t)__builtin_amdgcn_readlane((int)patch, (int)__builtin_ctzll(mask));
+    uint32_t sp = cnt * pl;
+    uint64_t sp2 = (uint64_t)sp * pl;
+    if (__ballot(in && patch != pl) != 0) {
+      sp = wave_reduce<false>(in ? patch : 0u);
+      // squares of 16-bit indices: 64 of them fit 2^38 — low and high halves of p^2 are summed apart
+      const uint32_t q = patch * patch;
+      sp2 = (uint64_t)wave_reduce<false>(in ? q & 0xFFFFu : 0u) + ((uint64_t)wave_reduce<false>(in ? q >> 16 : 0u) << 16);
+    }
     if (lane < 4u) {
-      uint32_t* word = &(grid + k)->count;                  // count, s[0..2], negminp, maxp
-      if (lane < 2u) {
-        const uint64_t val = lane == 0 ? (uint64_t)(uint32_t)__builtin_popcountll(mask) | ((uint64_t)s0 << 32)
-                                       : (uint64_t)s1 | ((uint64_t)s2 << 32);
-        atomicAdd(reinterpret_cast<unsigned long long*>(word) + lane, (unsigned long long)val);
-      } else {
-        atomicMax(word + 2u + lane, lane == 2 ? mm >> 16 : mm & 0xFFFFu);
-      }
+      const uint64_t val = lane == 0 ? (uint64_t)cnt | ((uint64_t)s0 << 32)
+                         : lane == 1 ? (uint64_t)s1 | ((uint64_t)s2 << 32)
+                         : lane == 2 ? sp2 : (uint64_t)sp;
+      atomicAdd(reinterpret_cast<unsigned long long*>(grid + k) + lane, (unsigned long long)val);
     }
     todo &= ~mask;
   }
@@ -151,7 +157,7 @@ __global__ __launch_bounds__(256) void k_smooth_stats(const DevFrame* __restrict
 }
 
 namespace {
-__device__ __forceinline__ bool cell_mixed(const SmoothCell& c) { return c.count != 0 && (65535u - c.negminp) != c.maxp; }
+__device__ __forceinline__ bool cell_mixed(const SmoothCell& c) { return (uint64_t)c.count * c.sp2 != (uint64_t)c.sp * c.sp; }
 
 // Writes `value` into the flag of every cell of the 3x3x3 block around cell `key` (clipped to the grid).
 __device__ __forceinline__ void paint_flags(unsigned char* flags, uint32_t key, uint32_t w, unsigned char value) {
@@ -198,7 +204,10 @@ __global__ __launch_bounds__(256) void k_smooth_mark(const DevFrame* __restrict_
   const uint32_t lead = load_keys4(sg.keys(blockIdx.y), i4, n, k);
 #pragma unroll
   for (uint32_t j = 0; j < 4; ++j)
-    if (((lead >> j) & 1u) && cell_mixed(gload(sg.cells(blockIdx.y) + k[j]))) paint_flags(sg.flags(blockIdx.y), k[j], w, 1);
+    if (((lead >> j) & 1u) && cell_mixed(gload(sg.cells(blockIdx.y) + k[j]))) {
+      paint_flags(sg.flags(blockIdx.y), k[j], w, 1);
+      (sg.cells(blockIdx.y) + k[j])->mixed = 1u;             // for the apply kernels: the 64-bit test once per cell, not per point
+    }
 }
 
 // Restores the all-zero state: the first point of every run of equal cell indices un-paints the flags of a mixed
@@ -217,9 +226,9 @@ __global__ __launch_bounds__(256) void k_smooth_clear(const DevFrame* __restrict
     SmoothCell* cell = sg.cells(blockIdx.y) + k[j];
     const SmoothCell seen = gload(cell);
     if (seen.count == 0) continue;                            // an earlier run of the same cell has cleared it
-    if (cell_mixed(seen)) paint_flags(sg.flags(blockIdx.y), k[j], w, 0);
-    uint2* c = reinterpret_cast<uint2*>(cell);
-    c[0] = make_uint2(0u, 0u); c[1] = make_uint2(0u, 0u); c[2] = make_uint2(0u, 0u);
+    if (seen.mixed) paint_flags(sg.flags(blockIdx.y), k[j], w, 0);
+    uint4* c = reinterpret_cast<uint4*>(cell);
+    c[0] = make_uint4(0u, 0u, 0u, 0u); c[1] = make_uint4(0u, 0u, 0u, 0u);
   }
 }
 
@@ -238,7 +247,7 @@ __device__ __forceinline__ bool load_hood(const SmoothCell* grid, const int32_t 
     h.inside[d] = !(cx < 0 || cy < 0 || cz < 0 || cx >= (int32_t)w || cy >= (int32_t)w || cz >= (int32_t)w);
     h.c[d] = SmoothCell{};
     if (h.inside[d]) h.c[d] = gload(grid + ((size_t)cz * w + cy) * w + cx);
-    mixed |= h.c[d].count != 0 && (65535u - h.c[d].negminp) != h.c[d].maxp;
+    mixed |= h.c[d].mixed != 0;
   }
   return mixed;
 }
@@ -326,7 +335,7 @@ __device__ __forceinline__ void smooth_apply_color_point(const DevFrame& f, uint
     const int64_t W = wt[0][d & 1] * wt[1][(d >> 1) & 1] * wt[2][d >> 2];
     num[0] += W * c.s[0]; num[1] += W * c.s[1]; num[2] += W * c.s[2];
     den += W * c.count;
-    mixed |= (65535u - c.negminp) != c.maxp;
+    mixed |= c.mixed != 0;
   }
   if (!mixed || den <= 0) return;
   int64_t m[3], dist = 0;
