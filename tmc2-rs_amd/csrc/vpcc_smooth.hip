@@ -85,7 +85,8 @@ __device__ __forceinline__ uint32_t wave_reduce(uint32_t v) {
 // with six global atomics each 1.19 ms (lanes of one instruction that hit the same LDS word are served one at a
 // time, ~4 cycles each).  With {max(65535 - patch), max(patch)} as two 32-bit max operations next to the adds (two
 // atomic instructions per cell) 0.29-0.30 ms, with all-sum cells (one instruction) 0.245; collecting up to 16 cells of a
-// wave into ONE atomic instruction changed nothing further, nor did removing reductions from the loop.
+// wave into ONE atomic instruction changed nothing further, nor did removing reductions from the loop.  Where the
+// 0.245 ms go (ablations): loads + key store 0.06 (at the memory rate), the de-duplication loop 0.10, the atomics 0.08.
 // Every workgroup handles kSmoothChunks chunks of 256 consecutive points: with one chunk per workgroup these
 // kernels were bound by the rate at which workgroups can be launched (1.3-1.7 resident waves per SIMD on average,
 // VALU 23 % busy — tools/pmc_smooth.sh), not by anything they do.
