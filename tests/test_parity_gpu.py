@@ -119,6 +119,30 @@ def test_full_size_owlii_frame(ctx):
     _check(ctx.reconstruct_frame(f, want_patch_index=True), ref)
 
 
+def test_gof_of_very_unequal_frames_on_the_tile_path(ctx):
+    """Frames of one launch get shares of the resident workgroups in proportion to their tile counts
+    (TileLaunchMap, plan_tile_launch): a GOF that mixes one full-size frame, medium and tiny frames and frames
+    without any patch — over full, partial and single-frame launch ranges, repeated (every launch re-arms the ticket
+    counters with the shares of ITS range)."""
+    empty = dict(synth.small_frame(3))
+    empty["patches"] = empty["patches"][:0]
+    makers = [lambda i: synth.longdress_frame(i), lambda i: cases.medium_frame(i), lambda i: synth.small_frame(i),
+              lambda i: dict(empty), lambda i: cases.medium_frame(100 + i, occupancy_values="random"),
+              lambda i: synth.small_frame(50 + i)]
+    order = [0, 1, 2, 3, 4, 5, 1, 2, 2, 3, 1, 4, 5, 5, 2, 1, 3, 2, 4, 1, 2, 5, 1, 2]       # one big frame, 24 in all
+    frames = [makers[k](i) for i, k in enumerate(order)]
+    refs = [ob.reconstruct(f)[1] for f in frames]
+    g = ctx.gof(frames, flags=_abi.VPCC_GOF_PROFILE | _abi.VPCC_GOF_WANT_PATCH_INDEX)
+    for first, count in [(0, None), (0, None), (3, 10), (0, 1), (23, 1), (5, 19), (0, None)]:
+        g.reconstruct(first=first, count=count)
+        assert [k for k, _ in g.kernel_times()] == ["k_recon_tiles"]
+        counts = g.point_counts()
+        for i in range(first, len(frames) if count is None else first + count):
+            assert counts[i] == refs[i]["n"], (first, count, i)
+            _check(g.download(i, want_patch_index=True), refs[i])
+    g.close()
+
+
 def test_gof_is_deterministic_and_idempotent(ctx):
     frames = [synth.longdress_frame(i) for i in range(4)]
     g = ctx.gof(frames, capacity=1_000_000)
