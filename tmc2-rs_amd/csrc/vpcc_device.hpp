@@ -55,7 +55,11 @@ constexpr uint8_t kTileSwap = 1, kTileMode1 = 2;
 #define VPCC_TILE_ITEMS_PER_WAVE 4
 #endif
 constexpr uint32_t kTileItemsPerWave = VPCC_TILE_ITEMS_PER_WAVE;
-constexpr uint32_t kTileItemsPerGroup = 4 * kTileItemsPerWave;   // 4 waves: one ticket / one look-back word per group
+#ifndef VPCC_TILE_WAVES
+#define VPCC_TILE_WAVES 4                 // waves per workgroup of the tile kernel (experiments: 1, 2)
+#endif
+constexpr uint32_t kTileWaves = VPCC_TILE_WAVES;
+constexpr uint32_t kTileItemsPerGroup = kTileWaves * kTileItemsPerWave;   // one ticket / one look-back word per group
 // Look-back words are allocated one per kTileScanGranule items: enough for the finest ticket granularity any
 // kernel structure uses (one ticket per wave = 4 items); a coarser structure uses the first words only.
 constexpr uint32_t kTileScanGranule = 4;

@@ -701,11 +701,11 @@ __device__ __forceinline__ void emit_item(const DevFrame& f, const Item& it, con
 #define VPCC_TILES_INTERLEAVE 1
 #endif
 __device__ __forceinline__ uint32_t item_in_group(uint32_t wave, uint32_t i) {
-  return VPCC_TILES_INTERLEAVE ? i * 4u + wave : wave * kTileItemsPerWave + i;
+  return VPCC_TILES_INTERLEAVE ? i * kTileWaves + wave : wave * kTileItemsPerWave + i;
 }
 
 template <bool kStamps>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(VPCC_TILES_WAVES_PER_EU, VPCC_TILES_WAVES_PER_EU)))
+__global__ __launch_bounds__(64 * kTileWaves) __attribute__((amdgpu_waves_per_eu(VPCC_TILES_WAVES_PER_EU, VPCC_TILES_WAVES_PER_EU)))
 void k_recon_tiles(const DevFrame* __restrict__ frames, uint32_t first,
                                                      uint32_t count, uint32_t groups_stride_arg, uint32_t gen,
                                                      uint32_t variant_arg, const TileLaunchMap map) {
@@ -716,7 +716,7 @@ void k_recon_tiles(const DevFrame* __restrict__ frames, uint32_t first,
   const uint32_t frame_groups = (count + 7u) / 8u;
   uint32_t fi = xcd + 8u * (slot % frame_groups);         // (spreading a frame over all XCDs instead: 0.147 -> 0.164 ms)
   uint32_t groups_stride = groups_stride_arg;              // workgroups of this frame in the launch
-  if (map.slots) {                                          // shares in proportion to the frames' sizes (TileLaunchMap)
+  if (map.slots && kTileWaves == 4) {                       // shares in proportion to the frames' sizes (TileLaunchMap)
     if (slot >= map.slots) return;
     const uint32_t v = map.frame_of_slot[xcd][slot];
     if (v == 0xFFu) return;
@@ -732,7 +732,7 @@ void k_recon_tiles(const DevFrame* __restrict__ frames, uint32_t first,
 
   __shared__ uint32_t s_group;
   __shared__ uint32_t s_tot[2][kTileItemsPerGroup];                     // point counts of the two groups in flight
-  __shared__ __attribute__((aligned(16))) uint2 s_slots[4][kSlotsPerWave];
+  __shared__ __attribute__((aligned(16))) uint2 s_slots[kTileWaves][kSlotsPerWave];
 
   [[maybe_unused]] unsigned long long t_prev = kStamps ? stamp() : 0ull;
   [[maybe_unused]] unsigned long long t_acc[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
@@ -1043,15 +1043,15 @@ void launch_tiles(const DevFrame* d_frames, uint32_t first, uint32_t count, uint
 #endif
   const uint32_t frame_groups = (count + 7u) / 8u;
   const uint32_t wgs = (max_groups + depth - 1u) / depth;     // workgroups per frame
-  const uint32_t grid = map.slots ? 8u * map.slots : 8u * frame_groups * wgs;
+  const uint32_t grid = (map.slots && kTileWaves == 4) ? 8u * map.slots : 8u * frame_groups * wgs;
 #ifdef VPCC_DIAGNOSTIC
   if (variant & 64u) {
-    hipLaunchKernelGGL(k_recon_tiles<true>, dim3(grid), dim3(256), 0, (hipStream_t)stream, d_frames, first, count,
+    hipLaunchKernelGGL(k_recon_tiles<true>, dim3(grid), dim3(64 * kTileWaves), 0, (hipStream_t)stream, d_frames, first, count,
                        wgs, gen, variant, map);
     return;
   }
 #endif
-  hipLaunchKernelGGL(k_recon_tiles<false>, dim3(grid), dim3(256), 0, (hipStream_t)stream, d_frames, first, count,
+  hipLaunchKernelGGL(k_recon_tiles<false>, dim3(grid), dim3(64 * kTileWaves), 0, (hipStream_t)stream, d_frames, first, count,
                      wgs, gen, variant, map);
 }
 
