@@ -614,7 +614,7 @@ __device__ __forceinline__ void emit_item(const DevFrame& f, const Item& it, con
   before_stores();
   if (n == 0) return;
   if (skeleton) {
-    const uint32_t room = base < f.capacity ? f.capacity - base : 0u, nw = n < room ? n : room;
+    const uint32_t room = base < f.capacity ? f.capacity - base : 0u, nw = (variant & 32u) ? 0u : (n < room ? n : room);
     for (uint32_t k = 2u * lane; k < nw; k += 128u) {
       const uint2 p0 = make_uint2(k, lane), p1 = make_uint2(lane, k);
       if (k + 1u < nw) {
