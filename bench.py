@@ -228,7 +228,7 @@ def main():
                 gofs[0].smooth(bitdepth, **smooth_kw)
         gofs[0].sync()
         t_rep, n_rep = time.perf_counter(), 0
-        while time.perf_counter() - t_rep < 0.25:
+        while n_rep < 256:                                  # short: these launches also end up in a rocprof average of the run
             for _ in range(32):
                 gofs[0].reconstruct()
                 if args.smooth:
