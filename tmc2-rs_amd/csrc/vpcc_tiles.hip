@@ -7,28 +7,30 @@
 // Work decomposition
 //   item   = one virtual block that owns its canvas block (host-filtered, see vpcc_host.cpp), in
 //            the reference's emission order (src/codec.rs:352-385);
-//   wave   = 4 consecutive items, one after the other.  Lane l reads the 4 CANVAS pixels
-//            x0 + 4*(l&3)..+3 of canvas row y0 + (l>>2): 8 contiguous bytes per plane.  For Default
-//            patches "lane order, then pixel order inside the lane" is the reference's emission order;
-//            for Swap patches (u runs down the canvas column) the per-pixel ranks are transposed
-//            through a 16x16 byte matrix in LDS instead of transposing the loads;
-//   group  = one 256-thread workgroup = 4 waves = 16 consecutive items = one ticket and one
-//            look-back word.
+//   group  = 16 consecutive items = one ticket and one look-back word = the work of one 256-thread
+//            workgroup for one step;
+//   wave   = items w, 4+w, 8+w, 12+w of the group, one after the other: the four waves work on four
+//            CONSECUTIVE items at the same time (horizontal neighbours share every 128-byte line).
+//            Lane l reads the 4 CANVAS pixels x0 + 4*(l&3)..+3 of canvas row y0 + (l>>2): 8 contiguous
+//            bytes per plane.  For Default patches "lane order, then pixel order inside the lane" is the
+//            reference's emission order; for Swap patches (u runs down the canvas column) the per-pixel
+//            ranks are transposed through a 16x16 byte matrix in LDS instead of transposing the loads.
 //
-// Per workgroup: a short pipeline over groups of ONE frame (tickets drawn dynamically)
-//   1. count the NEXT group: occupancy + both geometry layers of its 16 items; a D1 point is dropped
-//      when it equals the D0 point (src/codec.rs:422-427); the group total is published;
-//   2. wave 0 obtains the CURRENT group's output offset by decoupled look-back over the earlier groups
-//      of the frame (its total was published one step ago), while every wave already fetches its
-//      first item's samples again (L2-hot);
-//   3. per item (rolled loop, next item's samples prefetched): colour conversion of the lane's 8
+// Per workgroup: a two-stage pipeline over groups of ONE frame (tickets drawn dynamically, a step ahead)
+//   1. count the NEXT group: occupancy + both geometry layers of its 16 items (the geometry stays in
+//      registers until the group is emitted); a D1 point is dropped when it equals the D0 point
+//      (src/codec.rs:422-427); barrier; wave 0 publishes the group total;
+//   2. every wave obtains the CURRENT group's output offset by decoupled look-back over the earlier
+//      groups of the frame (its total was published one step ago; the words were read speculatively
+//      behind the count's loads);
+//   3. per item (unrolled, the next item's attribute samples prefetched): colour conversion of the lane's 8
 //      samples (src/codec.rs:661-687; vpcc_colour.h), then every lane writes one 8-B record
 //      {depth, du, dv, layer | r, g, b} per point into the wave's LDS slots at the point's rank
 //      (= compaction in emission order); then lane <-> point: back-projection
-//      (src/decoder.rs:871-888) and contiguous stores (12 + 6 bytes per lane for two points).
-//   PMC counters, in-kernel stamps and ablations (tools/pmc.sh, tools/stamps.py, tools/variants.sh)
-//   show instruction issue and wave lifetime bounding this kernel, not HBM: hence the division-free
-//   colour path, the byte-permute point assembly, DPP scans and unconditional record writes.
+//      (src/decoder.rs:871-888) and contiguous non-temporal stores (12 + 6 bytes per lane for two points).
+//   What bounds it: with the planes really coming from HBM the kernel runs within 3 % of its
+//   own memory skeleton at ~4 TB/s of memory-side traffic; the arithmetic (half of it the colour conversion) is hidden.
+//   The counter is ONE in-order vmcnt for loads and stores: see "take delivery" below and DESIGN.md 4.1.1.
 //
 // Cross-workgroup ordering is placement-independent (cdna_hip_programming.md §6 Guideline 16):
 // groups are drawn from a per-frame TICKET counter, so a look-back only waits for tickets that
@@ -551,10 +553,6 @@ __device__ __forceinline__ void store_rgb(VPCC_GLOBAL unsigned char* base, uint3
 #ifndef VPCC_TILES_UNROLL_ITEMS
 #define VPCC_TILES_UNROLL_ITEMS 1
 #endif
-// 1: the ticket of the step after next is drawn before the item loop
-#ifndef VPCC_TILES_TICKET_AHEAD
-#define VPCC_TILES_TICKET_AHEAD 1
-#endif
 // 1: pipelined (count group g+1, then emit group g), the emit phase reads the geometry again
 // 3: pipelined, the counted geometry stays in registers (default: every plane byte is requested once)
 // (Measured and dropped, see DESIGN.md: 2 = all samples of a group resident, no pipelining — least traffic,
@@ -754,18 +752,17 @@ void k_recon_tiles(const DevFrame* __restrict__ frames, uint32_t first,
   Samples a_first = {};                // attribute samples of the wave's first item of the current group,
                                        // prefetched during the previous step
   uint32_t t_ahead = 0;
-  if (VPCC_TILES_TICKET_AHEAD && threadIdx.x == 0)
+  if (threadIdx.x == 0)
     t_ahead = __hip_atomic_fetch_add(glw(f.ticket), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  if (VPCC_TILES_TICKET_AHEAD) asm volatile("" : "+v"(t_ahead));   // delivered on every path into the loop: no wait at its top
+  asm volatile("" : "+v"(t_ahead));                            // delivered on every path into the loop: no wait at its top
   for (;;) {
     // ---- 1. draw the NEXT group of this frame.  Every workgroup of the frame stops at its first ticket
     // past the end, so exactly n_groups + groups_stride tickets are drawn per launch: the last re-arms
     // the counter (nothing to clear between launches).
-    // The ticket itself was drawn a step earlier (VPCC_TILES_TICKET_AHEAD): the round trip of the atomic is hidden
+    // The ticket itself was drawn a step earlier: the round trip of the atomic is hidden
     // behind the previous group's item loop instead of being waited for by all four waves at this barrier.
     if (threadIdx.x == 0) {
-      const uint32_t t = VPCC_TILES_TICKET_AHEAD ? t_ahead
-                                                 : __hip_atomic_fetch_add(glw(f.ticket), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      const uint32_t t = t_ahead;
       if (t + 1u == n_groups + groups_stride)
         __hip_atomic_store(glw(f.ticket), 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       s_group = t;
@@ -850,7 +847,7 @@ void k_recon_tiles(const DevFrame* __restrict__ frames, uint32_t first,
       if (lane == 0)
         st_store(f.scan_state + g_next, ((uint64_t)gen << kGenShift) | (g_next == 0 ? kPrefix : kAggregate) | total_next);
     }
-    if (VPCC_TILES_TICKET_AHEAD && threadIdx.x == 0 && have_next)   // a workgroup that saw the end draws no more
+    if (threadIdx.x == 0 && have_next)                       // a workgroup that saw the end draws no more
       t_ahead = __hip_atomic_fetch_add(glw(f.ticket), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     VPCC_STAMP(3)
 #if VPCC_TILES_SETPRIO & 2
@@ -937,7 +934,7 @@ void k_recon_tiles(const DevFrame* __restrict__ frames, uint32_t first,
           // later, the in-order vmcnt would make that wait cover the stores as well.
           emit_item(f, it, cur, dup, n, base, lane, slots, variant, [&]() {
             take_delivery(nxt);
-            if (VPCC_TILES_TICKET_AHEAD) asm volatile("" : "+v"(t_ahead));
+            asm volatile("" : "+v"(t_ahead));
             if (kHandOverEarly && i + 1u == K) {
               // Hand the loop-carried registers over BEFORE the last item's stores: register copies made in
               // the loop latch, behind those stores, are preceded by a vmcnt(0) (with loads and stores both in
@@ -972,7 +969,7 @@ void k_recon_tiles(const DevFrame* __restrict__ frames, uint32_t first,
         for (int j = 0; j < 4; ++j) { gc0[j] = gn0[j]; gc1[j] = gn1[j]; }
       }
       asm volatile("" : "+v"(early));                        // (never read on this path, but pending in the compiler's books)
-      if (VPCC_TILES_TICKET_AHEAD) asm volatile("" : "+v"(t_ahead));
+      asm volatile("" : "+v"(t_ahead));
     }
     if (!have_next) break;
 #ifdef VPCC_DIAGNOSTIC
