@@ -70,16 +70,24 @@ def parse():
     ap.add_argument("--ramp-ms", type=float, default=150.0,
                     help="untimed launches before the warmup steps until this much wall time has passed: a step is ~0.1 ms, "
                          "far shorter than the GPU's clock ramp from idle")
-    ap.add_argument("--frames", type=int, default=32, help="frames per GOF (per rank)")
-    ap.add_argument("--gofs", type=int, default=3,
-                    help="resident GOFs (same frames, separate device buffers) the steps rotate over: consecutive steps "
-                         "must not find the previous step's planes in the 256 MB Infinity Cache (SURVEY 8d); 1 = one GOF "
-                         "reconstructed again and again")
+    ap.add_argument("--frames", type=int, default=32, help="distinct synthetic frames (per rank): one GOF of the sequence")
+    ap.add_argument("--cycles", type=int, default=4,
+                    help="a step reconstructs the --frames distinct frames this many times over, each copy in device buffers "
+                         "of its own, in ONE launch (default 4 x 32 = 128 frames, 3.7 GB: a 300-frame job is two or three such "
+                         "launches).  Larger launches amortise the kernel's ramp and tail: 4.4 us per frame at 32 frames per "
+                         "launch, 3.9 at 128")
+    ap.add_argument("--gofs", type=int, default=1,
+                    help="resident copies of the step's batch that consecutive steps rotate over.  A launch must not find the "
+                         "previous launch's planes in the 256 MB Infinity Cache (SURVEY 8d): the default batch reads 1.2 GB per "
+                         "launch, so one copy is enough; a 32-frame batch (--cycles 1) reads 0.29 GB and needs --gofs 3")
     ap.add_argument("--workload", default="longdress", choices=["longdress", "owlii"])
     ap.add_argument("--general", action="store_true", help="force the general kernel sequence")
     ap.add_argument("--smooth", action="store_true",
                     help="BASELINE config 4: grid geometry + colour smoothing after reconstruction (own spec, see DESIGN.md)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-compare", action="store_true",
+                    help="skip the `launches_of_one_gof` leg (32-frame launches, the step of round 1): its ~1 000 short "
+                         "launches of the same kernel would blur a rocprofv3 average of the run")
     ap.add_argument("--no-verify", action="store_true", help="skip the oracle check of the timed GOF's output (tools/ only)")
     ap.add_argument("--no-end-to-end", action="store_true", help="skip the PCIe-inclusive Decoder run")
     ap.add_argument("--e2e-gofs", type=int, default=4, help="GOFs in the end-to-end container")
@@ -160,7 +168,9 @@ def main():
     # three S-longdress GOFs): with one GOF reconstructed again and again a launch finds part of the planes the
     # previous launch read (290 MB, about the size of the Infinity Cache) still on chip and runs 15-18 % faster than
     # any real stream of GOFs would (tools/two_gofs.py) — that rate is reported as `repeat_one_gof`, never as `value`.
-    gofs = [ctx.gof(frames, capacity=cap, flags=flags) for _ in range(max(args.gofs, 1))]
+    batch = frames * max(args.cycles, 1)                      # the same host planes, uploaded once per copy
+    n_batch = len(batch)
+    gofs = [ctx.gof(batch, capacity=cap, flags=flags) for _ in range(max(args.gofs, 1))]
     for g_ in gofs:
         g_.profile_interval(args.profile_every)
     gof = gofs[0]
@@ -179,11 +189,11 @@ def main():
 
     gof.reconstruct()
     counts = gof.point_counts().astype(np.int64)
-    assert all(gof.frame_status(i) == 0 for i in range(args.frames)), "capacity too small"
+    assert all(gof.frame_status(i) == 0 for i in range(n_batch)), "capacity too small"
     points_per_step = int(counts.sum())
-    alg_bytes = sum(gof.algorithmic_bytes(i) for i in range(args.frames))
+    alg_bytes = sum(gof.algorithmic_bytes(i) for i in range(n_batch))
     smooth_bytes = smoothing_algorithmic_bytes(gof, args.frames, bitdepth, smooth_kw["grid_size"],
-                                               smooth_kw["color_grid_size"]) if args.smooth and rank == 0 else 0
+                                               smooth_kw["color_grid_size"]) * max(args.cycles, 1) if args.smooth and rank == 0 else 0
 
     t_ramp = time.perf_counter()
     while (time.perf_counter() - t_ramp) * 1e3 < args.ramp_ms:     # untimed: brings the clocks up from idle
@@ -219,7 +229,39 @@ def main():
         launches_averaged += n_
     kernels = {name: v / max(launches_averaged, 1) for name, v in kernels.items()}
 
-    # the same launches on ONE GOF over and over (what round 1 timed): reported beside the rotation, never as `value`
+    # Launches of ONE 32-frame GOF, the step of round 1, for comparison (rank 0, never `value`): over three copies in
+    # rotation (an HBM rate) and on one copy again and again (how round 1 was timed; part of its planes stays in the
+    # Infinity Cache).
+    one_gof = None
+    if rank == 0 and world == 1 and not args.smooth and not args.no_compare and max(args.cycles, 1) > 1:
+        small = [ctx.gof(frames, capacity=cap, flags=flags & ~_abi.VPCC_GOF_PROFILE) for _ in range(3)]
+
+        def leg(seq, launches=384):
+            for k_ in range(48):
+                seq[k_ % len(seq)].reconstruct()
+            for g_ in seq:
+                g_.sync()
+            t_ = time.perf_counter()
+            for k_ in range(launches):
+                seq[k_ % len(seq)].reconstruct()
+            for g_ in seq:
+                g_.sync()
+            return (time.perf_counter() - t_) / launches
+
+        pts32 = int(counts[:args.frames].sum())
+        alg32 = sum(gof.algorithmic_bytes(i) for i in range(args.frames))
+        t_rot, t_one = leg(small), leg(small[:1])
+        one_gof = {"frames_per_launch": args.frames,
+                   "rotating_over_3": {"ms_per_launch": round(t_rot * 1e3, 4), "Mpoints_per_s": round(pts32 / t_rot / 1e6, 1),
+                                       "frac": round(alg32 / t_rot / 1e9 / HBM_PEAK_GBPS, 4)},
+                   "one_copy_repeated": {"ms_per_launch": round(t_one * 1e3, 4), "Mpoints_per_s": round(pts32 / t_one / 1e6, 1),
+                                         "frac_if_it_were_hbm": round(alg32 / t_one / 1e9 / HBM_PEAK_GBPS, 4),
+                                         "note": "how round 1 was timed (0.1467 ms, frac 0.677); not an HBM rate: part of the "
+                                                 "0.29 GB a launch reads stays in the 256 MB Infinity Cache"}}
+        for g_ in small:
+            g_.close()
+
+    # the same launches on ONE batch over and over, when the steps rotate over several (--gofs > 1)
     repeat = None
     if len(gofs) > 1 and rank == 0:
         for _ in range(32):
@@ -239,8 +281,7 @@ def main():
         repeat = {"ms_per_step": round(t_rep / n_rep * 1e3, 4), "Mpoints_per_s": round(points_per_step * n_rep / t_rep / 1e6, 1),
                   "steps": n_rep,
                   "frac_if_it_were_hbm": None if args.smooth else round(alg_bytes / (t_rep / n_rep) / 1e9 / HBM_PEAK_GBPS, 4),
-                  "note": "one GOF reconstructed again and again (how round 1 was timed: 0.1467 ms, frac 0.677): part of "
-                          "its planes stays in the 256 MB Infinity Cache, so this is not an HBM rate"}
+                  "note": "one batch reconstructed again and again instead of --gofs batches in rotation"}
 
     # ---- the timed GOF's output against the CPU oracle (checker only) -----------------------------
     verified, ok = [], 1
@@ -250,14 +291,14 @@ def main():
         ok = 1
         for g_ in gofs:
             ok &= int(np.array_equal(g_.point_counts().astype(np.int64), counts))
-        for i in sorted({0, args.frames // 2, args.frames - 1}):
-            st, ref = ob.reconstruct(frames[i])
+        for i in sorted({0, n_batch // 2, n_batch - 1}):          # entries of the batch: copies of frames[i % --frames]
+            st, ref = ob.reconstruct(frames[i % args.frames])
             for gi, g_ in enumerate(gofs):                      # every GOF of the rotation was written by timed launches
                 res = g_.download(i)
                 good = st == 0 and res["n"] == ref["n"] and np.array_equal(res["xyz"], ob.xyz_array(ref)) and \
                     np.array_equal(res["rgb"], ob.rgb_array(ref))
                 ok &= int(good)
-                verified.append({"frame": rank * args.frames + i, "gof": gi, "points": int(res["n"]),
+                verified.append({"frame": rank * args.frames + i % args.frames, "batch_entry": i, "gof": gi, "points": int(res["n"]),
                                  "xyz_crc32": zlib.crc32(res["xyz"].tobytes()), "rgb_crc32": zlib.crc32(res["rgb"].tobytes()),
                                  "equals_oracle": bool(good)})
     if dist is not None:
@@ -271,7 +312,7 @@ def main():
     # ---- roofline of the dominant kernel ---------------------------------------------------------
     roofline = None
     if rank == 0:
-        rd = traffic.gof_read_bytes(frames)
+        rd = {k: v * max(args.cycles, 1) for k, v in traffic.gof_read_bytes(frames).items() if isinstance(v, (int, float))}
         out_bytes = 9 * points_per_step
         necessary = rd["block_bytes"] + rd["occupancy_plane"] + out_bytes
         line_floor = rd["seg128"] + rd["occupancy_plane"] + out_bytes
@@ -282,7 +323,7 @@ def main():
             dom_bytes = smooth_bytes           # a smoothing kernel dominates: its own algorithmic bytes (whole pass pair)
             dom_ms = sum(v for k, v in kernels.items() if k.startswith(("k_smooth", "smooth_")))
         achieved = dom_bytes / (dom_ms * 1e-3) / 1e9
-        tr = measured_traffic(dom, args.workload, args.frames) if not args.smooth else None
+        tr = measured_traffic(dom, args.workload, n_batch) if not args.smooth else None
         roofline = {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 1), "peak": HBM_PEAK_GBPS,
                     "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBPS, 4),
                     "traffic": tr["hbm_bytes_per_launch"] if tr else None,
@@ -315,10 +356,11 @@ def main():
             t_first = dec.first_frame_seconds()
             dec.close()
             steady = (sec - t_first) / max(args.e2e_gofs - 1, 1)
-            assert nf == args.frames * args.e2e_gofs and npts == points_per_step * args.e2e_gofs, "Decoder output differs"
-            e2e = {"frames_per_s": round(args.frames / steady, 1), "Mpoints_per_s": round(points_per_step / steady / 1e6, 1),
+            points_per_gof = int(counts[:args.frames].sum())
+            assert nf == args.frames * args.e2e_gofs and npts == points_per_gof * args.e2e_gofs, "Decoder output differs"
+            e2e = {"frames_per_s": round(args.frames / steady, 1), "Mpoints_per_s": round(points_per_gof / steady / 1e6, 1),
                    "h2d_GBps": round(size / args.e2e_gofs / steady / 1e9, 2),
-                   "d2h_GBps": round(points_per_step * 9 / steady / 1e9, 2), "startup_s": round(t_first, 3),
+                   "d2h_GBps": round(points_per_gof * 9 / steady / 1e9, 2), "startup_s": round(t_first, 3),
                    "whole_run_frames_per_s": round(nf / sec, 1),
                    "sample": f"{args.e2e_gofs} GOFs x {args.frames} frames through tmc2rs::Decoder (pinned container -> "
                              f"H2D -> kernels -> D2H -> consumer), steady state after the first GOF"}
@@ -376,21 +418,25 @@ def main():
             "metric": "V-PCC reconstruction throughput (points/s; frames/s alongside)",
             "value": round(reg["points_total_per_step"] * steps_eff / elapsed / 1e6, 2),
             "unit": "Mpoints/s",
-            "frames_per_s": round(args.frames * world * steps_eff / elapsed, 1),
+            "frames_per_s": round(n_batch * world * steps_eff / elapsed, 1),
+            "us_per_frame": round(elapsed / steps_eff / n_batch * 1e6, 3),
             "n_gpus": world, "steps": args.steps, "steps_effective": steps_eff, "warmup": args.warmup,
             "ms_per_step": round(ms_per_step, 4),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "u16", "data": "synthetic",
             "config": {"workload": f"S-{args.workload}: {frames[0]['width']}x{frames[0]['height']} geometry+attribute, "
                                    f"occupancy /{frames[0]['occupancy_precision']}, {args.frames} distinct frames per GOF "
-                                   f"per GPU, ~{int(counts.mean())} points/frame (BASELINE configs[1] shape)",
-                       "frames_per_step_per_gpu": args.frames, "points_per_step_per_gpu": points_per_step,
-                       "gofs_in_rotation": len(gofs),
+                                   f"per GPU, ~{int(counts.mean())} points/frame (BASELINE configs[1] shape); a step = ONE launch "
+                                   f"over {max(args.cycles, 1)} such GOFs ({n_batch} frames, every copy in device buffers of its own)",
+                       "frames_per_step_per_gpu": n_batch, "points_per_step_per_gpu": points_per_step,
+                       "distinct_frames": args.frames, "gofs_per_launch": max(args.cycles, 1),
+                       "batches_in_rotation": len(gofs),
                        "kernel_path": "general" if args.general else "default",
                        "smoothing": smooth_kw if args.smooth else None,
                        "parallelism": f"frame-sharded x{world}, no collective on the data path"},
             "roofline": roofline,
-            "repeat_one_gof": repeat,
+            "launches_of_one_gof": one_gof,
+            "repeat_one_batch": repeat,
             "verified_frames": verified,
             "end_to_end": e2e,
             "cpu_baseline": cpu,

@@ -143,6 +143,32 @@ def test_gof_of_very_unequal_frames_on_the_tile_path(ctx):
     g.close()
 
 
+def test_launch_of_more_than_128_frames_runs_in_rounds(ctx):
+    """Launches of more than 128 frames work through each XCD label's frames sixteen at a time, a workgroup moving on
+    to the next frame of its team when its frame has no ticket left (k_recon_tiles, kFramesInFlight): 150 frames of
+    different sizes (a partial second round, labels with 18 and 19 frames), launched twice and over a sub-range that
+    is itself more than one round."""
+    makers = [lambda i: cases.medium_frame(i % 12), lambda i: synth.small_frame(i % 20),
+              lambda i: cases.medium_frame(200 + i % 10, occupancy_values="random")]
+    frames = [makers[(i * 7 + i // 5) % 3](i) for i in range(150)]
+    cache = {}
+    refs = []
+    for i, f in enumerate(frames):
+        key = ((i * 7 + i // 5) % 3, i % 12 if (i * 7 + i // 5) % 3 == 0 else i % 20 if (i * 7 + i // 5) % 3 == 1 else i % 10)
+        if key not in cache:
+            cache[key] = ob.reconstruct(f)[1]
+        refs.append(cache[key])
+    g = ctx.gof(frames, flags=_abi.VPCC_GOF_PROFILE | _abi.VPCC_GOF_WANT_PATCH_INDEX)
+    for first, count in [(0, None), (0, None), (7, 137), (0, None)]:
+        g.reconstruct(first=first, count=count)
+        assert [k for k, _ in g.kernel_times()] == ["k_recon_tiles"]
+        counts = g.point_counts()
+        for i in range(first, len(frames) if count is None else first + count):
+            assert counts[i] == refs[i]["n"], (first, count, i)
+            _check(g.download(i, want_patch_index=True), refs[i])
+    g.close()
+
+
 def test_gof_is_deterministic_and_idempotent(ctx):
     frames = [synth.longdress_frame(i) for i in range(4)]
     g = ctx.gof(frames, capacity=1_000_000)

@@ -161,7 +161,7 @@ struct TileLaunchMap {
 // weights[i]: tiles of frame first + i.  resident_per_xcd: workgroups of this kernel an XCD holds at a time.
 void plan_tile_launch(const uint32_t* tiles, uint32_t count, uint32_t resident_per_xcd, uint32_t depth, TileLaunchMap& map);
 void launch_tiles(const DevFrame* d_frames, uint32_t first, uint32_t count, uint32_t max_groups, uint32_t gen,
-                  const TileLaunchMap& map,
+                  const TileLaunchMap& map, uint32_t resident_per_xcd,
                   void* stream);
 void launch_upsample_occupancy(const DevFrame* d_frames, uint32_t frame, uint8_t* d_out, uint32_t width,
                                uint32_t height, void* stream);

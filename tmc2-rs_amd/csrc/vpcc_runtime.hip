@@ -536,7 +536,7 @@ extern "C" int vpcc_gof_reconstruct(vpcc_gof* g, uint32_t first, uint32_t count,
       plan_tile_launch(tiles.data(), count, ctx->resident_tile_wgs_per_xcd, 3, g->tile_map);
       g->tile_map_first = first; g->tile_map_count = count; g->tile_map_valid = true;
     }
-    launch_tiles(g->d_frames, first, count, max_groups, g->generation, g->tile_map, s);
+    launch_tiles(g->d_frames, first, count, max_groups, g->generation, g->tile_map, ctx->resident_tile_wgs_per_xcd, s);
     T.end();
     HIP_TRY(ctx, hipGetLastError());
     HIP_TRY(ctx, hipEventRecord(g->results_ready, s));

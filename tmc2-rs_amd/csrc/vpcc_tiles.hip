@@ -37,6 +37,7 @@
 // running workgroups hold; state words are 8-byte {status,value} granules moved with relaxed
 // agent-scope atomics.  XCD-aware blockIdx mapping is used for L2 locality only.
 #include <hip/hip_runtime.h>
+#include <algorithm>
 
 #include <cstdlib>
 
@@ -64,6 +65,10 @@ constexpr uint64_t kGenShift = 34;
 constexpr uint64_t kAggregate = 1ull << kStatusShift;
 constexpr uint64_t kPrefix = 2ull << kStatusShift;
 constexpr uint32_t kSpinLimit = 1u << 22;
+#ifndef VPCC_TILES_FRAMES_IN_FLIGHT
+#define VPCC_TILES_FRAMES_IN_FLIGHT 16
+#endif
+constexpr uint32_t kFramesInFlight = VPCC_TILES_FRAMES_IN_FLIGHT;    // frames of one XCD label worked on at a time (launches of more than 8 x this many frames run in rounds)
 
 __device__ __forceinline__ uint64_t st_load(const uint64_t* p) {
   return __hip_atomic_load(gl(p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -710,19 +715,27 @@ void k_recon_tiles(const DevFrame* __restrict__ frames, uint32_t first,
   const uint32_t variant = kDiagnostic ? variant_arg : 0u;
   // XCD-aware placement (speed only): ids equal mod 8 share an XCD/L2; a frame stays on one label.
   // The frames of one label are interleaved, so the workgroups of ONE frame start a few slots apart.
+  // Launches of more than 128 frames run in ROUNDS: an XCD works on kFramesInFlight frames of its label at a time
+  // (an equal share of its resident workgroups each); a workgroup that has drawn the last ticket of its frame goes on
+  // to the frame kFramesInFlight places further down its label and starts a fresh pipeline there.  Nobody waits for
+  // a round to end.  Measured on 128-frame launches: 4 / 8 / 16 frames in flight read 1 217 / 1 308 / 1 414 MB but take
+  // 0.566 / 0.555 / 0.552 ms — every change of frame costs a workgroup a count-only step, and with few frames in
+  // flight a workgroup changes frames often.  16 keeps the L2 pressure of very large launches bounded.
   const uint32_t xcd = blockIdx.x & 7u, slot = blockIdx.x >> 3;
   const uint32_t frame_groups = (count + 7u) / 8u;
-  uint32_t fi = xcd + 8u * (slot % frame_groups);         // (spreading a frame over all XCDs instead: 0.147 -> 0.164 ms)
+  const bool rounds = frame_groups > kFramesInFlight;
+  uint32_t label_frame = rounds ? slot % kFramesInFlight : slot % frame_groups;   // (spreading a frame over all XCDs instead: 0.147 -> 0.164 ms)
   uint32_t groups_stride = groups_stride_arg;              // workgroups of this frame in the launch
-  if (map.slots && kTileWaves == 4) {                       // shares in proportion to the frames' sizes (TileLaunchMap)
+  if (rounds) {
+    const uint32_t per_xcd = gridDim.x >> 3;               // every frame of team t is visited by the slots = t mod kFramesInFlight
+    groups_stride = (per_xcd - label_frame + kFramesInFlight - 1u) / kFramesInFlight;
+  } else if (map.slots && kTileWaves == 4) {                // shares in proportion to the frames' sizes (TileLaunchMap)
     if (slot >= map.slots) return;
     const uint32_t v = map.frame_of_slot[xcd][slot];
     if (v == 0xFFu) return;
-    fi = xcd + 8u * v;
+    label_frame = v;
     groups_stride = map.wgs_of_slot[xcd][slot];
   }
-  if (fi >= count) return;
-  const DevFrame& f = frames[first + fi];
 #ifdef VPCC_DIAGNOSTIC
   const unsigned long long wg_t0 = (variant & 8192u) ? stamp_time() : 0ull;
   unsigned long long wg_steps = 0;
@@ -734,13 +747,17 @@ void k_recon_tiles(const DevFrame* __restrict__ frames, uint32_t first,
 
   [[maybe_unused]] unsigned long long t_prev = kStamps ? stamp() : 0ull;
   [[maybe_unused]] unsigned long long t_acc[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
-  const uint32_t n_groups = (f.n_tiles + kTileItemsPerGroup - 1u) / kTileItemsPerGroup;
   const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = lane_id();
   constexpr uint32_t K = kTileItemsPerWave;
   static_assert(K == 4, "one occupancy / duplicate nibble per item; four items of resident geometry");
 
   uint2* slots = s_slots[wave];
 
+  for (;;) {                                                 // the frames of this workgroup, one after the other
+  const uint32_t fi = xcd + 8u * label_frame;
+  if (fi < count) {
+  const DevFrame& f = frames[first + fi];
+  const uint32_t n_groups = (f.n_tiles + kTileItemsPerGroup - 1u) / kTileItemsPerGroup;
   uint32_t g_cur = 0, occ_cur = 0, dup_cur = 0, total_cur = 0, cb = 0;
   bool have_cur = false;
   // Structure 3: the geometry the count phase loaded stays in registers until the group is emitted one step
@@ -986,6 +1003,12 @@ void k_recon_tiles(const DevFrame* __restrict__ frames, uint32_t first,
     cb ^= 1u;
     have_cur = true;
   }
+  }  // fi < count
+  if (!rounds) break;
+  label_frame += kFramesInFlight;
+  if (label_frame >= frame_groups) break;
+  wg_sync_lds();                                             // s_group / s_tot of the frame just left are dead
+  }  // frames
 #ifdef VPCC_DIAGNOSTIC
   if ((variant & 8192u) && blockIdx.x < 8192u) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // the workgroup's stores have left
@@ -1021,7 +1044,7 @@ extern "C" int vpcc_debug_read_stamps(unsigned long long* out16, int reset) {
 namespace vpcc {
 
 void launch_tiles(const DevFrame* d_frames, uint32_t first, uint32_t count, uint32_t max_groups, uint32_t gen,
-                  const TileLaunchMap& map, void* stream) {
+                  const TileLaunchMap& map, uint32_t resident_per_xcd, void* stream) {
   if (!count || !max_groups) return;
   // groups each workgroup is expected to pipeline (tickets are drawn dynamically; this only sizes the grid)
   uint32_t depth = 3, variant = 0;
@@ -1040,7 +1063,9 @@ void launch_tiles(const DevFrame* d_frames, uint32_t first, uint32_t count, uint
 #endif
   const uint32_t frame_groups = (count + 7u) / 8u;
   const uint32_t wgs = (max_groups + depth - 1u) / depth;     // workgroups per frame
-  const uint32_t grid = (map.slots && kTileWaves == 4) ? 8u * map.slots : 8u * frame_groups * wgs;
+  uint32_t grid = (map.slots && kTileWaves == 4) ? 8u * map.slots : 8u * frame_groups * wgs;
+  if (frame_groups > kFramesInFlight)                         // rounds: the resident workgroups and no more
+    grid = 8u * std::min(resident_per_xcd * 4u / kTileWaves, kFramesInFlight * wgs);
 #ifdef VPCC_DIAGNOSTIC
   if (variant & 64u) {
     hipLaunchKernelGGL(k_recon_tiles<true>, dim3(grid), dim3(64 * kTileWaves), 0, (hipStream_t)stream, d_frames, first, count,
