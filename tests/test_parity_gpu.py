@@ -143,10 +143,10 @@ def test_gof_of_very_unequal_frames_on_the_tile_path(ctx):
     g.close()
 
 
-def test_launch_of_more_than_128_frames_runs_in_rounds(ctx):
-    """Launches of more than 128 frames work through each XCD label's frames sixteen at a time, a workgroup moving on
+def test_large_launch_runs_in_rounds(ctx):
+    """Launches of more than 64 frames work through each XCD label's frames eight at a time, a workgroup moving on
     to the next frame of its team when its frame has no ticket left (k_recon_tiles, kFramesInFlight): 150 frames of
-    different sizes (a partial second round, labels with 18 and 19 frames), launched twice and over a sub-range that
+    different sizes (a partial third round, labels with 18 and 19 frames), launched twice and over a sub-range that
     is itself more than one round."""
     makers = [lambda i: cases.medium_frame(i % 12), lambda i: synth.small_frame(i % 20),
               lambda i: cases.medium_frame(200 + i % 10, occupancy_values="random")]

@@ -66,7 +66,7 @@ constexpr uint64_t kAggregate = 1ull << kStatusShift;
 constexpr uint64_t kPrefix = 2ull << kStatusShift;
 constexpr uint32_t kSpinLimit = 1u << 22;
 #ifndef VPCC_TILES_FRAMES_IN_FLIGHT
-#define VPCC_TILES_FRAMES_IN_FLIGHT 16
+#define VPCC_TILES_FRAMES_IN_FLIGHT 8
 #endif
 constexpr uint32_t kFramesInFlight = VPCC_TILES_FRAMES_IN_FLIGHT;    // frames of one XCD label worked on at a time (launches of more than 8 x this many frames run in rounds)
 
@@ -715,12 +715,12 @@ void k_recon_tiles(const DevFrame* __restrict__ frames, uint32_t first,
   const uint32_t variant = kDiagnostic ? variant_arg : 0u;
   // XCD-aware placement (speed only): ids equal mod 8 share an XCD/L2; a frame stays on one label.
   // The frames of one label are interleaved, so the workgroups of ONE frame start a few slots apart.
-  // Launches of more than 128 frames run in ROUNDS: an XCD works on kFramesInFlight frames of its label at a time
+  // Launches of more than 64 frames run in ROUNDS: an XCD works on kFramesInFlight frames of its label at a time
   // (an equal share of its resident workgroups each); a workgroup that has drawn the last ticket of its frame goes on
   // to the frame kFramesInFlight places further down its label and starts a fresh pipeline there.  Nobody waits for
   // a round to end.  Measured on 128-frame launches: 4 / 8 / 16 frames in flight read 1 217 / 1 308 / 1 414 MB but take
   // 0.566 / 0.555 / 0.552 ms — every change of frame costs a workgroup a count-only step, and with few frames in
-  // flight a workgroup changes frames often.  16 keeps the L2 pressure of very large launches bounded.
+  // flight a workgroup changes frames often.  8 is the compromise (1.32 x the necessary bytes at 128 frames per launch).
   const uint32_t xcd = blockIdx.x & 7u, slot = blockIdx.x >> 3;
   const uint32_t frame_groups = (count + 7u) / 8u;
   const bool rounds = frame_groups > kFramesInFlight;
