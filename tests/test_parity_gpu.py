@@ -169,6 +169,28 @@ def test_large_launch_runs_in_rounds(ctx):
     g.close()
 
 
+@pytest.mark.parametrize("n_frames", [1, 7, 8, 9, 31, 33, 63, 64, 65, 71, 129, 200])
+def test_launch_shapes(ctx, n_frames):
+    """Every shape of a tile-kernel launch — fewer frames than XCDs, labels of unequal length, proportional shares up
+    to 64 frames, rounds above — on GOFs cycled from a few small and medium frames, full range and a sub-range."""
+    pool = [synth.small_frame(i) for i in range(6)] + [cases.medium_frame(i) for i in range(3)]
+    refs_pool = [ob.reconstruct(f)[1] for f in pool]
+    pick = [(i * 5 + i // 3) % len(pool) for i in range(n_frames)]
+    g = ctx.gof([pool[k] for k in pick], flags=_abi.VPCC_GOF_PROFILE | _abi.VPCC_GOF_WANT_PATCH_INDEX)
+    ranges = [(0, n_frames)]
+    if n_frames > 2:
+        ranges += [(n_frames // 3, n_frames - n_frames // 3 - 1), (0, n_frames)]
+    for first, count in ranges:
+        g.reconstruct(first=first, count=count)
+        assert [k for k, _ in g.kernel_times()] == ["k_recon_tiles"]
+        counts = g.point_counts()
+        for i in range(first, first + count):
+            assert counts[i] == refs_pool[pick[i]]["n"], (n_frames, first, count, i)
+        for i in sorted({first, first + count // 2, first + count - 1}):
+            _check(g.download(i, want_patch_index=True), refs_pool[pick[i]])
+    g.close()
+
+
 def test_gof_is_deterministic_and_idempotent(ctx):
     frames = [synth.longdress_frame(i) for i in range(4)]
     g = ctx.gof(frames, capacity=1_000_000)
