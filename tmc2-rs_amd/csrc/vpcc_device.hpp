@@ -51,14 +51,8 @@ struct TileItem {
 };
 static_assert(sizeof(TileItem) == 32, "TileItem is 32 B");
 constexpr uint8_t kTileSwap = 1, kTileMode1 = 2;
-#ifndef VPCC_TILE_ITEMS_PER_WAVE
-#define VPCC_TILE_ITEMS_PER_WAVE 4
-#endif
-constexpr uint32_t kTileItemsPerWave = VPCC_TILE_ITEMS_PER_WAVE;
-#ifndef VPCC_TILE_WAVES
-#define VPCC_TILE_WAVES 4                 // waves per workgroup of the tile kernel (experiments: 1, 2)
-#endif
-constexpr uint32_t kTileWaves = VPCC_TILE_WAVES;
+constexpr uint32_t kTileItemsPerWave = 4;
+constexpr uint32_t kTileWaves = 4;        // waves per workgroup of the tile kernel (1, 2 and 8 were measured and dropped: DESIGN.md)
 constexpr uint32_t kTileItemsPerGroup = kTileWaves * kTileItemsPerWave;   // one ticket / one look-back word per group
 // Look-back words are allocated one per kTileScanGranule items: enough for the finest ticket granularity any
 // kernel structure uses (one ticket per wave = 4 items); a coarser structure uses the first words only.

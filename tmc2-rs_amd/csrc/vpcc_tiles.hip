@@ -51,7 +51,7 @@ namespace {
 
 // Look-back word: {generation:30 | status:2 | value:32}.  The generation is the launch counter of the
 // gof: words written by earlier launches read as EMPTY, so nothing has to be cleared between launches.
-// Ablation switches and in-kernel stamps exist in the DIAGNOSTIC build only (`make diag`:
+// A few timing-only ablation switches and in-kernel stamps exist in the DIAGNOSTIC build only (`make diag`:
 // -DVPCC_DIAGNOSTIC, libvpcc_recon_diag.so, used by tools/ — never by tests, bench.py or the
 // product): in the product build `variant` is the constant 0 and every switch folds away.
 #ifdef VPCC_DIAGNOSTIC
@@ -65,10 +65,7 @@ constexpr uint64_t kGenShift = 34;
 constexpr uint64_t kAggregate = 1ull << kStatusShift;
 constexpr uint64_t kPrefix = 2ull << kStatusShift;
 constexpr uint32_t kSpinLimit = 1u << 22;
-#ifndef VPCC_TILES_FRAMES_IN_FLIGHT
-#define VPCC_TILES_FRAMES_IN_FLIGHT 8
-#endif
-constexpr uint32_t kFramesInFlight = VPCC_TILES_FRAMES_IN_FLIGHT;    // frames of one XCD label worked on at a time (launches of more than 8 x this many frames run in rounds)
+constexpr uint32_t kFramesInFlight = 8;    // frames of one XCD label worked on at a time (launches of more than 8 x this many frames run in rounds)
 
 __device__ __forceinline__ uint64_t st_load(const uint64_t* p) {
   return __hip_atomic_load(gl(p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -190,27 +187,18 @@ struct Samples {       // one item's samples of the lane's 4 pixels
   uint32_t occ;        // bit j: pixel j occupied
 };
 
-// Cache policy of the streaming accesses: bit 1 = output stores, bit 2 = attribute loads, bit 4 = the
-// per-item geometry re-read are issued non-temporal.  Measured on MI355X (S-longdress, 32 frames):
-// non-temporal STORES keep the 230 MB of output from evicting the geometry lines a group reads twice
-// (count, then emit one pipeline step later) out of the XCD's 4 MB L2 — 0.180 -> 0.150 ms and 70 MB
-// less L2-miss traffic; non-temporal LOADS make things worse (0.19 ms), so only bit 1 is on.
-#ifndef VPCC_TILES_NT
-#define VPCC_TILES_NT 1
-#endif
+// Cache policy of the streaming accesses: the output STORES are non-temporal (they would otherwise push the
+// plane lines that neighbouring items are about to share out of the XCD's 4 MB L2), every load is plain
+// (non-temporal loads: 0.19 vs 0.15 ms per 32 S-longdress frames).
 // Plane loads take a wave-uniform base and a 32-bit BYTE offset per lane (saddr + voffset addressing:
 // no 64-bit address arithmetic in vector registers); tile_planes_aligned keeps planes below 4 GiB.
-template <bool kStream>
 __device__ __forceinline__ Px4 load4_row(const uint16_t* base, uint32_t byte_off) {   // 8-B aligned by construction
   typedef uint32_t v2 __attribute__((ext_vector_type(2)));
-  const VPCC_GLOBAL v2* p = (const VPCC_GLOBAL v2*)((const VPCC_GLOBAL unsigned char*)base + byte_off);
-  const v2 v = kStream ? __builtin_nontemporal_load(p) : *p;
+  const v2 v = *(const VPCC_GLOBAL v2*)((const VPCC_GLOBAL unsigned char*)base + byte_off);
   return Px4{v.x, v.y};
 }
-template <bool kStream>
 __device__ __forceinline__ uint32_t load2(const uint16_t* base, uint32_t byte_off) {   // 4-B aligned by construction
-  const VPCC_GLOBAL uint32_t* p = (const VPCC_GLOBAL uint32_t*)((const VPCC_GLOBAL unsigned char*)base + byte_off);
-  return kStream ? __builtin_nontemporal_load(p) : *p;
+  return *(const VPCC_GLOBAL uint32_t*)((const VPCC_GLOBAL unsigned char*)base + byte_off);
 }
 // Lane l always reads the 4 CANVAS pixels x0 + 4*(l&3) .. +3 of canvas row y0 + (l>>2): 8 contiguous
 // bytes per plane, whatever the patch orientation.  For Default patches this is already the
@@ -257,42 +245,28 @@ __device__ __forceinline__ void load_origin(const Item& it, uint32_t lane, uint3
   px0 = occ ? it.x0 + 4u * (lane & 3u) : it.x0;
   py0 = occ ? it.y0 + (lane >> 2) : it.y0;
 }
-template <bool kLastUse>
 __device__ __forceinline__ void load_geometry(const DevFrame& f, const Item& it, uint32_t lane, Samples& s) {
-  constexpr bool kS = (kLastUse && (VPCC_TILES_NT & 4)) || (!kLastUse && (VPCC_TILES_NT & 8));   // 8: the count phase's (only) read
   uint32_t px0, py0;
   load_origin(it, lane, s.occ, px0, py0);
   const uint32_t off = (__umul24(py0, f.geo_stride[0]) + px0) * 2u;                // both layers: one video, one row pitch
-  s.g0 = load4_row<kS>(f.geo[0], off);
-  s.g1 = load4_row<kS>(f.geo[1], off);                                             // single map: an alias of layer 0
+  s.g0 = load4_row(f.geo[0], off);
+  s.g1 = load4_row(f.geo[1], off);                                             // single map: an alias of layer 0
 }
 
 // Attribute samples; chroma is nearest-neighbour (src/decoder.rs:977): pixels 0,1 of the lane use
 // chroma sample px0/2, pixels 2,3 the next one.
-__device__ __forceinline__ void load_attributes(const DevFrame& f, const Item& it, uint32_t lane, Samples& s,
-                                                uint32_t variant = 0) {
+__device__ __forceinline__ void load_attributes(const DevFrame& f, const Item& it, uint32_t lane, Samples& s) {
   uint32_t px0, py0;
   load_origin(it, lane, s.occ, px0, py0);
   // both layers come from one video: one row pitch (tile_planes_aligned), one offset per plane kind
   const uint32_t c0 = (__umul24(py0 >> 1, f.attr_cstride[0]) + (px0 >> 1)) * 2u;
   const uint32_t y0 = (__umul24(py0, f.attr_stride[0]) + px0) * 2u;
-  constexpr bool kS = VPCC_TILES_NT & 2;
-  if (kDiagnostic && (variant & 6144u)) {                  // ablations: 2048 no chroma loads, 4096 no luma loads
-    s.y0 = s.y1 = Px4{lane, 0u};
-    s.u0 = s.v0 = s.u1 = s.v1 = lane;
-    if (!(variant & 4096u)) { s.y0 = load4_row<kS>(f.attr_y[0], y0); s.y1 = load4_row<kS>(f.attr_y[1], y0); }
-    if (!(variant & 2048u)) {
-      s.u0 = load2<kS>(f.attr_u[0], c0); s.v0 = load2<kS>(f.attr_v[0], c0);
-      s.u1 = load2<kS>(f.attr_u[1], c0); s.v1 = load2<kS>(f.attr_v[1], c0);
-    }
-    return;
-  }
-  s.y0 = load4_row<kS>(f.attr_y[0], y0);   // absent planes alias present ones
-  s.u0 = load2<kS>(f.attr_u[0], c0);
-  s.v0 = load2<kS>(f.attr_v[0], c0);
-  s.y1 = load4_row<kS>(f.attr_y[1], y0);
-  s.u1 = load2<kS>(f.attr_u[1], c0);
-  s.v1 = load2<kS>(f.attr_v[1], c0);
+  s.y0 = load4_row(f.attr_y[0], y0);   // absent planes alias present ones
+  s.u0 = load2(f.attr_u[0], c0);
+  s.v0 = load2(f.attr_v[0], c0);
+  s.y1 = load4_row(f.attr_y[1], y0);
+  s.u1 = load2(f.attr_u[1], c0);
+  s.v1 = load2(f.attr_v[1], c0);
 }
 
 // Which D1 points duplicate their D0 point (src/codec.rs:422-427), one bit per pixel of the lane.
@@ -496,8 +470,7 @@ typedef uint16_t u16_a2 __attribute__((aligned(2)));
 
 template <class T>
 __device__ __forceinline__ void out_store(VPCC_GLOBAL unsigned char* p, T v) {
-  if (VPCC_TILES_NT & 1) __builtin_nontemporal_store(v, (VPCC_GLOBAL T*)p);
-  else *(VPCC_GLOBAL T*)p = v;
+  __builtin_nontemporal_store(v, (VPCC_GLOBAL T*)p);
 }
 
 // One point's 6 B (dword + short) / one colour's 3 B at a 32-bit byte offset from a uniform base:
@@ -523,10 +496,9 @@ __device__ __forceinline__ void store_rgb(VPCC_GLOBAL unsigned char* base, uint3
 }  // namespace
 
 // `variant_arg`: ignored by the product build.  Diagnostic build (VPCC_TILES_VARIANT): timing/traffic-only
-// ablation bits: 1 skip look-back wait, 2 look back but place the outputs as ablation 1 does, 8 skip colour conversion, 16 skip the lane<->point loop, 32 skip only its
-// stores, 64 in-kernel stamps, 128 no geometry re-read in the emit phase, 256 no attribute loads, 512 no
-// count-phase geometry loads, 1024 memory skeleton (all loads, waits and stores, none of the per-item arithmetic
-// or LDS traffic).  Outputs of an ablated run are wrong by construction.
+// ablation bits: 1 skip the look-back wait (the groups' outputs spread over the frame's arrays), 8 skip the colour
+// conversion, 32 skip the output stores, 64 in-kernel stamps, 256 no attribute loads, 512 no geometry loads,
+// 8192 start / exit time of every workgroup.  Outputs of an ablated run are wrong by construction.
 //
 // Every workgroup is a short pipeline over the groups of ONE frame: it draws a ticket, counts that
 // group and publishes the group total BEFORE it looks back for and emits the group it counted one
@@ -534,37 +506,14 @@ __device__ __forceinline__ void store_rgb(VPCC_GLOBAL unsigned char* base, uint3
 // its total was published, when the totals of the earlier tickets have long arrived: the wait that
 // cost a quarter of the kernel in the count -> look back -> emit form is gone, and the plane loads
 // of the next group overlap the stores of the current one across the waves of a CU.
+// The geometry the count phase loaded stays in registers until the group is emitted one step later (16 VGPRs per
+// group in flight): every plane byte is requested once.
 // Register budget: 4 waves per SIMD.  Measured (tools/ab.sh): 3 waves 0.139, 4 waves 0.126, 5 waves (spills)
 // 0.143 ms.
-#ifndef VPCC_TILES_WAVES_PER_EU
-#define VPCC_TILES_WAVES_PER_EU 4
-#endif
-// 1: the loop over a wave's four items of a group is unrolled (no register rotation, no cur = nxt copies)
-// scope of the speculative look-back read: wavefront = plain cacheable load (may hit a stale L1 line, then the
-// look-back re-reads coherently), agent = sc1 load served by the L2
-#ifndef VPCC_TILES_EARLY_SCOPE
-#define VPCC_TILES_EARLY_SCOPE __HIP_MEMORY_SCOPE_WAVEFRONT
-#endif
-// 1: colours leave as one 12-byte store per four points (even lanes) instead of dword + short per two points
-#ifndef VPCC_TILES_RGB_QUADS
-#define VPCC_TILES_RGB_QUADS 1
-#endif
 // Static wave priorities (s_setprio) for the phases that feed the memory pipeline or that other workgroups wait
-// for: 1 the store loop, 2 count + publication of the group total, 4 the issue of the next item's loads.  Each is
+// for: the store loop, count + publication of the group total, the issue of the next item's loads.  Each is
 // worth 0.7-1.4 % (tools/ab.sh), together 2.5 %; holding the priority through the look-back as well costs 5 %.
-#ifndef VPCC_TILES_SETPRIO
-#define VPCC_TILES_SETPRIO 7
-#endif
-#ifndef VPCC_TILES_UNROLL_ITEMS
-#define VPCC_TILES_UNROLL_ITEMS 1
-#endif
-// 1: pipelined (count group g+1, then emit group g), the emit phase reads the geometry again
-// 3: pipelined, the counted geometry stays in registers (default: every plane byte is requested once)
-// (Measured and dropped, see DESIGN.md: 2 = all samples of a group resident, no pipelining — least traffic,
-//  0.171 ms; 4 = structure 3 with wave-level tickets and no workgroup barrier — 0.136 vs 0.129 ms.)
-#ifndef VPCC_TILES_STRUCTURE
-#define VPCC_TILES_STRUCTURE 3
-#endif
+
 // "Take delivery" of prefetched samples: an empty asm that uses the registers, so the compiler places the
 // wait for their loads HERE (and knows them complete afterwards).
 __device__ __forceinline__ void take_delivery(Samples& s) {
@@ -586,15 +535,7 @@ __device__ __forceinline__ void emit_item(const DevFrame& f, const Item& it, con
   // in either branch: the compiler's branch lowering leaves bypass edges that never run ("exec == 0") around
   // conditional code, and a delivery that such an edge skips counts as missing — the price is a vmcnt(0), a wait
   // for this wave's output stores, wherever the registers are next written (the loop latch: once per step).
-  const bool skeleton = kDiagnostic && (variant & 1024u);
-  if (n != 0 && skeleton) {
-    // Diagnostic "memory skeleton": the item's loads were issued and are waited for, its stores go to the same
-    // addresses with the same instructions — but no ranks, colours, records or back-projection.  What this
-    // build takes is what the kernel's memory behaviour and control flow cost on their own.
-    asm volatile("" ::"v"(cur.y0.lo), "v"(cur.y0.hi), "v"(cur.y1.lo), "v"(cur.y1.hi), "v"(cur.u0), "v"(cur.v0), "v"(cur.u1), "v"(cur.v1),
-                 "v"(cur.g0.lo), "v"(cur.g1.lo));
-  }
-  if (n != 0 && !skeleton) {
+  if (n != 0) {
     uint32_t rk[4];
     const uint32_t cnt = 2u * (uint32_t)__builtin_popcount(cur.occ) - (uint32_t)__builtin_popcount(dup);
     pixel_ranks(it, cur, dup, cnt, lane, reinterpret_cast<unsigned char*>(slots), rk);
@@ -616,31 +557,10 @@ __device__ __forceinline__ void emit_item(const DevFrame& f, const Item& it, con
   }
   before_stores();
   if (n == 0) return;
-  if (skeleton) {
-    const uint32_t room = base < f.capacity ? f.capacity - base : 0u, nw = (variant & 32u) ? 0u : (n < room ? n : room);
-    for (uint32_t k = 2u * lane; k < nw; k += 128u) {
-      const uint2 p0 = make_uint2(k, lane), p1 = make_uint2(lane, k);
-      if (k + 1u < nw) {
-        store_xyz2(gx, (base + k) * 6u, p0, p1);
-        if (f.has_attr) {
-          if (!(lane & 1u) && k + 3u < nw) {
-            u32x3 o; o.x = k; o.y = lane; o.z = k;
-            out_store<u32x3_a2>(gc + (base + k) * 3u, o);
-          } else if (!((lane & 1u) && k + 1u < nw)) store_rgb2(gc, (base + k) * 3u, k, lane);
-        }
-      } else {
-        store_xyz(gx, (base + k) * 6u, p0);
-        if (f.has_attr) store_rgb(gc, (base + k) * 3u, k);
-      }
-    }
-    return;
-  }
-#if VPCC_TILES_SETPRIO & 1
   __builtin_amdgcn_s_setprio(1);                    // the store loop feeds the memory pipeline: issue it ahead of arithmetic waves
-#endif
 
   const uint32_t room = base < f.capacity ? f.capacity - base : 0u;   // never write past the caller's arrays
-  const uint32_t nw = (variant & 16u) ? 0u : (n < room ? n : room);
+  const uint32_t nw = n < room ? n : room;
   // Per-item constants of the back-projection (src/decoder.rs:871-888).  The addends live in VGPRs (a VOP3
   // takes one scalar operand: with two, the compiler re-materialises one as v_mov inside the loop), the
   // mode-1 clamp is a plain unsigned min against d1 (mode 0: against 2^32-1).
@@ -659,16 +579,12 @@ __device__ __forceinline__ void emit_item(const DevFrame& f, const Item& it, con
         p1 = relative_point(it.axes & 3u, it.flags & kTileMode1, pack_point(pc, (rr.x & 0xFFFFu) | (rr.z & 0xFF0000u)), rr.z & 0xFFFFu);
     }
     if ((variant & 32u) && p0.x != 0xFFFFFFFEu) continue;               // ablation: all the arithmetic, no stores
-#if VPCC_TILES_RGB_QUADS
     // Colours: 6 B per lane would take two interleaved store instructions (dword + short) that the L2 has to
     // merge; instead an even lane stores the 12 B of FOUR points — its own two and its odd neighbour's,
     // fetched with a quad permute — as one dwordx3, so every instruction writes a contiguous range.
     const uint32_t c2 = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)rr.y, 0xF5, 0xF, 0xF, false);   // quad_perm:[1,1,3,3]
     const uint32_t c3 = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)rr.w, 0xF5, 0xF, 0xF, false);
     const bool odd = lane & 1u, quad = !odd && k + 3u < nw;
-#else
-    const bool odd = false, quad = false;
-#endif
     if (two) {
       store_xyz2(gx, (base + k) * 6u, p0, p1);
       if (gp) out_store<u32_a2>((VPCC_GLOBAL unsigned char*)gp + (base + k) * 2u, it.patch | (it.patch << 16));   // partition, codec.rs:452
@@ -677,38 +593,29 @@ __device__ __forceinline__ void emit_item(const DevFrame& f, const Item& it, con
       if (gp) gp[base + k] = (uint16_t)it.patch;
     }
     if (f.has_attr) {
-#if VPCC_TILES_RGB_QUADS
       if (quad) {
         u32x3 o;
         o.x = (rr.y & 0xFFFFFFu) | (rr.w << 24); o.y = ((rr.w >> 8) & 0xFFFFu) | (c2 << 16); o.z = ((c2 >> 16) & 0xFFu) | (c3 << 8);
         out_store<u32x3_a2>(gc + (base + k) * 3u, o);
       } else
-#endif
       if (!(odd && two)) {                                 // (an odd lane with two points: its even neighbour stored them)
         if (two) store_rgb2(gc, (base + k) * 3u, rr.y, rr.w);
         else store_rgb(gc, (base + k) * 3u, rr.y);
       }
     }
   }
-#if VPCC_TILES_SETPRIO & 1
   __builtin_amdgcn_s_setprio(0);
-#endif
   wave_sync();                                      // the next item overwrites the slots
 }
 
-// Which item of its group a wave handles in its i-th turn.  Interleaved (default): the four waves take four
-// CONSECUTIVE items at the same time — in a Default patch these are horizontal neighbours that share
-// every 128-byte line (a 16-pixel row is 32 B), so the line is requested once while it is in flight or
-// L1/L2-hot instead of four times, 6 us apart (measured: profiles/r02).  0: wave w takes items 4w..4w+3.
-#ifndef VPCC_TILES_INTERLEAVE
-#define VPCC_TILES_INTERLEAVE 1
-#endif
-__device__ __forceinline__ uint32_t item_in_group(uint32_t wave, uint32_t i) {
-  return VPCC_TILES_INTERLEAVE ? i * kTileWaves + wave : wave * kTileItemsPerWave + i;
-}
+// Which item of its group a wave handles in its i-th turn: the four waves take four CONSECUTIVE items at the
+// same time — in a Default patch these are horizontal neighbours that share every 128-byte line (a 16-pixel
+// row is 32 B), so the line is requested once while it is in flight or L1/L2-hot instead of four times, 6 us
+// apart (measured: profiles/r02).
+__device__ __forceinline__ uint32_t item_in_group(uint32_t wave, uint32_t i) { return i * kTileWaves + wave; }
 
 template <bool kStamps>
-__global__ __launch_bounds__(64 * kTileWaves) __attribute__((amdgpu_waves_per_eu(VPCC_TILES_WAVES_PER_EU, VPCC_TILES_WAVES_PER_EU)))
+__global__ __launch_bounds__(64 * kTileWaves) __attribute__((amdgpu_waves_per_eu(4, 4)))
 void k_recon_tiles(const DevFrame* __restrict__ frames, uint32_t first,
                                                      uint32_t count, uint32_t groups_stride_arg, uint32_t gen,
                                                      uint32_t variant_arg, const TileLaunchMap map) {
@@ -729,7 +636,7 @@ void k_recon_tiles(const DevFrame* __restrict__ frames, uint32_t first,
   if (rounds) {
     const uint32_t per_xcd = gridDim.x >> 3;               // every frame of team t is visited by the slots = t mod kFramesInFlight
     groups_stride = (per_xcd - label_frame + kFramesInFlight - 1u) / kFramesInFlight;
-  } else if (map.slots && kTileWaves == 4) {                // shares in proportion to the frames' sizes (TileLaunchMap)
+  } else if (map.slots) {                // shares in proportion to the frames' sizes (TileLaunchMap)
     if (slot >= map.slots) return;
     const uint32_t v = map.frame_of_slot[xcd][slot];
     if (v == 0xFFu) return;
@@ -760,11 +667,7 @@ void k_recon_tiles(const DevFrame* __restrict__ frames, uint32_t first,
   const uint32_t n_groups = (f.n_tiles + kTileItemsPerGroup - 1u) / kTileItemsPerGroup;
   uint32_t g_cur = 0, occ_cur = 0, dup_cur = 0, total_cur = 0, cb = 0;
   bool have_cur = false;
-  // Structure 3: the geometry the count phase loaded stays in registers until the group is emitted one step
-  // later (16 VGPRs per group in flight) instead of being read again: the re-read missed the L2 almost
-  // always (23 us and ~60 MB of output per XCD lie between the two reads; profiles/r02).
-  constexpr bool kGeoResident = VPCC_TILES_STRUCTURE == 3;
-  constexpr bool kHandOverEarly = kGeoResident && VPCC_TILES_UNROLL_ITEMS;
+  // gn*: geometry of the group just counted (next), gc*: of the group being emitted (current)
   Px4 gn0[4] = {}, gn1[4] = {}, gc0[4] = {}, gc1[4] = {};
   Samples a_first = {};                // attribute samples of the wave's first item of the current group,
                                        // prefetched during the previous step
@@ -795,17 +698,15 @@ void k_recon_tiles(const DevFrame* __restrict__ frames, uint32_t first,
       // EMPTY -> AGGREGATE -> PREFIX within a launch and carries the launch generation, so any older state
       // is safe to act on — a stale EMPTY just sends the lane to the coherent re-read in look_back_groups.
       if (have_cur && lane < g_cur)
-        early = __hip_atomic_load(gl(f.scan_state + (g_cur - 1u - lane)), __ATOMIC_RELAXED, VPCC_TILES_EARLY_SCOPE);
+        early = __hip_atomic_load(gl(f.scan_state + (g_cur - 1u - lane)), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
     };
     VPCC_STAMP(0)
 
     // ---- 2. count it: occupancy + geometry of the wave's 4 items, all loads of a kind issued together.
-    // Geometry registers are transient (the per-item loop re-reads its samples, L2-hot); kept are the
+    // The geometry stays in registers (gn0/gn1) until the group is emitted in the next step; kept besides are the
     // occupancy nibbles (occ_next) and the duplicate nibbles (dup_next), one nibble per item.
     uint32_t occ_next = 0, dup_next = 0;
-#if VPCC_TILES_SETPRIO & 2
     __builtin_amdgcn_s_setprio(2);                          // count + publish: other workgroups' look-backs wait for it
-#endif
     if (have_next) {
 #pragma unroll
       for (uint32_t c0 = 0; c0 < K; c0 += 4u) {            // four items' loads in flight at a time
@@ -829,19 +730,17 @@ void k_recon_tiles(const DevFrame* __restrict__ frames, uint32_t first,
         for (int i = 0; i < 4; ++i) {
           s4[i].occ = idx4[i] < f.n_tiles ? occupancy_bits(f, raw[i]) : 0u;   // past the end: an empty copy of item 0
           if (variant & 512u) { s4[i].g0 = Px4{lane, 0u}; s4[i].g1 = Px4{0u, lane}; }
-          else load_geometry<false>(f, it4[i], lane, s4[i]);
+          else load_geometry(f, it4[i], lane, s4[i]);
         }
         if (c0 == 0) read_early();
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
           const uint32_t dup = classify(f, it4[i], s4[i]) & s4[i].occ;
-          if (kGeoResident) {
-            gn0[i] = s4[i].g0; gn1[i] = s4[i].g1;
-            // classify() does not touch the samples on every path (single map, degenerate axes): make the
-            // loads complete on ALL paths, or the emit loop has to wait for vmcnt(0) — its own stores — at
-            // the first move of these registers
-            asm volatile("" : "+v"(gn0[i].lo), "+v"(gn0[i].hi), "+v"(gn1[i].lo), "+v"(gn1[i].hi));
-          }
+          gn0[i] = s4[i].g0; gn1[i] = s4[i].g1;
+          // classify() does not touch the samples on every path (single map, degenerate axes): make the
+          // loads complete on ALL paths, or the emit loop has to wait for vmcnt(0) — its own stores — at
+          // the first move of these registers
+          asm volatile("" : "+v"(gn0[i].lo), "+v"(gn0[i].hi), "+v"(gn1[i].lo), "+v"(gn1[i].hi));
           occ_next |= s4[i].occ << (4u * (c0 + i));
           dup_next |= dup << (4u * (c0 + i));
           const uint32_t cnt = wave_sum(2u * (uint32_t)__builtin_popcount(s4[i].occ) - (uint32_t)__builtin_popcount(dup));
@@ -867,9 +766,7 @@ void k_recon_tiles(const DevFrame* __restrict__ frames, uint32_t first,
     if (threadIdx.x == 0 && have_next)                       // a workgroup that saw the end draws no more
       t_ahead = __hip_atomic_fetch_add(glw(f.ticket), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     VPCC_STAMP(3)
-#if VPCC_TILES_SETPRIO & 2
     __builtin_amdgcn_s_setprio(0);
-#endif
 
     // The speculative read is complete on EVERY path from here on (group 0 and a workgroup's first step never look
     // at it; all paths, the exit included, meet again in the loop's single latch): a load that the compiler
@@ -880,8 +777,6 @@ void k_recon_tiles(const DevFrame* __restrict__ frames, uint32_t first,
       // delivery of them here waits for nothing.
       uint32_t excl = (variant & 1u) ? g_cur * (f.capacity / n_groups) : 0u;   // ablation: no wait, outputs still spread over the frame
       if (g_cur != 0 && !(variant & 1u)) excl = look_back_groups(f, g_cur, gen, early);
-      // ablation 2: the look-back runs (all its waits), but the outputs go to the spread positions of ablation 1
-      if (variant & 2u) { asm volatile("" :: "v"(excl)); excl = g_cur * (f.capacity / n_groups); }
       // the speculative read is complete on EVERY path from here on (group 0 never looks at it): a pending
       // load into registers the item loop reuses would cost a vmcnt(0) — a wait for the output stores — per item
       asm volatile("" : "+v"(early));
@@ -889,25 +784,19 @@ void k_recon_tiles(const DevFrame* __restrict__ frames, uint32_t first,
       Item it = load_item(f.tiles + (first_item < f.n_tiles ? first_item : 0u));
       Samples cur = a_first;                                 // attributes prefetched during the previous step
       cur.occ = occ_cur & 0xFu;
-      if (kGeoResident) { cur.g0 = gc0[0]; cur.g1 = gc1[0]; }
-      else {
-        if (!(variant & 128u)) load_geometry<true>(f, it, lane, cur);
-        take_delivery(cur);
-      }
+      cur.g0 = gc0[0]; cur.g1 = gc1[0];
       if (wave == 0 && lane == 0) {
         if (g_cur != 0 && !(variant & 1u))
           st_store(f.scan_state + g_cur, ((uint64_t)gen << kGenShift) | kPrefix | (uint64_t)(excl + total_cur));
         if (g_cur + 1u == n_groups)                                        // tile.total_number_of_regular_points
-          *glw(f.n_points) = (variant & 3u) ? (excl + total_cur < f.capacity ? excl + total_cur : f.capacity) : excl + total_cur;
+          *glw(f.n_points) = (variant & 1u) ? (excl + total_cur < f.capacity ? excl + total_cur : f.capacity) : excl + total_cur;
       }
       VPCC_STAMP(4)
       uint32_t base = excl;
       for (uint32_t k = 0; k < item_in_group(wave, 0); ++k) base += s_tot[cb][k];
 
       // ---- 4. per item: colours, compaction of the records through LDS, then lane <-> point ---------
-#if VPCC_TILES_UNROLL_ITEMS
 #pragma unroll
-#endif
       for (uint32_t i = 0; i < K; ++i) {
         // scalar on purpose: a branch on a VGPR value is lowered with exec masks and an "exec == 0" bypass edge —
         // a path that never runs, but along which the compiler sees this item's prefetch loads undelivered
@@ -916,9 +805,7 @@ void k_recon_tiles(const DevFrame* __restrict__ frames, uint32_t first,
         // its first item of the NEXT group (counted above), so that no step begins with an exposed load.
         // The loads are unconditional (at the very end of the frame they re-read the current item): one
         // counter state on every path.  Nothing here depends on an outstanding vector load.
-#if VPCC_TILES_SETPRIO & 4
         __builtin_amdgcn_s_setprio(1);                      // get the next item's loads out before this item's arithmetic
-#endif
         const bool within = i + 1u < K;
         uint32_t next_item = within ? g_cur * kTileItemsPerGroup + item_in_group(wave, i + 1u)
                                     : g_next * kTileItemsPerGroup + item_in_group(wave, 0);
@@ -926,25 +813,12 @@ void k_recon_tiles(const DevFrame* __restrict__ frames, uint32_t first,
         const Item nit = load_item(f.tiles + (next_item < f.n_tiles ? next_item : 0u));
         Samples nxt;
         nxt.occ = within ? (occ_cur >> (4u * (i + 1u))) & 0xFu : (have_next ? occ_next & 0xFu : cur.occ);
-        if (kGeoResident) {
-#if VPCC_TILES_UNROLL_ITEMS
-          nxt.g0 = within ? gc0[(i + 1u) & 3u] : gn0[0];                  // unrolled: static indices
-          nxt.g1 = within ? gc1[(i + 1u) & 3u] : gn1[0];
-#else
-          nxt.g0 = within ? gc0[1] : gn0[0];
-          nxt.g1 = within ? gc1[1] : gn1[0];
-          gc0[0] = gc0[1]; gc0[1] = gc0[2]; gc0[2] = gc0[3];             // rotate: static register indices in a rolled loop
-          gc1[0] = gc1[1]; gc1[1] = gc1[2]; gc1[2] = gc1[3];
-#endif
-        } else if (!(variant & 128u)) {
-          load_geometry<true>(f, nit, lane, nxt);
-        }
-        if (!(variant & 256u)) load_attributes(f, nit, lane, nxt, variant);
+        nxt.g0 = within ? gc0[(i + 1u) & 3u] : gn0[0];                  // unrolled: static indices
+        nxt.g1 = within ? gc1[(i + 1u) & 3u] : gn1[0];
+        if (!(variant & 256u)) load_attributes(f, nit, lane, nxt);
         else { nxt.y0 = nxt.y1 = Px4{0u, 0u}; nxt.u0 = nxt.v0 = nxt.u1 = nxt.v1 = 0u; }
 
-#if VPCC_TILES_SETPRIO & 4
         __builtin_amdgcn_s_setprio(0);
-#endif
         {
           const uint32_t dup = (dup_cur >> (4u * i)) & 0xFu;                 // from the count phase
           // Take delivery of the prefetched samples before this item's stores are issued: waited for
@@ -952,7 +826,7 @@ void k_recon_tiles(const DevFrame* __restrict__ frames, uint32_t first,
           emit_item(f, it, cur, dup, n, base, lane, slots, variant, [&]() {
             take_delivery(nxt);
             asm volatile("" : "+v"(t_ahead));
-            if (kHandOverEarly && i + 1u == K) {
+            if (i + 1u == K) {
               // Hand the loop-carried registers over BEFORE the last item's stores: register copies made in
               // the loop latch, behind those stores, are preceded by a vmcnt(0) (with loads and stores both in
               // flight the compiler cannot count, and any register it believes pending costs a full wait).
@@ -966,12 +840,11 @@ void k_recon_tiles(const DevFrame* __restrict__ frames, uint32_t first,
             }
           });
         }
-        // the items between this one and the wave's next one (the other waves' when interleaved)
+        // the items between this one and the wave's next one (the other waves')
         for (uint32_t k = item_in_group(wave, i); k < item_in_group(wave, i + 1u) && k < kTileItemsPerGroup; ++k) base += s_tot[cb][k];
         it = nit;
         cur = nxt;
       }
-      if (!kHandOverEarly) a_first = cur;
       VPCC_STAMP(5)
     } else if (have_next) {
       // first step of the workgroup: nothing to emit yet; fetch the attributes of the first item just counted
@@ -979,12 +852,10 @@ void k_recon_tiles(const DevFrame* __restrict__ frames, uint32_t first,
       const Item nit = load_item(f.tiles + (next_item < f.n_tiles ? next_item : 0u));
       a_first.occ = occ_next & 0xFu;
       a_first.g0 = gn0[0]; a_first.g1 = gn1[0];
-      if (!(variant & 256u)) load_attributes(f, nit, lane, a_first, variant);
+      if (!(variant & 256u)) load_attributes(f, nit, lane, a_first);
       take_delivery(a_first);                                // once per workgroup: keeps the item loop free of waits on `cur`
-      if (kHandOverEarly) {
 #pragma unroll
-        for (int j = 0; j < 4; ++j) { gc0[j] = gn0[j]; gc1[j] = gn1[j]; }
-      }
+      for (int j = 0; j < 4; ++j) { gc0[j] = gn0[j]; gc1[j] = gn1[j]; }
       asm volatile("" : "+v"(early));                        // (never read on this path, but pending in the compiler's books)
       asm volatile("" : "+v"(t_ahead));
     }
@@ -996,10 +867,6 @@ void k_recon_tiles(const DevFrame* __restrict__ frames, uint32_t first,
     occ_cur = occ_next;
     dup_cur = dup_next;
     total_cur = total_next;
-    if (kGeoResident && !kHandOverEarly) {
-#pragma unroll
-      for (int i = 0; i < 4; ++i) { gc0[i] = gn0[i]; gc1[i] = gn1[i]; }
-    }
     cb ^= 1u;
     have_cur = true;
   }
@@ -1063,7 +930,7 @@ void launch_tiles(const DevFrame* d_frames, uint32_t first, uint32_t count, uint
 #endif
   const uint32_t frame_groups = (count + 7u) / 8u;
   const uint32_t wgs = (max_groups + depth - 1u) / depth;     // workgroups per frame
-  uint32_t grid = (map.slots && kTileWaves == 4) ? 8u * map.slots : 8u * frame_groups * wgs;
+  uint32_t grid = map.slots ? 8u * map.slots : 8u * frame_groups * wgs;
   if (frame_groups > kFramesInFlight)                         // rounds: the resident workgroups and no more
     grid = 8u * std::min(resident_per_xcd * 4u / kTileWaves, kFramesInFlight * wgs);
 #ifdef VPCC_DIAGNOSTIC
