@@ -34,7 +34,7 @@
 extern "C" {
 #endif
 
-#define VPCC_ABI_VERSION 1
+#define VPCC_ABI_VERSION 2   /* 2: vpcc_ctx_bind_thread, vpcc_decoder_stats, vpcc_gof_profile_interval / _kernel_time_means; portable page-locking */
 
 /* ------------------------------------------------------------------ status */
 typedef enum vpcc_status {
@@ -145,6 +145,13 @@ const char* vpcc_last_error(const vpcc_ctx* ctx);
 /* The context's compute stream (a hipStream_t): the stream kernels are launched on when a call is given a null
  * stream.  For callers that order their own work behind the reconstruction or time it with HIP events. */
 void* vpcc_ctx_stream(const vpcc_ctx* ctx);
+
+/* Binds the CALLING thread to the CPUs of the NUMA node the context's GPU hangs off (PCI bus id -> sysfs
+ * numa_node / cpulist -> sched_setaffinity), so that the thread's staging buffers, its HIP calls and the copy
+ * engines' host side stay on the socket next to the device.  Meant for the one worker thread that drives a
+ * context (the reference's decode thread, src/lib.rs:113-137).  Returns VPCC_OK and the node in *node_out (-1: the
+ * platform reports none — nothing was changed); VPCC_ERR_DEVICE when the affinity call fails. */
+int  vpcc_ctx_bind_thread(vpcc_ctx* ctx, int* node_out);
 
 /* Plane ingest (stand-in for LibavcodecDecoder::decode, src/decoder.rs:1089-1156, whose Vec<u8> planes
  * are the H2D source): page-locks a host range so that uploads from it are true asynchronous DMA. */
@@ -308,6 +315,19 @@ int  vpcc_decoder_drain(vpcc_decoder* dec, uint64_t* frames, uint64_t* points, d
 /* Seconds from the start of the last vpcc_decoder_drain to its first frame (contexts, page-locking the input,
  * first GOF): the start-up latency a long stream amortises. */
 double vpcc_decoder_first_frame_seconds(const vpcc_decoder* d);
+/* What the decoder's worker did so far (complete after end of stream).  The worker reconstructs every GOF that
+ * is resident on a device in ONE launch: the first launch covers one GOF (start-up latency), later ones up to
+ * four (GOFs and their frames are independent: src/lib.rs:113-137, src/decoder.rs:186). */
+typedef struct vpcc_decoder_stats_t {
+  uint64_t launches;               /* reconstruction launches, all lanes */
+  uint64_t frames;                 /* frames those launches covered */
+  uint32_t max_frames_per_launch;  /* largest launch on one lane */
+  uint32_t lanes;                  /* devices in use */
+  double kernel_seconds;           /* HIP-event time of the reconstruction kernels, summed over launches and lanes */
+  double launch_seconds;           /* host time of planning + upload enqueue + launch, slowest lane per unit, summed */
+  int32_t numa_node[8];            /* NUMA node lane i was bound to (-1: none reported), first 8 lanes */
+} vpcc_decoder_stats_t;
+int  vpcc_decoder_stats(const vpcc_decoder* dec, vpcc_decoder_stats_t* out);
 void vpcc_decoder_close(vpcc_decoder* dec);
 
 /* writer::PlyWriter::write, ASCII (src/writer.rs:25-74); rgb may be NULL (no colour properties). */

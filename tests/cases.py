@@ -180,3 +180,25 @@ PARITY_CASES = {
     "empty_no_patches": lambda: _tiny_frame([], np.ones((8, 8), np.uint8)),
     "empty_no_occupancy": lambda: _tiny_frame([_patch(0, 0, 2, 2)], np.zeros((8, 8), np.uint8)),
 }
+
+
+def random_sweep_frames(n=40):
+    """Seeded sweep over canvas sizes, precisions, occupancy value styles, patch statistics and map counts (block size
+    16): the frames of test_parity_gpu.py::test_random_sweep_against_oracle and of the oracle-vs-pyref CPU test."""
+    rng = np.random.default_rng(20261003)
+    frames = []
+    for i in range(n):
+        prec = int(rng.choice([1, 2, 4, 4, 4, 8]))
+        w = 16 * int(rng.integers(2, 26)) * (2 if prec == 8 else 1)
+        h = 16 * int(rng.integers(2, 20)) * (2 if prec == 8 else 1)
+        f = synth.make_frame(w, h, prec, 16, seed=0xABC000 + i, max_side=int(rng.integers(2, 9)),
+                             cover_target=float(rng.uniform(0.2, 0.95)), size_skew=float(rng.uniform(0.7, 4.0)),
+                             swap_prob=float(rng.uniform(0, 1)), overlap_prob=float(rng.uniform(0, 0.5)),
+                             dup_prob=float(rng.uniform(0, 0.6)), ellipse_scale=float(rng.uniform(0.5, 1.3)),
+                             occupancy_values="random" if i % 3 == 0 else "one")
+        if i % 7 == 3:                                     # full-range samples
+            f["attribute"] = [tuple(rng.integers(0, 65536, pl.shape, dtype=np.uint16) for pl in layer) for layer in f["attribute"]]
+        if i % 11 == 5:
+            f["absolute_d1"] = 0
+        frames.append(f)
+    return frames

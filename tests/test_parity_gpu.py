@@ -266,22 +266,7 @@ def test_which_kernel_path_ran(ctx, name):
 def test_random_sweep_against_oracle(ctx):
     """Seeded sweep over canvas sizes, precisions, occupancy value styles, patch statistics and map counts;
     every frame runs through the single-pass kernel (block size 16) in ONE batch and must equal the oracle."""
-    rng = np.random.default_rng(20261003)
-    frames = []
-    for i in range(40):
-        prec = int(rng.choice([1, 2, 4, 4, 4, 8]))
-        w = 16 * int(rng.integers(2, 26)) * (2 if prec == 8 else 1)
-        h = 16 * int(rng.integers(2, 20)) * (2 if prec == 8 else 1)
-        f = synth.make_frame(w, h, prec, 16, seed=0xABC000 + i, max_side=int(rng.integers(2, 9)),
-                             cover_target=float(rng.uniform(0.2, 0.95)), size_skew=float(rng.uniform(0.7, 4.0)),
-                             swap_prob=float(rng.uniform(0, 1)), overlap_prob=float(rng.uniform(0, 0.5)),
-                             dup_prob=float(rng.uniform(0, 0.6)), ellipse_scale=float(rng.uniform(0.5, 1.3)),
-                             occupancy_values="random" if i % 3 == 0 else "one")
-        if i % 7 == 3:                                     # full-range samples
-            f["attribute"] = [tuple(rng.integers(0, 65536, pl.shape, dtype=np.uint16) for pl in layer) for layer in f["attribute"]]
-        if i % 11 == 5:
-            f["absolute_d1"] = 0
-        frames.append(f)
+    frames = cases.random_sweep_frames()
     g = ctx.gof(frames, flags=_abi.VPCC_GOF_PROFILE | _abi.VPCC_GOF_WANT_PATCH_INDEX)
     g.reconstruct()
     assert [k for k, _ in g.kernel_times()] == ["k_recon_tiles"]

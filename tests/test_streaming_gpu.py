@@ -43,6 +43,7 @@ def _stream(gofs, devices):
         got = [(fr["n"], _crc(fr["xyz"], fr["rgb"])) for fr in dec]
         err = dec.error()
         assert dec.recv_frame() is None
+        _stream.last_stats = dec.stats()
         dec.close()
         return got, err
     finally:
@@ -66,6 +67,28 @@ def test_config2_300_full_size_frames_in_order(longdress32):
     assert len(got) == 300
     assert got == [ref[k] for k in order]
     assert sum(n for n, _ in got) == sum(ref[k][0] for k in order)
+    # the product issues the launch the bench measures: GOF 0 alone (start-up latency), then every resident run
+    # of up to four GOFs in ONE k_recon_tiles launch — [0], [1..4], [5..8], [9]
+    st = _stream.last_stats
+    assert st["launches"] == 4 and st["frames"] == 300 and st["max_frames_per_launch"] == 128
+    assert st["kernel_seconds"] > 0
+
+
+def test_decoder_launch_covers_several_gofs_small_frames():
+    """A 4-GOF stream of small frames (ragged GOF sizes): launches of more than one GOF, per-frame oracle CRCs and
+    the presentation order unchanged."""
+    sizes = [5, 7, 3, 6]
+    frames = [synth.small_frame(100 + i) for i in range(sum(sizes))]
+    ref = _oracle_crcs(frames)
+    gofs, at = [], 0
+    for n in sizes:
+        gofs.append(frames[at:at + n])
+        at += n
+    got, err = _stream(gofs, devices=(0,))
+    assert err == "" and got == ref
+    st = _stream.last_stats
+    assert st["launches"] == 2 and st["frames"] == sum(sizes) and st["max_frames_per_launch"] == 7 + 3 + 6
+    assert st["lanes"] == 1 and len(st["numa_node"]) == 1
 
 
 def test_config3_three_sequences_sharded_over_two_contexts(longdress32):
@@ -86,6 +109,8 @@ def test_config3_three_sequences_sharded_over_two_contexts(longdress32):
     got, err = _stream(gofs, devices=devices)
     assert err == ""
     assert len(got) == 288 and got == expect
+    st = _stream.last_stats                                        # 9 GOFs: [0], [1..4], [5..8], each dealt over two lanes
+    assert st["lanes"] == 2 and st["launches"] == 6 and st["max_frames_per_launch"] == 64
 
 
 def test_decoder_to_ply_matches_oracle_bytes(tmp_path):

@@ -103,7 +103,9 @@ struct CtxDeleter { void operator()(vpcc_ctx* c) const { vpcc_ctx_destroy(c); } 
 // One lane per GPU: a thread that owns the device's vpcc_ctx and runs every call on it, in FIFO order.  A
 // vpcc_ctx is a single-thread object (include/vpcc_recon.h), and with one lane per device the host work of
 // a GOF — frame planning, vpcc_gof_create with its H2D enqueues, the result downloads — runs in parallel
-// across the devices instead of on one thread that would bound an 8-GPU node.
+// across the devices instead of on one thread that would bound an 8-GPU node.  The thread binds itself to the
+// CPUs of its GPU's NUMA node before it allocates anything: its page-locked result pool, its HIP calls and the
+// host side of its copy engines stay on the socket next to the device.
 class Lane {
  public:
   explicit Lane(int device) : device_(device), th_([this] { run(); }) {}
@@ -125,12 +127,19 @@ class Lane {
     cv_.notify_all();
     return r;
   }
+  // valid once a posted task has run
+  int numa_node() const { return numa_node_; }
+  const std::shared_ptr<PinnedPool>& pool() const { return pool_; }
 
  private:
   void run() {
     vpcc_ctx* c = nullptr;
     create_status_ = vpcc_ctx_create(device_, &c);
     ctx_.reset(c);
+    if (c) {
+      (void)vpcc_ctx_bind_thread(c, &numa_node_);
+      pool_ = std::make_shared<PinnedPool>(c);        // blocks are allocated by this thread (PinnedPool::get in a task)
+    }
     for (;;) {
       std::packaged_task<int(vpcc_ctx*)> t;
       {
@@ -142,6 +151,7 @@ class Lane {
       }
       t(ctx_.get());                                 // tasks see a null context when its creation failed
     }
+    if (pool_) pool_->detach();                      // frames the consumer still holds outlive the context safely
     ctx_.reset();                                    // destroyed on the thread that used it
   }
   int device_;
@@ -150,31 +160,34 @@ class Lane {
   std::deque<std::packaged_task<int(vpcc_ctx*)>> q_;
   bool stop_ = false;
   std::unique_ptr<vpcc_ctx, CtxDeleter> ctx_;
+  std::shared_ptr<PinnedPool> pool_;
+  int numa_node_ = -1;
   int create_status_ = 0;
   std::thread th_;                                   // last member: starts when everything above exists
 };
 }  // namespace
 
 void Decoder::worker() {
-  // One lane (thread + context) per GPU; frames of a GOF are dealt round-robin (frame f -> device f % G) and
+  // One lane (thread + context) per GPU; the frames of a unit are dealt round-robin (frame f -> device f % G) and
   // delivered in presentation order — they are independent (src/decoder.rs:186), so no data moves between
   // GPUs.  Plane ingest: the container buffer is page-locked once (portable: every device DMAs from it), so
-  // every plane upload is an asynchronous DMA on its context's copy stream, and GOF k+1, k+2 are uploaded
-  // while GOF k is reconstructed and drained.
+  // every plane upload is an asynchronous DMA on its context's copy stream, and the next units are uploaded
+  // while the current one is reconstructed and drained.
+  //
+  // A UNIT is what one launch per lane reconstructs: the first GOF alone (the consumer gets its first frame after
+  // one GOF's upload), then up to kGofsPerLaunch consecutive GOFs — GOFs are as independent of each other as
+  // frames are (a fresh Context per GOF, src/lib.rs:120), and a launch over 128 frames costs 12 % less per frame
+  // than four launches over 32.
   const size_t G = params_.devices.empty() ? 1 : params_.devices.size();
   std::vector<std::unique_ptr<Lane>> lanes;
   for (size_t d = 0; d < G; ++d) lanes.push_back(std::make_unique<Lane>(params_.devices.empty() ? 0 : params_.devices[d]));
   auto fail = [&](const std::string& why) { error_ = why; chan_.close_tx(); };
   for (size_t d = 0; d < G; ++d)
     if (lanes[d]->post([](vpcc_ctx* c) { return c ? 0 : 1; }).get()) { fail("vpcc_ctx_create failed: no usable gfx950 device (no CPU fallback)"); return; }
+  stats_.lanes = (uint32_t)G;
+  for (size_t d = 0; d < G && d < 8; ++d) stats_.numa_node[d] = lanes[d]->numa_node();
 
-  // the pool's blocks and the input registration are portable; they are made on lane 0's context
-  std::shared_ptr<PinnedPool> pool;
-  lanes[0]->post([&](vpcc_ctx* c) { pool = std::make_shared<PinnedPool>(c); return 0; }).get();
-  struct Detach {
-    std::shared_ptr<PinnedPool> p;
-    ~Detach() { p->detach(); }              // frames the consumer still holds outlive the context safely
-  } detach{pool};
+  // the input registration is portable (every device may DMA from it); it is made on lane 0's context
   bool pinned = false;
   if (!file_.empty())
     pinned = lanes[0]->post([&](vpcc_ctx* c) { return vpcc_host_pin(c, file_.data(), file_.size()); }).get() == VPCC_OK;
@@ -183,31 +196,34 @@ void Decoder::worker() {
     ~Unpin() { if (on) l->post([this](vpcc_ctx* c) { return vpcc_host_unpin(c, p); }).get(); }
   } unpin{lanes[0].get(), file_.data(), pinned};
 
-  struct Part {                                       // one device's share of one GOF
+  struct Part {                                       // one device's share of one unit
     std::vector<vpcc_frame_desc> frames;
     vpcc_gof* g = nullptr;
     std::string err;
     std::future<int> launched;
-    double launch_seconds = 0;
+    double launch_seconds = 0, kernel_seconds = 0;
   };
-  struct InFlight { std::vector<Part> part; };
+  struct InFlight {
+    std::vector<const vpcc_frame_desc*> frames;       // the unit's frames in presentation order
+    std::vector<Part> part;
+  };
   auto now = [] { return std::chrono::steady_clock::now(); };
   auto secs = [](std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point b) {
     return std::chrono::duration<double>(b - a).count();
   };
-  // posts the planning + upload + launch of GOF `gof` to every lane; returns at once
-  auto launch = [&](const DecodedGof& gof, InFlight* f) {
+  // posts the planning + upload + launch of a unit to every lane; returns at once
+  auto launch = [&](InFlight* f) {
     f->part.clear();
     f->part.resize(G);
-    for (size_t i = 0; i < gof.frames.size(); ++i) f->part[i % G].frames.push_back(gof.frames[i]);
+    for (size_t i = 0; i < f->frames.size(); ++i) f->part[i % G].frames.push_back(*f->frames[i]);
     for (size_t d = 0; d < G; ++d) {
       Part* p = &f->part[d];
       if (p->frames.empty()) continue;
       p->launched = lanes[d]->post([p, pinned, now, secs](vpcc_ctx* c) {
         const auto t0 = now();
         int st = vpcc_gof_create(c, p->frames.data(), (uint32_t)p->frames.size(), VPCC_MEM_HOST, 0,
-                                 pinned ? VPCC_GOF_ASYNC_UPLOAD : 0u, &p->g);
-        if (st == VPCC_OK) st = vpcc_gof_reconstruct(p->g, 0, (uint32_t)p->frames.size(), nullptr);   // asynchronous
+                                 (pinned ? VPCC_GOF_ASYNC_UPLOAD : 0u) | VPCC_GOF_PROFILE, &p->g);
+        if (st == VPCC_OK) st = vpcc_gof_reconstruct(p->g, 0, (uint32_t)p->frames.size(), nullptr);   // ONE launch, asynchronous
         if (st) p->err = std::string(vpcc_status_string(st)) + ": " + vpcc_last_error(c);
         p->launch_seconds = secs(t0, now());
         return st;
@@ -224,18 +240,47 @@ void Decoder::worker() {
   };
 
   // VPCC_DECODER_TRACE=1: where the wall time goes (stderr, one line at the end of the stream).  `launch` is
-  // the longest lane's planning + enqueue time per GOF, summed over GOFs: it must not grow with G.
+  // the longest lane's planning + enqueue time per unit, summed over units: it must not grow with G.
   const bool trace = std::getenv("VPCC_DECODER_TRACE") != nullptr;
-  double t_launch = 0, t_counts = 0, t_download = 0, t_send = 0;
+  double t_counts = 0, t_download = 0, t_send = 0;
   struct Report {
-    const bool on; const size_t G; const double &a, &b, &c, &d;
+    const bool on; const Stats& s; const double &b, &c, &d;
     ~Report() {
-      if (on) std::fprintf(stderr, "[vpcc decoder] %zu device(s): launch(plan+enqueue, slowest lane) %.3f s, wait-for-counts %.3f s, "
-                           "wait-for-downloads %.3f s, send %.3f s\n", G, a, b, c, d);
+      if (!on) return;
+      std::string nodes;
+      for (uint32_t i = 0; i < s.lanes && i < 8; ++i) nodes += (i ? "," : "") + std::to_string(s.numa_node[i]);
+      std::fprintf(stderr, "[vpcc decoder] %u device(s), lane NUMA nodes [%s]: %llu launch(es) over %llu frames (largest %u), "
+                           "kernels %.4f s, launch(plan+enqueue, slowest lane) %.3f s, wait-for-counts %.3f s, "
+                           "wait-for-downloads %.3f s, send %.3f s\n", s.lanes, nodes.c_str(), (unsigned long long)s.launches,
+                   (unsigned long long)s.frames, s.max_frames_per_launch, s.kernel_seconds, s.launch_seconds, b, c, d);
     }
-  } report{trace, G, t_launch, t_counts, t_download, t_send};
-  // Two GOFs are kept queued behind the one being drained: the copy engines then always have the next
-  // upload waiting (with one GOF of look-ahead they idled while the current GOF was downloaded).
+  } report{trace, stats_, t_counts, t_download, t_send};
+
+  // The units of the stream: [GOF 0], then runs of up to kGofsPerLaunch GOFs, each run below ~16 GiB of device memory.
+  constexpr size_t kGofsPerLaunch = 4;
+  std::vector<std::pair<size_t, size_t>> units;       // [first GOF, one past the last)
+  for (size_t k = 0; k < gofs_.size();) {
+    size_t end = k + 1;
+    uint64_t bytes = 0;
+    auto gof_bytes = [&](const DecodedGof& g) {
+      uint64_t b = 0;
+      for (const vpcc_frame_desc& fr : g.frames)
+        b += (uint64_t)fr.map_count * fr.width * fr.height * (4 + 9 + (fr.attribute_count ? 3 : 0));   // planes + output capacity bound
+      return b;
+    };
+    bytes = gof_bytes(gofs_[k]);
+    while (k != 0 && end < gofs_.size() && end - k < kGofsPerLaunch) {
+      const uint64_t more = gof_bytes(gofs_[end]);
+      if ((bytes + more) / G > (uint64_t(16) << 30)) break;
+      bytes += more;
+      ++end;
+    }
+    units.emplace_back(k, end);
+    k = end;
+  }
+
+  // Two units are kept queued behind the one being drained: the copy engines then always have the next
+  // upload waiting (with one unit of look-ahead they idled while the current one was downloaded).
   constexpr size_t kAhead = 2;
   std::deque<InFlight> inflight;
   struct Cleanup {                                    // early returns: nothing may outlive the lanes
@@ -243,24 +288,32 @@ void Decoder::worker() {
     ~Cleanup() { for (auto& f : q) destroy_fn(&f); }
   } cleanup{inflight, destroy};
   size_t launched = 0;
-  for (size_t k = 0; k < gofs_.size(); ++k) {         // while ssvu.get_v3c_unit_count() > 0, src/lib.rs:118
-    while (launched < gofs_.size() && launched <= k + kAhead) {   // their ingest overlaps this GOF's work
+  for (size_t k = 0; k < units.size(); ++k) {         // while ssvu.get_v3c_unit_count() > 0, src/lib.rs:118
+    while (launched < units.size() && launched <= k + kAhead) {   // their ingest overlaps this unit's work
       inflight.emplace_back();
-      launch(gofs_[launched], &inflight.back());
+      for (size_t q = units[launched].first; q < units[launched].second; ++q)
+        for (const vpcc_frame_desc& fr : gofs_[q].frames) inflight.back().frames.push_back(&fr);
+      launch(&inflight.back());
       ++launched;
     }
-    const DecodedGof& gof = gofs_[k];
     InFlight& cur = inflight.front();
-    const size_t n = gof.frames.size();
+    const size_t n = cur.frames.size();
     double slowest = 0;
+    std::string first_err;
     for (size_t d = 0; d < G; ++d) {
       if (!cur.part[d].launched.valid()) continue;
       const int st = cur.part[d].launched.get();
       slowest = std::max(slowest, cur.part[d].launch_seconds);
-      // reference: a panic in the worker -> the consumer sees end-of-stream where this GOF would have started
-      if (st) { fail(cur.part[d].err); return; }
+      if (st && first_err.empty()) first_err = cur.part[d].err;
+      if (!st) {
+        stats_.launches += 1;
+        stats_.frames += cur.part[d].frames.size();
+        stats_.max_frames_per_launch = std::max<uint32_t>(stats_.max_frames_per_launch, (uint32_t)cur.part[d].frames.size());
+      }
     }
-    t_launch += slowest;
+    // reference: a panic in the worker -> the consumer sees end-of-stream where this GOF would have started
+    if (!first_err.empty()) { fail(first_err); return; }
+    stats_.launch_seconds += slowest;
     std::vector<std::vector<uint32_t>> counts(G);
     {
       const auto t0 = now();
@@ -273,53 +326,61 @@ void Decoder::worker() {
         uint32_t* out = counts[d].data();
         std::string* e = &errs[d];
         fc[d] = lanes[d]->post([p, out, e](vpcc_ctx* c) {
-          const int st = vpcc_gof_point_counts(p->g, out);
+          int st = vpcc_gof_point_counts(p->g, out);            // waits for the launch
           if (st) *e = vpcc_last_error(c);
+          const char* names[8];
+          float ms[8];
+          const int nk = st ? 0 : vpcc_gof_kernel_times(p->g, names, ms, 8);
+          for (int q = 0; q < nk; ++q) p->kernel_seconds += ms[q] * 1e-3;
           return st;
         });
       }
+      // every lane's task writes into `counts` and `errs`: all of them have finished before either goes away
+      int bad = -1;
       for (size_t d = 0; d < G; ++d)
-        if (fc[d].valid() && fc[d].get()) { fail(errs[d]); return; }
+        if (fc[d].valid() && fc[d].get() && bad < 0) bad = (int)d;
+      if (bad >= 0) { fail(errs[(size_t)bad]); return; }
+      for (size_t d = 0; d < G; ++d) stats_.kernel_seconds += cur.part[d].kernel_seconds;
       t_counts += secs(t0, now());
     }
     // Downloads are posted a window of frames ahead of the hand-over — every lane works through its own
     // frames while earlier ones are delivered in presentation order (src/decoder.rs:188) — but not the whole
-    // GOF at once: the page-locked result blocks come from a small pool and are recycled as the consumer
-    // drops frames (allocating and freeing pinned memory costs milliseconds).
+    // unit at once: the page-locked result blocks come from a small pool per lane (allocated by the lane's
+    // thread, on its NUMA node) and are recycled as the consumer drops frames (allocating and freeing pinned
+    // memory costs milliseconds).
     const size_t window = std::max<size_t>(8, 4 * G);
     std::vector<PointSet3> sets(n);
     std::vector<std::future<int>> done(n);
     std::vector<std::string> derr(n);
     size_t posted = 0;
-    auto post_downloads = [&](size_t upto) -> bool {
+    auto post_downloads = [&](size_t upto) {
       for (; posted < n && posted < upto; ++posted) {
         const size_t f = posted, d = f % G, local = f / G;
-        PointSet3& ps = sets[f];
-        ps.with_colors = gof.frames[f].attribute_count > 0;
+        PointSet3* ps = &sets[f];
+        ps->with_colors = cur.frames[f]->attribute_count > 0;
         const size_t np = counts[d][local];
-        PinnedBlock bx = pool->get(np * sizeof(vpcc_point3)), bc;
-        if (ps.with_colors) bc = pool->get(np * sizeof(vpcc_color3));
-        if (!bx.ptr || (ps.with_colors && !bc.ptr)) return false;
-        ps.positions.adopt(std::move(bx), np);
-        if (ps.with_colors) ps.colors.adopt(std::move(bc), np);
         Part* p = &cur.part[d];
-        vpcc_point3* px = ps.positions.data();
-        vpcc_color3* pc = ps.with_colors ? ps.colors.data() : nullptr;
+        PinnedPool* pool = lanes[d]->pool().get();
         std::string* e = &derr[f];
-        done[f] = lanes[d]->post([p, local, px, pc, np, e](vpcc_ctx* c) {
+        done[f] = lanes[d]->post([p, local, ps, np, pool, e](vpcc_ctx* c) {
+          PinnedBlock bx = pool->get(np * sizeof(vpcc_point3)), bc;
+          if (ps->with_colors) bc = pool->get(np * sizeof(vpcc_color3));
+          if (!bx.ptr || (ps->with_colors && !bc.ptr)) { *e = "out of page-locked memory"; return (int)VPCC_ERR_DEVICE; }
+          ps->positions.adopt(std::move(bx), np);
+          if (ps->with_colors) ps->colors.adopt(std::move(bc), np);
           size_t got = 0;
-          const int st = vpcc_gof_download(p->g, (uint32_t)local, px, pc, nullptr, np ? np : 1, &got);
+          const int st = vpcc_gof_download(p->g, (uint32_t)local, ps->positions.data(), ps->with_colors ? ps->colors.data() : nullptr,
+                                           nullptr, np ? np : 1, &got);
           if (st || got != np) { *e = st ? vpcc_last_error(c) : "point count changed between calls"; return st ? st : (int)VPCC_ERR_DEVICE; }
           return 0;
         });
       }
-      return true;
     };
     auto settle = [&](size_t from) {                       // downloads in flight write into `sets`
       for (size_t q = from; q < posted; ++q) done[q].wait();
     };
     for (size_t f = 0; f < n; ++f) {
-      if (!post_downloads(f + window)) { settle(f); fail("out of page-locked memory"); return; }
+      post_downloads(f + window);
       const auto t0 = now();
       const int st = done[f].get();
       const auto t1 = now();
@@ -472,6 +533,12 @@ extern "C" int vpcc_decoder_drain(vpcc_decoder* d, uint64_t* frames, uint64_t* p
 }
 
 extern "C" double vpcc_decoder_first_frame_seconds(const vpcc_decoder* d) { return d ? d->first_frame_seconds : 0.0; }
+
+extern "C" int vpcc_decoder_stats(const vpcc_decoder* d, vpcc_decoder_stats_t* out) {
+  if (!d || !out) return VPCC_ERR_INVALID_ARG;
+  *out = d->dec.stats();
+  return VPCC_OK;
+}
 
 extern "C" void vpcc_decoder_close(vpcc_decoder* d) { delete d; }
 

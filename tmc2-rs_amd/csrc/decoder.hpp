@@ -167,6 +167,8 @@ class Decoder {
   void start();                               // src/lib.rs:97-138
   std::optional<PointSet3> recv_frame();      // src/lib.rs:143-145
   const std::string& last_error() const { return error_; }   // extension: why the stream ended early
+  using Stats = vpcc_decoder_stats_t;         // launches, frames per launch, kernel time, lane affinity (vpcc_recon.h)
+  Stats stats() const { return stats_; }      // complete once recv_frame() has returned nullopt
 
   struct iterator {                           // impl Iterator for Decoder, src/lib.rs:148-154
     Decoder* d;
@@ -188,6 +190,7 @@ class Decoder {
   std::thread thread_;
   bool started_ = false;
   std::string error_;
+  Stats stats_{};
 };
 
 enum class Format { Ascii, BinaryLittleEndian };   // src/writer.rs:8-12 (the binary variant is commented out there)

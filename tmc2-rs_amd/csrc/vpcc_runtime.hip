@@ -6,7 +6,11 @@
 // this file: without a gfx950 device vpcc_ctx_create fails with VPCC_ERR_NO_DEVICE.
 #include <hip/hip_runtime.h>
 
+#include <pthread.h>
+#include <sched.h>
+
 #include <algorithm>
+#include <cctype>
 #include <cstdio>
 #include <cstring>
 #include <string>
@@ -166,6 +170,49 @@ extern "C" void vpcc_ctx_destroy(vpcc_ctx* ctx) {
 extern "C" const char* vpcc_last_error(const vpcc_ctx* ctx) { return ctx ? ctx->last_error.c_str() : ""; }
 
 extern "C" void* vpcc_ctx_stream(const vpcc_ctx* ctx) { return ctx ? (void*)ctx->stream : nullptr; }
+
+extern "C" int vpcc_ctx_bind_thread(vpcc_ctx* ctx, int* node_out) {
+  if (!ctx) return VPCC_ERR_INVALID_ARG;
+  if (node_out) *node_out = -1;
+  char bus[64] = {0};
+  if (hipDeviceGetPCIBusId(bus, (int)sizeof bus, ctx->device) != hipSuccess) return VPCC_OK;
+  for (char* c = bus; *c; ++c) *c = (char)tolower((unsigned char)*c);      // sysfs names are lower case
+  const std::string dir = std::string("/sys/bus/pci/devices/") + bus;
+  int node = -1;
+  if (FILE* f = std::fopen((dir + "/numa_node").c_str(), "r")) {
+    if (std::fscanf(f, "%d", &node) != 1) node = -1;
+    std::fclose(f);
+  }
+  if (node < 0) return VPCC_OK;                        // single-socket machines and most VMs report -1
+  cpu_set_t set;
+  CPU_ZERO(&set);
+  int n_cpus = 0;
+  if (FILE* f = std::fopen(("/sys/devices/system/node/node" + std::to_string(node) + "/cpulist").c_str(), "r")) {
+    int a = 0, b = 0;
+    for (;;) {                                         // "0-15,64-79"
+      if (std::fscanf(f, "%d", &a) != 1) break;
+      b = a;
+      int ch = std::fgetc(f);
+      if (ch == '-') { if (std::fscanf(f, "%d", &b) != 1) break; ch = std::fgetc(f); }
+      for (int c = a; c <= b && c < CPU_SETSIZE; ++c) { CPU_SET(c, &set); ++n_cpus; }
+      if (ch != ',') break;
+    }
+    std::fclose(f);
+  }
+  if (!n_cpus) return VPCC_OK;
+  // only CPUs the process may use at all (cgroup / taskset restrictions stay in force)
+  cpu_set_t allowed;
+  if (sched_getaffinity(0, sizeof allowed, &allowed) == 0) {
+    cpu_set_t both;
+    CPU_AND(&both, &set, &allowed);
+    if (CPU_COUNT(&both) == 0) return VPCC_OK;          // the node's CPUs are not ours: leave the thread where it is
+    set = both;
+  }
+  if (pthread_setaffinity_np(pthread_self(), sizeof set, &set) != 0)
+    return fail(ctx, VPCC_ERR_DEVICE, "pthread_setaffinity_np failed");
+  if (node_out) *node_out = node;
+  return VPCC_OK;
+}
 
 extern "C" int vpcc_host_pin(vpcc_ctx* ctx, const void* ptr, size_t bytes) {
   if (!ctx || !ptr || !bytes) return VPCC_ERR_INVALID_ARG;

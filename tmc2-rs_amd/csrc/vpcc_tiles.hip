@@ -16,7 +16,8 @@
 //            reference's emission order; for Swap patches (u runs down the canvas column) the per-pixel
 //            ranks are transposed through a 16x16 byte matrix in LDS instead of transposing the loads.
 //
-// Per workgroup: a two-stage pipeline over groups of ONE frame (tickets drawn dynamically, a step ahead)
+// Per workgroup: a two-stage pipeline over groups (tickets drawn dynamically per frame, a step ahead; the group being
+// counted may already belong to the workgroup's next frame)
 //   1. count the NEXT group: occupancy + both geometry layers of its 16 items (the geometry stays in
 //      registers until the group is emitted); a D1 point is dropped when it equals the D0 point
 //      (src/codec.rs:422-427); barrier; wave 0 publishes the group total;
@@ -60,6 +61,12 @@ constexpr bool kDiagnostic = true;
 constexpr bool kDiagnostic = false;
 #endif
 
+#define VPCC_CONSTANT __attribute__((address_space(4)))
+// The frame descriptors are host-written too: read through the constant address space, every field of a frame
+// whose address is wave-uniform is a scalar load (a generic pointer that changes inside a loop would be loaded
+// with VECTOR loads, each behind a vmcnt(0) — a wait for the wave's output stores).
+typedef const VPCC_CONSTANT DevFrame CFrame;
+
 constexpr uint64_t kStatusShift = 32;
 constexpr uint64_t kGenShift = 34;
 constexpr uint64_t kAggregate = 1ull << kStatusShift;
@@ -99,7 +106,7 @@ __device__ __forceinline__ uint32_t wave_sum(uint32_t v) {
 
 // `early` is this lane's word of the first 64 predecessors, read speculatively before the caller's
 // count phase (the words of a pipelined group were published a step ago, so it is normally final).
-__device__ uint32_t look_back_groups(const DevFrame& f, uint32_t g, uint32_t gen, uint64_t early) {
+__device__ uint32_t look_back_groups(CFrame& f, uint32_t g, uint32_t gen, uint64_t early) {
   uint32_t excl = 0;
   int32_t idx = (int32_t)g - 1;
   const uint32_t lane = lane_id();
@@ -165,7 +172,7 @@ struct Item {
 // The item tables are written by the host before the launch and never by a kernel: with a
 // wave-uniform address the constant address space makes this ONE s_load_dwordx8 — no vector load, no
 // readfirstlane, and (unlike a vector load) it does not queue behind the wave's outstanding stores.
-#define VPCC_CONSTANT __attribute__((address_space(4)))
+// (VPCC_CONSTANT: defined above.)
 __device__ __forceinline__ Item load_item(const TileItem* p) {
   const VPCC_CONSTANT uint32_t* q = (const VPCC_CONSTANT uint32_t*)p;
   uint32_t w[8];
@@ -214,7 +221,7 @@ __device__ __forceinline__ void lane_origin(const Item& it, uint32_t lane, uint3
 // lie inside one aligned dword (tile_planes_aligned), which is what is loaded — an aligned dword
 // that contains a valid byte never leaves the allocation's pages.
 // Returns the aligned dword; `shift` is the bit position of the lane's first byte inside it.
-__device__ __forceinline__ uint32_t load_occupancy_word(const DevFrame& f, const Item& it, uint32_t lane, uint32_t& shift) {
+__device__ __forceinline__ uint32_t load_occupancy_word(CFrame& f, const Item& it, uint32_t lane, uint32_t& shift) {
   uint32_t px0, py0;
   lane_origin(it, lane, px0, py0);
   const uint32_t off = __umul24(py0 >> f.prec_shift, f.occ_stride) + (px0 >> f.prec_shift);
@@ -222,13 +229,13 @@ __device__ __forceinline__ uint32_t load_occupancy_word(const DevFrame& f, const
   shift = 8u * mis;
   return *reinterpret_cast<const VPCC_GLOBAL uint32_t*>((const VPCC_GLOBAL unsigned char*)f.occ + (off - mis));
 }
-__device__ __forceinline__ uint32_t load_occupancy_raw(const DevFrame& f, const Item& it, uint32_t lane) {
+__device__ __forceinline__ uint32_t load_occupancy_raw(CFrame& f, const Item& it, uint32_t lane) {
   uint32_t shift;
   const uint32_t w = load_occupancy_word(f, it, lane, shift);
   return w >> shift;
 }
 // bit j: pixel j of the lane is occupied; pixel j reads byte j >> prec_shift (byte 0 for precision >= 4)
-__device__ __forceinline__ uint32_t occupancy_bits(const DevFrame& f, uint32_t raw) {
+__device__ __forceinline__ uint32_t occupancy_bits(CFrame& f, uint32_t raw) {
   if (f.prec_shift >= 2u) return (raw & 0xFFu) ? 0xFu : 0u;     // the usual case (precision 4): one byte, four pixels
   const uint32_t sh = f.prec_shift;
   uint32_t bits = 0;
@@ -245,7 +252,7 @@ __device__ __forceinline__ void load_origin(const Item& it, uint32_t lane, uint3
   px0 = occ ? it.x0 + 4u * (lane & 3u) : it.x0;
   py0 = occ ? it.y0 + (lane >> 2) : it.y0;
 }
-__device__ __forceinline__ void load_geometry(const DevFrame& f, const Item& it, uint32_t lane, Samples& s) {
+__device__ __forceinline__ void load_geometry(CFrame& f, const Item& it, uint32_t lane, Samples& s) {
   uint32_t px0, py0;
   load_origin(it, lane, s.occ, px0, py0);
   const uint32_t off = (__umul24(py0, f.geo_stride[0]) + px0) * 2u;                // both layers: one video, one row pitch
@@ -255,7 +262,7 @@ __device__ __forceinline__ void load_geometry(const DevFrame& f, const Item& it,
 
 // Attribute samples; chroma is nearest-neighbour (src/decoder.rs:977): pixels 0,1 of the lane use
 // chroma sample px0/2, pixels 2,3 the next one.
-__device__ __forceinline__ void load_attributes(const DevFrame& f, const Item& it, uint32_t lane, Samples& s) {
+__device__ __forceinline__ void load_attributes(CFrame& f, const Item& it, uint32_t lane, Samples& s) {
   uint32_t px0, py0;
   load_origin(it, lane, s.occ, px0, py0);
   // both layers come from one video: one row pitch (tile_planes_aligned), one offset per plane kind
@@ -291,7 +298,7 @@ __device__ __forceinline__ bool normal_visible(const Item& it) {
   const uint32_t na = it.axes & 3u;
   return na != ((it.axes >> 2) & 3u) && na != ((it.axes >> 4) & 3u);
 }
-__device__ __forceinline__ uint32_t classify(const DevFrame& f, const Item& it, const Samples& s) {
+__device__ __forceinline__ uint32_t classify(CFrame& f, const Item& it, const Samples& s) {
   if (f.map_count < 2) return 0xFu;                      // single map: D0 only
   if (f.absolute_d1) {
     if (!normal_visible(it)) return 0xFu;
@@ -500,7 +507,7 @@ __device__ __forceinline__ void store_rgb(VPCC_GLOBAL unsigned char* base, uint3
 // conversion, 32 skip the output stores, 64 in-kernel stamps, 256 no attribute loads, 512 no geometry loads,
 // 8192 start / exit time of every workgroup.  Outputs of an ablated run are wrong by construction.
 //
-// Every workgroup is a short pipeline over the groups of ONE frame: it draws a ticket, counts that
+// Every workgroup is a short pipeline over groups: it draws a ticket, counts that
 // group and publishes the group total BEFORE it looks back for and emits the group it counted one
 // step earlier.  A group's look-back therefore happens a whole count phase (or a whole step) after
 // its total was published, when the totals of the earlier tickets have long arrived: the wait that
@@ -525,9 +532,11 @@ __device__ __forceinline__ void take_delivery(Samples& s) {
 // One item from samples in registers to its points in HBM: ranks, colours, compaction of the 8-B records
 // through the wave's LDS slots, then lane <-> point (back-projection, contiguous stores at `base`).
 // `n` = the item's point count (wave-uniform, from the count phase), `dup` its duplicate nibble.
-template <class Hook>
-__device__ __forceinline__ void emit_item(const DevFrame& f, const Item& it, const Samples& cur, uint32_t dup, uint32_t n,
-                                          uint32_t base, uint32_t lane, uint2* slots, uint32_t variant, Hook before_stores) {
+template <bool kStamps = false, class Hook>
+__device__ __forceinline__ void emit_item(CFrame& f, const Item& it, const Samples& cur, uint32_t dup, uint32_t n,
+                                          uint32_t base, uint32_t lane, uint2* slots, uint32_t variant, Hook before_stores,
+                                          unsigned long long* t_acc = nullptr) {
+  [[maybe_unused]] unsigned long long t_prev = kStamps ? stamp() : 0ull;
   VPCC_GLOBAL unsigned char* const gx = (VPCC_GLOBAL unsigned char*)f.out_xyz;
   VPCC_GLOBAL unsigned char* const gc = (VPCC_GLOBAL unsigned char*)f.out_rgb;
   VPCC_GLOBAL uint16_t* const gp = glw(f.out_patch);
@@ -555,7 +564,9 @@ __device__ __forceinline__ void emit_item(const DevFrame& f, const Item& it, con
     put_records<3>(cur, dup, pix0 + 3u * pstep, rk[3], dump, rgb0, rgb1, slots);
     wave_sync();                                      // records written by other lanes are read below
   }
+  VPCC_STAMP(7)
   before_stores();
+  VPCC_STAMP(8)
   if (n == 0) return;
   __builtin_amdgcn_s_setprio(1);                    // the store loop feeds the memory pipeline: issue it ahead of arithmetic waves
 
@@ -565,47 +576,56 @@ __device__ __forceinline__ void emit_item(const DevFrame& f, const Item& it, con
   // takes one scalar operand: with two, the compiler re-materialises one as v_mov inside the loop), the
   // mode-1 clamp is a plain unsigned min against d1 (mode 0: against 2^32-1).
   const PointConsts pc = point_consts(it);
-  // Two consecutive points per lane: one 16-B record read, one 12-B xyz store and one 6-B rgb store
-  // per lane and step (the CU issues a vector-memory instruction only every few cycles).  An odd tail
-  // reads one record too many — whatever it holds becomes a point that is not stored.
-  for (uint32_t k = 2u * lane; k < nw; k += 128u) {
-    const uint4 rr = *reinterpret_cast<const uint4*>(slots + k);       // records k and k+1
-    const bool two = k + 1u < nw;
-    uint2 p0 = pack_point(pc, rr.x), p1 = pack_point(pc, rr.z);
+  // Two consecutive points per lane (one 12-B xyz store per lane, one 12-B rgb store per even lane for FOUR points).
+  // The lane <-> point map is aligned to the frame's ABSOLUTE point index, not to the item's first point: lane l of
+  // trip t handles the points abs0 + 128 t + 2 l, +1 with abs0 a multiple of 128, so that every store instruction
+  // between the item's first and last covers whole 128-byte lines (128 points = 768 B of positions = 384 B of
+  // colours = 256 B of partition entries) and every dwordx3 is dword-aligned.  Lanes before the item's first point
+  // (first trip) and behind its last one (last trip) store nothing.
+  const uint32_t shift = base & 127u, abs0 = base - shift;
+  for (uint32_t kk = 2u * lane; kk < nw + shift; kk += 128u) {
+    const uint32_t k = kk - shift;                             // record index of the lane's first point (wraps below 0)
+    const bool v0 = k < nw, v1 = k + 1u < nw;                  // unsigned: "negative" indices are >= nw
+    const uint2 r0 = slots[v0 ? k : 0u], r1 = slots[v1 ? k + 1u : 0u];
+    uint2 p0 = pack_point(pc, r0.x), p1 = pack_point(pc, r1.x);
     if (!f.absolute_d1) {                                   // wave-uniform; relative D1: the D0 record of the pixel precedes it
-      if ((rr.x >> 24) != 0)
-        p0 = relative_point(it.axes & 3u, it.flags & kTileMode1, pack_point(pc, (slots[k - 1u].x & 0xFFFFu) | (rr.x & 0xFF0000u)), rr.x & 0xFFFFu);
-      if ((rr.z >> 24) != 0)
-        p1 = relative_point(it.axes & 3u, it.flags & kTileMode1, pack_point(pc, (rr.x & 0xFFFFu) | (rr.z & 0xFF0000u)), rr.z & 0xFFFFu);
+      if (v0 && (r0.x >> 24) != 0)
+        p0 = relative_point(it.axes & 3u, it.flags & kTileMode1, pack_point(pc, (slots[k - 1u].x & 0xFFFFu) | (r0.x & 0xFF0000u)), r0.x & 0xFFFFu);
+      if (v1 && (r1.x >> 24) != 0)
+        p1 = relative_point(it.axes & 3u, it.flags & kTileMode1, pack_point(pc, (slots[k].x & 0xFFFFu) | (r1.x & 0xFF0000u)), r1.x & 0xFFFFu);
     }
     if ((variant & 32u) && p0.x != 0xFFFFFFFEu) continue;               // ablation: all the arithmetic, no stores
-    // Colours: 6 B per lane would take two interleaved store instructions (dword + short) that the L2 has to
-    // merge; instead an even lane stores the 12 B of FOUR points — its own two and its odd neighbour's,
-    // fetched with a quad permute — as one dwordx3, so every instruction writes a contiguous range.
-    const uint32_t c2 = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)rr.y, 0xF5, 0xF, 0xF, false);   // quad_perm:[1,1,3,3]
-    const uint32_t c3 = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)rr.w, 0xF5, 0xF, 0xF, false);
-    const bool odd = lane & 1u, quad = !odd && k + 3u < nw;
-    if (two) {
-      store_xyz2(gx, (base + k) * 6u, p0, p1);
-      if (gp) out_store<u32_a2>((VPCC_GLOBAL unsigned char*)gp + (base + k) * 2u, it.patch | (it.patch << 16));   // partition, codec.rs:452
-    } else {
-      store_xyz(gx, (base + k) * 6u, p0);
-      if (gp) gp[base + k] = (uint16_t)it.patch;
+    const uint32_t c2 = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)r0.y, 0xF5, 0xF, 0xF, false);   // quad_perm:[1,1,3,3]
+    const uint32_t c3 = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)r1.y, 0xF5, 0xF, 0xF, false);
+    const bool odd = lane & 1u;
+    const bool quad = !odd && v0 && k + 3u < nw;               // this even lane stores its own and its odd neighbour's colours
+    const bool covered = odd && k - 2u < nw && v1;             // ... and for an odd lane: its even neighbour does
+    const uint32_t a = abs0 + kk;                              // absolute index of the lane's first point (even)
+    if (v0 && v1) {
+      store_xyz2(gx, a * 6u, p0, p1);
+      if (gp) out_store<uint32_t>((VPCC_GLOBAL unsigned char*)gp + a * 2u, it.patch | (it.patch << 16));   // partition, codec.rs:452
+    } else if (v0) {
+      store_xyz(gx, a * 6u, p0);
+      if (gp) gp[a] = (uint16_t)it.patch;
+    } else if (v1) {
+      store_xyz(gx, (a + 1u) * 6u, p1);
+      if (gp) gp[a + 1u] = (uint16_t)it.patch;
     }
     if (f.has_attr) {
       if (quad) {
         u32x3 o;
-        o.x = (rr.y & 0xFFFFFFu) | (rr.w << 24); o.y = ((rr.w >> 8) & 0xFFFFu) | (c2 << 16); o.z = ((c2 >> 16) & 0xFFu) | (c3 << 8);
-        out_store<u32x3_a2>(gc + (base + k) * 3u, o);
-      } else
-      if (!(odd && two)) {                                 // (an odd lane with two points: its even neighbour stored them)
-        if (two) store_rgb2(gc, (base + k) * 3u, rr.y, rr.w);
-        else store_rgb(gc, (base + k) * 3u, rr.y);
+        o.x = (r0.y & 0xFFFFFFu) | (r1.y << 24); o.y = ((r1.y >> 8) & 0xFFFFu) | (c2 << 16); o.z = ((c2 >> 16) & 0xFFu) | (c3 << 8);
+        out_store<u32x3>(gc + a * 3u, o);
+      } else if (!covered) {
+        if (v0 && v1) store_rgb2(gc, a * 3u, r0.y, r1.y);
+        else if (v0) store_rgb(gc, a * 3u, r0.y);
+        else if (v1) store_rgb(gc, (a + 1u) * 3u, r1.y);
       }
     }
   }
   __builtin_amdgcn_s_setprio(0);
   wave_sync();                                      // the next item overwrites the slots
+  VPCC_STAMP(9)
 }
 
 // Which item of its group a wave handles in its i-th turn: the four waves take four CONSECUTIVE items at the
@@ -623,11 +643,12 @@ void k_recon_tiles(const DevFrame* __restrict__ frames, uint32_t first,
   // XCD-aware placement (speed only): ids equal mod 8 share an XCD/L2; a frame stays on one label.
   // The frames of one label are interleaved, so the workgroups of ONE frame start a few slots apart.
   // Launches of more than 64 frames run in ROUNDS: an XCD works on kFramesInFlight frames of its label at a time
-  // (an equal share of its resident workgroups each); a workgroup that has drawn the last ticket of its frame goes on
-  // to the frame kFramesInFlight places further down its label and starts a fresh pipeline there.  Nobody waits for
-  // a round to end.  Measured on 128-frame launches: 4 / 8 / 16 frames in flight read 1 217 / 1 308 / 1 414 MB but take
-  // 0.566 / 0.555 / 0.552 ms — every change of frame costs a workgroup a count-only step, and with few frames in
-  // flight a workgroup changes frames often.  8 is the compromise (1.32 x the necessary bytes at 128 frames per launch).
+  // (an equal share of its resident workgroups each); a workgroup whose ticket lies past the end of its frame goes on
+  // to the frame kFramesInFlight places further down its label at once — its pipeline carries on across the change:
+  // it counts the new frame's group while it emits the last group it holds of the old one.  Nobody waits for a
+  // round to end.  Measured on 128-frame launches (profiles/r03/ab_tiles.txt): 2 / 4 / 8 frames in flight read
+  // 1 212 / 1 240 / 1 311 MB and take 0.556 / 0.547 / 0.541 ms — more workgroups per frame mean longer look-back
+  // chains; 8 it is.
   const uint32_t xcd = blockIdx.x & 7u, slot = blockIdx.x >> 3;
   const uint32_t frame_groups = (count + 7u) / 8u;
   const bool rounds = frame_groups > kFramesInFlight;
@@ -660,11 +681,11 @@ void k_recon_tiles(const DevFrame* __restrict__ frames, uint32_t first,
 
   uint2* slots = s_slots[wave];
 
-  for (;;) {                                                 // the frames of this workgroup, one after the other
-  const uint32_t fi = xcd + 8u * label_frame;
-  if (fi < count) {
-  const DevFrame& f = frames[first + fi];
-  const uint32_t n_groups = (f.n_tiles + kTileItemsPerGroup - 1u) / kTileItemsPerGroup;
+  // ---- cross-frame pipeline: the workgroup's "next" group may belong to a later frame than its "current" one
+  if (xcd + 8u * label_frame >= count) return;
+  CFrame* fn = (CFrame*)frames + (first + xcd + 8u * label_frame);     // frame of the group being counted
+  CFrame* fc = fn;                                             // frame of the group being emitted
+  uint32_t n_groups_next = (fn->n_tiles + kTileItemsPerGroup - 1u) / kTileItemsPerGroup, n_groups_cur = n_groups_next;
   uint32_t g_cur = 0, occ_cur = 0, dup_cur = 0, total_cur = 0, cb = 0;
   bool have_cur = false;
   // gn*: geometry of the group just counted (next), gc*: of the group being emitted (current)
@@ -673,23 +694,33 @@ void k_recon_tiles(const DevFrame* __restrict__ frames, uint32_t first,
                                        // prefetched during the previous step
   uint32_t t_ahead = 0;
   if (threadIdx.x == 0)
-    t_ahead = __hip_atomic_fetch_add(glw(f.ticket), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    t_ahead = __hip_atomic_fetch_add(glw(fn->ticket), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   asm volatile("" : "+v"(t_ahead));                            // delivered on every path into the loop: no wait at its top
   for (;;) {
-    // ---- 1. draw the NEXT group of this frame.  Every workgroup of the frame stops at its first ticket
-    // past the end, so exactly n_groups + groups_stride tickets are drawn per launch: the last re-arms
-    // the counter (nothing to clear between launches).
-    // The ticket itself was drawn a step earlier: the round trip of the atomic is hidden
-    // behind the previous group's item loop instead of being waited for by all four waves at this barrier.
-    if (threadIdx.x == 0) {
-      const uint32_t t = t_ahead;
-      if (t + 1u == n_groups + groups_stride)
-        __hip_atomic_store(glw(f.ticket), 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      s_group = t;
-    }
+    // ---- 1. the NEXT group.  Its ticket was drawn a step earlier (the round trip of the atomic is hidden behind the
+    // previous group's item loop).  Every workgroup of a frame stops at its first ticket past the end, so exactly
+    // n_groups + groups_stride tickets are drawn per frame and launch: the last re-arms the counter (nothing to clear
+    // between launches).  A workgroup whose ticket is past the end goes on to the next frame of its team AT ONCE and
+    // counts that frame's group while it emits the last group it holds of the frame it leaves: a change of frame
+    // costs one exposed ticket round trip, not a count-only step.
+    if (threadIdx.x == 0) s_group = t_ahead;
     wg_sync_lds();
-    const uint32_t g_next = __builtin_amdgcn_readfirstlane(s_group);
-    const bool have_next = g_next < n_groups;
+    uint32_t g_next = __builtin_amdgcn_readfirstlane(s_group);
+    bool have_next = true;
+    for (;;) {
+      if (threadIdx.x == 0 && g_next + 1u == n_groups_next + groups_stride)
+        __hip_atomic_store(glw(fn->ticket), 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if (g_next < n_groups_next) break;
+      label_frame += kFramesInFlight;
+      if (!rounds || xcd + 8u * label_frame >= count) { have_next = false; break; }
+      fn = (CFrame*)frames + (first + xcd + 8u * label_frame);
+      n_groups_next = (fn->n_tiles + kTileItemsPerGroup - 1u) / kTileItemsPerGroup;
+      wg_sync_lds();                                         // every wave has read s_group
+      if (threadIdx.x == 0)
+        s_group = __hip_atomic_fetch_add(glw(fn->ticket), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      wg_sync_lds();
+      g_next = __builtin_amdgcn_readfirstlane(s_group);
+    }
     // Speculative read of the current group's look-back words.  It is issued BEHIND the count phase's plane
     // loads: vmcnt retires in order, and this coherent load is the slowest of them.
     uint64_t early = 0;
@@ -698,7 +729,7 @@ void k_recon_tiles(const DevFrame* __restrict__ frames, uint32_t first,
       // EMPTY -> AGGREGATE -> PREFIX within a launch and carries the launch generation, so any older state
       // is safe to act on — a stale EMPTY just sends the lane to the coherent re-read in look_back_groups.
       if (have_cur && lane < g_cur)
-        early = __hip_atomic_load(gl(f.scan_state + (g_cur - 1u - lane)), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+        early = __hip_atomic_load(gl(fc->scan_state + (g_cur - 1u - lane)), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
     };
     VPCC_STAMP(0)
 
@@ -708,44 +739,42 @@ void k_recon_tiles(const DevFrame* __restrict__ frames, uint32_t first,
     uint32_t occ_next = 0, dup_next = 0;
     __builtin_amdgcn_s_setprio(2);                          // count + publish: other workgroups' look-backs wait for it
     if (have_next) {
+      CFrame& f = *fn;
+      uint32_t idx4[4];
 #pragma unroll
-      for (uint32_t c0 = 0; c0 < K; c0 += 4u) {            // four items' loads in flight at a time
-        uint32_t idx4[4];
+      for (int i = 0; i < 4; ++i) idx4[i] = g_next * kTileItemsPerGroup + item_in_group(wave, i);
+      Item it4[4];
+      Samples s4[4];
+      uint32_t raw[4];
 #pragma unroll
-        for (int i = 0; i < 4; ++i) idx4[i] = g_next * kTileItemsPerGroup + item_in_group(wave, c0 + i);
-        Item it4[4];
-        Samples s4[4];
-        uint32_t raw[4];
+      for (int i = 0; i < 4; ++i) it4[i] = load_item(f.tiles + (idx4[i] < f.n_tiles ? idx4[i] : 0u));
+      uint32_t raw_shift[4];
 #pragma unroll
-        for (int i = 0; i < 4; ++i) it4[i] = load_item(f.tiles + (idx4[i] < f.n_tiles ? idx4[i] : 0u));
-        uint32_t raw_shift[4];
+      for (int i = 0; i < 4; ++i) raw[i] = load_occupancy_word(f, it4[i], lane, raw_shift[i]);
+      // complete on EVERY path (a group's items past the end of the frame never look at theirs): a load the
+      // compiler believes pending at the top of the next step costs a vmcnt(0) there — a wait for the stores
+      asm volatile("" : "+v"(raw[0]), "+v"(raw[1]), "+v"(raw[2]), "+v"(raw[3]));
 #pragma unroll
-        for (int i = 0; i < 4; ++i) raw[i] = load_occupancy_word(f, it4[i], lane, raw_shift[i]);
-        // complete on EVERY path (a group's items past the end of the frame never look at theirs): a load the
-        // compiler believes pending at the top of the next step costs a vmcnt(0) there — a wait for the stores
-        asm volatile("" : "+v"(raw[0]), "+v"(raw[1]), "+v"(raw[2]), "+v"(raw[3]));
+      for (int i = 0; i < 4; ++i) raw[i] >>= raw_shift[i];
 #pragma unroll
-        for (int i = 0; i < 4; ++i) raw[i] >>= raw_shift[i];
+      for (int i = 0; i < 4; ++i) {
+        s4[i].occ = idx4[i] < f.n_tiles ? occupancy_bits(f, raw[i]) : 0u;   // past the end: an empty copy of item 0
+        if (variant & 512u) { s4[i].g0 = Px4{lane, 0u}; s4[i].g1 = Px4{0u, lane}; }
+        else load_geometry(f, it4[i], lane, s4[i]);
+      }
+      read_early();
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-          s4[i].occ = idx4[i] < f.n_tiles ? occupancy_bits(f, raw[i]) : 0u;   // past the end: an empty copy of item 0
-          if (variant & 512u) { s4[i].g0 = Px4{lane, 0u}; s4[i].g1 = Px4{0u, lane}; }
-          else load_geometry(f, it4[i], lane, s4[i]);
-        }
-        if (c0 == 0) read_early();
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-          const uint32_t dup = classify(f, it4[i], s4[i]) & s4[i].occ;
-          gn0[i] = s4[i].g0; gn1[i] = s4[i].g1;
-          // classify() does not touch the samples on every path (single map, degenerate axes): make the
-          // loads complete on ALL paths, or the emit loop has to wait for vmcnt(0) — its own stores — at
-          // the first move of these registers
-          asm volatile("" : "+v"(gn0[i].lo), "+v"(gn0[i].hi), "+v"(gn1[i].lo), "+v"(gn1[i].hi));
-          occ_next |= s4[i].occ << (4u * (c0 + i));
-          dup_next |= dup << (4u * (c0 + i));
-          const uint32_t cnt = wave_sum(2u * (uint32_t)__builtin_popcount(s4[i].occ) - (uint32_t)__builtin_popcount(dup));
-          if (lane == 0) s_tot[cb ^ 1u][item_in_group(wave, c0 + i)] = cnt;
-        }
+      for (int i = 0; i < 4; ++i) {
+        const uint32_t dup = classify(f, it4[i], s4[i]) & s4[i].occ;
+        gn0[i] = s4[i].g0; gn1[i] = s4[i].g1;
+        // classify() does not touch the samples on every path (single map, degenerate axes): make the
+        // loads complete on ALL paths, or the emit loop has to wait for vmcnt(0) — its own stores — at
+        // the first move of these registers
+        asm volatile("" : "+v"(gn0[i].lo), "+v"(gn0[i].hi), "+v"(gn1[i].lo), "+v"(gn1[i].hi));
+        occ_next |= s4[i].occ << (4u * i);
+        dup_next |= dup << (4u * i);
+        const uint32_t cnt = wave_sum(2u * (uint32_t)__builtin_popcount(s4[i].occ) - (uint32_t)__builtin_popcount(dup));
+        if (lane == 0) s_tot[cb ^ 1u][item_in_group(wave, i)] = cnt;
       }
     }
     if (!have_next) read_early();
@@ -761,10 +790,10 @@ void k_recon_tiles(const DevFrame* __restrict__ frames, uint32_t first,
       total_next = lane < kTileItemsPerGroup ? s_tot[cb ^ 1u][lane] : 0u;   // kTileItemsPerGroup <= 64
       total_next = wave_sum(total_next);
       if (lane == 0)
-        st_store(f.scan_state + g_next, ((uint64_t)gen << kGenShift) | (g_next == 0 ? kPrefix : kAggregate) | total_next);
+        st_store(fn->scan_state + g_next, ((uint64_t)gen << kGenShift) | (g_next == 0 ? kPrefix : kAggregate) | total_next);
     }
-    if (threadIdx.x == 0 && have_next)                       // a workgroup that saw the end draws no more
-      t_ahead = __hip_atomic_fetch_add(glw(f.ticket), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (threadIdx.x == 0 && have_next)                       // a workgroup that saw the end of its last frame draws no more
+      t_ahead = __hip_atomic_fetch_add(glw(fn->ticket), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     VPCC_STAMP(3)
     __builtin_amdgcn_s_setprio(0);
 
@@ -773,9 +802,10 @@ void k_recon_tiles(const DevFrame* __restrict__ frames, uint32_t first,
     // believes pending there costs a vmcnt(0) — a wait for the output stores — at the top of every step.
     asm volatile("" : "+v"(early));
     if (have_cur) {
+      CFrame& f = *fc;
       // The look-back words were read before the count phase, whose loads have all been consumed: taking
       // delivery of them here waits for nothing.
-      uint32_t excl = (variant & 1u) ? g_cur * (f.capacity / n_groups) : 0u;   // ablation: no wait, outputs still spread over the frame
+      uint32_t excl = (variant & 1u) ? g_cur * (f.capacity / n_groups_cur) : 0u;   // ablation: no wait, outputs still spread over the frame
       if (g_cur != 0 && !(variant & 1u)) excl = look_back_groups(f, g_cur, gen, early);
       // the speculative read is complete on EVERY path from here on (group 0 never looks at it): a pending
       // load into registers the item loop reuses would cost a vmcnt(0) — a wait for the output stores — per item
@@ -788,7 +818,7 @@ void k_recon_tiles(const DevFrame* __restrict__ frames, uint32_t first,
       if (wave == 0 && lane == 0) {
         if (g_cur != 0 && !(variant & 1u))
           st_store(f.scan_state + g_cur, ((uint64_t)gen << kGenShift) | kPrefix | (uint64_t)(excl + total_cur));
-        if (g_cur + 1u == n_groups)                                        // tile.total_number_of_regular_points
+        if (g_cur + 1u == n_groups_cur)                                    // tile.total_number_of_regular_points
           *glw(f.n_points) = (variant & 1u) ? (excl + total_cur < f.capacity ? excl + total_cur : f.capacity) : excl + total_cur;
       }
       VPCC_STAMP(4)
@@ -802,20 +832,21 @@ void k_recon_tiles(const DevFrame* __restrict__ frames, uint32_t first,
         // a path that never runs, but along which the compiler sees this item's prefetch loads undelivered
         const uint32_t n = __builtin_amdgcn_readfirstlane(s_tot[cb][item_in_group(wave, i)]);
         // Prefetch the attribute samples of the wave's next item — after its last item of this group, of
-        // its first item of the NEXT group (counted above), so that no step begins with an exposed load.
-        // The loads are unconditional (at the very end of the frame they re-read the current item): one
-        // counter state on every path.  Nothing here depends on an outstanding vector load.
+        // its first item of the NEXT group (counted above; possibly of another frame), so that no step begins with an
+        // exposed load.  The loads are unconditional (at the very end of the workgroup's work they re-read the current
+        // item): one counter state on every path.  Nothing here depends on an outstanding vector load.
         __builtin_amdgcn_s_setprio(1);                      // get the next item's loads out before this item's arithmetic
         const bool within = i + 1u < K;
         uint32_t next_item = within ? g_cur * kTileItemsPerGroup + item_in_group(wave, i + 1u)
                                     : g_next * kTileItemsPerGroup + item_in_group(wave, 0);
         if (!within && !have_next) next_item = g_cur * kTileItemsPerGroup + item_in_group(wave, i);
-        const Item nit = load_item(f.tiles + (next_item < f.n_tiles ? next_item : 0u));
+        CFrame& fp = (within || !have_next) ? *fc : *fn;
+        const Item nit = load_item(fp.tiles + (next_item < fp.n_tiles ? next_item : 0u));
         Samples nxt;
         nxt.occ = within ? (occ_cur >> (4u * (i + 1u))) & 0xFu : (have_next ? occ_next & 0xFu : cur.occ);
         nxt.g0 = within ? gc0[(i + 1u) & 3u] : gn0[0];                  // unrolled: static indices
         nxt.g1 = within ? gc1[(i + 1u) & 3u] : gn1[0];
-        if (!(variant & 256u)) load_attributes(f, nit, lane, nxt);
+        if (!(variant & 256u)) load_attributes(fp, nit, lane, nxt);
         else { nxt.y0 = nxt.y1 = Px4{0u, 0u}; nxt.u0 = nxt.v0 = nxt.u1 = nxt.v1 = 0u; }
 
         __builtin_amdgcn_s_setprio(0);
@@ -823,7 +854,7 @@ void k_recon_tiles(const DevFrame* __restrict__ frames, uint32_t first,
           const uint32_t dup = (dup_cur >> (4u * i)) & 0xFu;                 // from the count phase
           // Take delivery of the prefetched samples before this item's stores are issued: waited for
           // later, the in-order vmcnt would make that wait cover the stores as well.
-          emit_item(f, it, cur, dup, n, base, lane, slots, variant, [&]() {
+          emit_item<kStamps>(f, it, cur, dup, n, base, lane, slots, variant, [&]() {
             take_delivery(nxt);
             asm volatile("" : "+v"(t_ahead));
             if (i + 1u == K) {
@@ -838,7 +869,7 @@ void k_recon_tiles(const DevFrame* __restrict__ frames, uint32_t first,
               a_first = nxt;
               take_delivery(a_first);
             }
-          });
+          }, t_acc);
         }
         // the items between this one and the wave's next one (the other waves')
         for (uint32_t k = item_in_group(wave, i); k < item_in_group(wave, i + 1u) && k < kTileItemsPerGroup; ++k) base += s_tot[cb][k];
@@ -848,6 +879,7 @@ void k_recon_tiles(const DevFrame* __restrict__ frames, uint32_t first,
       VPCC_STAMP(5)
     } else if (have_next) {
       // first step of the workgroup: nothing to emit yet; fetch the attributes of the first item just counted
+      CFrame& f = *fn;
       const uint32_t next_item = g_next * kTileItemsPerGroup + item_in_group(wave, 0);
       const Item nit = load_item(f.tiles + (next_item < f.n_tiles ? next_item : 0u));
       a_first.occ = occ_next & 0xFu;
@@ -864,18 +896,14 @@ void k_recon_tiles(const DevFrame* __restrict__ frames, uint32_t first,
     ++wg_steps;
 #endif
     g_cur = g_next;
+    fc = fn;
+    n_groups_cur = n_groups_next;
     occ_cur = occ_next;
     dup_cur = dup_next;
     total_cur = total_next;
     cb ^= 1u;
     have_cur = true;
   }
-  }  // fi < count
-  if (!rounds) break;
-  label_frame += kFramesInFlight;
-  if (label_frame >= frame_groups) break;
-  wg_sync_lds();                                             // s_group / s_tot of the frame just left are dead
-  }  // frames
 #ifdef VPCC_DIAGNOSTIC
   if ((variant & 8192u) && blockIdx.x < 8192u) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // the workgroup's stores have left
@@ -931,8 +959,9 @@ void launch_tiles(const DevFrame* d_frames, uint32_t first, uint32_t count, uint
   const uint32_t frame_groups = (count + 7u) / 8u;
   const uint32_t wgs = (max_groups + depth - 1u) / depth;     // workgroups per frame
   uint32_t grid = map.slots ? 8u * map.slots : 8u * frame_groups * wgs;
-  if (frame_groups > kFramesInFlight)                         // rounds: the resident workgroups and no more
-    grid = 8u * std::min(resident_per_xcd * 4u / kTileWaves, kFramesInFlight * wgs);
+  if (frame_groups > kFramesInFlight)                         // rounds: the resident workgroups and no more — but every team
+    grid = 8u * std::max(kFramesInFlight,                     // of frames needs a workgroup, however small the device
+                         std::min(resident_per_xcd * 4u / kTileWaves, kFramesInFlight * wgs));
 #ifdef VPCC_DIAGNOSTIC
   if (variant & 64u) {
     hipLaunchKernelGGL(k_recon_tiles<true>, dim3(grid), dim3(64 * kTileWaves), 0, (hipStream_t)stream, d_frames, first, count,

@@ -159,6 +159,12 @@ def host_frame_desc(frame):
 _lib = None
 
 
+class DecoderStats(C.Structure):          # vpcc_decoder_stats_t
+    _fields_ = [("launches", C.c_uint64), ("frames", C.c_uint64), ("max_frames_per_launch", C.c_uint32),
+                ("lanes", C.c_uint32), ("kernel_seconds", C.c_double), ("launch_seconds", C.c_double),
+                ("numa_node", C.c_int32 * 8)]
+
+
 class V3cGofInfo(C.Structure):
     """vpcc_v3c_gof_info (include/vpcc_recon.h)."""
     _fields_ = [(n, C.c_uint32) for n in (
@@ -227,6 +233,8 @@ def load_library():
     lib.vpcc_decoder_drain.argtypes = [vp, C.POINTER(u64), C.POINTER(u64), C.POINTER(C.c_double)]
     lib.vpcc_host_pin.argtypes = [vp, vp, sz]
     lib.vpcc_host_unpin.argtypes = [vp, vp]
+    lib.vpcc_decoder_stats.argtypes = [vp, C.POINTER(DecoderStats)]
+    lib.vpcc_ctx_bind_thread.argtypes = [vp, C.POINTER(C.c_int)]
     lib.vpcc_decoder_close.argtypes = [vp]
     lib.vpcc_decoder_close.restype = None
     lib.vpcc_write_ply.argtypes = [C.c_char_p, vp, vp, sz]

@@ -263,6 +263,16 @@ class Decoder:
     def first_frame_seconds(self):
         return self.lib.vpcc_decoder_first_frame_seconds(self.h)
 
+    def stats(self):
+        """Launches, frames per launch, kernel seconds, lane NUMA nodes (complete after end of stream)."""
+        st = _abi.DecoderStats()
+        rc = self.lib.vpcc_decoder_stats(self.h, C.byref(st))
+        if rc:
+            raise VpccError(rc, "vpcc_decoder_stats")
+        return {"launches": st.launches, "frames": st.frames, "max_frames_per_launch": st.max_frames_per_launch,
+                "lanes": st.lanes, "kernel_seconds": st.kernel_seconds, "launch_seconds": st.launch_seconds,
+                "numa_node": list(st.numa_node)[:st.lanes]}
+
     def __iter__(self):
         return self
 

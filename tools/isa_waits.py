@@ -19,7 +19,7 @@ def build():
     full = "/tmp/vpcc_tiles_full.s"
     cmd = ["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off",
            "-mllvm", "-amdgpu-atomic-optimizer-strategy=None", "-I" + REPO + "/include", "-I" + REPO + "/tmc2-rs_amd/csrc",
-           "-S", "--cuda-device-only", "-o", full, REPO + "/tmc2-rs_amd/csrc/vpcc_tiles.hip"]
+           *os.environ.get("VPCC_ISA_EXTRA", "").split(), "-S", "--cuda-device-only", "-o", full, REPO + "/tmc2-rs_amd/csrc/vpcc_tiles.hip"]
     subprocess.run(cmd, check=True, stderr=subprocess.DEVNULL)
     on, lines = False, []
     for l in open(full):

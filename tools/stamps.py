@@ -19,9 +19,9 @@ for _ in range(3):
     g.reconstruct()
 g.sync()
 lib.vpcc_debug_read_stamps(buf, 1)
-names = ["ticket+barrier", "count(occ+geo x4)", "barrier#1", "publish next", "look-back+1st loads", "4 items", "drain", "-", "-", "-"]
+names = ["ticket+barrier", "count(occ+geo x4)", "barrier#1", "publish next", "look-back+1st loads", "4 items (all)", "drain", "  item: ranks+colour+records", "  item: wait for next item's loads", "  item: store loop"]
 n = buf[15] or 1
-tot = sum(buf[i] for i in range(10)) or 1
+tot = sum(buf[i] for i in range(7)) or 1
 for i, nm in enumerate(names):
     print(f"{nm:16s} {buf[i]/n:10.0f} cycles/wave  {100.0*buf[i]/tot:5.1f}%")
 print("waves sampled", n, " total cycles/wave", tot / n, "(s_memtime ticks; 100 MHz? see below)")

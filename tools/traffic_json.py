@@ -2,16 +2,22 @@
 """Builds profiles/rNN/traffic*.json from a tools/profile_round.sh output directory.
 Usage: tools/traffic_json.py <profile_round_outdir> <round> <kernel substring> "<workload text>" > profiles/rNN/traffic.json"""
 import collections, csv, glob, json, os, sys
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tmc2-rs_amd"))
+from tmc2rs import provenance
 root, rnd, kernel, workload = sys.argv[1], int(sys.argv[2]), sys.argv[3], sys.argv[4]
 
 
 def means(sub, kern):
-    acc = collections.defaultdict(list)
+    """Per counter: the mean per dispatch of every kernel whose name contains `kern`, SUMMED over those kernels (one
+    kernel for k_recon_tiles; the eight launches of a smoothing step for k_smooth)."""
+    acc = collections.defaultdict(lambda: collections.defaultdict(list))
     for f in glob.glob(os.path.join(root, sub, "**", "*counter_collection.csv"), recursive=True):
         for r in csv.DictReader(open(f)):
             if kern in r["Kernel_Name"]:
-                acc[r["Counter_Name"]].append(float(r["Counter_Value"]))
-    return {k: sum(v) / len(v) for k, v in acc.items()}, {k: len(v) for k, v in acc.items()}
+                acc[r["Counter_Name"]][r["Kernel_Name"]].append(float(r["Counter_Value"]))
+    tot = {c: sum(sum(v) / len(v) for v in per.values()) for c, per in acc.items()}
+    n = {c: min(len(v) for v in per.values()) for c, per in acc.items()}
+    return tot, n
 
 
 f, nf = means("pmc_FETCH_SIZE", kernel)
@@ -47,6 +53,8 @@ for i, (K, rs) in enumerate(cfg):
                     "FETCH_SIZE_bytes": fs.get(fids[3 * i]) if 3 * i < len(fids) else None})
 print(json.dumps({
     "round": rnd, "kernel": kernel, "workload": workload,
+    # what was measured: the library the passes loaded and the kernel sources + flags it was built from
+    "library": provenance.library(), "kernel_source_sha16": provenance.kernel_source_sha16(), "hipflags": provenance.hipflags(),
     "source": "rocprofv3 --kernel-trace --pmc, separate passes (tools/profile_round.sh); reads = 2 x FETCH_SIZE as "
               "MI355X_MICROARCH.md prescribes for gfx950, cross-checked by the exact request-size counters; writes = WRITE_SIZE",
     "launches_averaged": {"FETCH_SIZE": nf.get("FETCH_SIZE", 0), "WRITE_SIZE": nw.get("WRITE_SIZE", 0), "request_counters": max(nrd.values()) if nrd else 0},
