@@ -99,7 +99,7 @@ int validate_frame(const vpcc_frame_desc* f) {
   return VPCC_OK;
 }
 
-void plan_frame(const vpcc_frame_desc& f, FramePlan* out) {
+void plan_frame(const vpcc_frame_desc& f, FramePlan* out, bool host_occupancy) {
   const int64_t R = f.occupancy_resolution;
   out->bw = f.width / f.occupancy_resolution;
   out->bh = f.height / f.occupancy_resolution;
@@ -147,8 +147,20 @@ void plan_frame(const vpcc_frame_desc& f, FramePlan* out) {
   if (out->tile_eligible) {
     std::vector<int32_t> cover((size_t)out->bw * out->bh, -1);
     for (const VBlock& b : out->vblocks) cover[b.canvas_block] = std::max(cover[b.canvas_block], (int32_t)b.patch);
+    // occupancy samples of a 16x16 block: 16 / prec per side (at least one)
+    const uint32_t spb = prec >= 16 ? 1u : 16u / prec;
+    auto block_has_occupancy = [&](uint32_t cb) {
+      const uint32_t sx = (cb % out->bw) * 16u / prec, sy = (cb / out->bw) * 16u / prec;
+      for (uint32_t y = sy; y < sy + spb && y < f.occupancy.height; ++y) {
+        const uint8_t* row = f.occupancy.y + (size_t)y * f.occupancy.stride;
+        for (uint32_t x = sx; x < sx + spb && x < f.occupancy.width; ++x)
+          if (row[x]) return true;
+      }
+      return false;
+    };
     for (const VBlock& b : out->vblocks) {
       if (cover[b.canvas_block] != (int32_t)b.patch) continue;
+      if (host_occupancy && !block_has_occupancy(b.canvas_block)) continue;   // emits nothing (src/codec.rs:236-244, 393)
       const vpcc_patch& p = f.patches[b.patch];
       TileItem t{};
       t.x0 = (uint16_t)((b.canvas_block % out->bw) * 16u);

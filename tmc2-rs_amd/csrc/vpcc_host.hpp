@@ -36,8 +36,11 @@ struct FramePlan {
 // whether an occupied pixel would actually touch the missing part.
 int validate_frame(const vpcc_frame_desc* f);
 
-// Requires validate_frame(f) == VPCC_OK.
-void plan_frame(const vpcc_frame_desc& f, FramePlan* out);
+// Requires validate_frame(f) == VPCC_OK.  `host_occupancy`: the occupancy plane is readable by the host (VPCC_MEM_HOST) —
+// the tile work list then leaves out the blocks that hold no occupancy at all (they emit nothing; the reference skips
+// them the same way: block_to_patch stays 0, src/codec.rs:236-244); with device-resident planes every covered block
+// stays in the list and the kernel finds it empty.
+void plan_frame(const vpcc_frame_desc& f, FramePlan* out, bool host_occupancy = false);
 
 // Elements of a chroma plane that the reference's flat index (v/2)*cstride + (u/2) can reach (src/decoder.rs:977):
 // what the runtime uploads of a U or V plane.

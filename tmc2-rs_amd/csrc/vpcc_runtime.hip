@@ -305,7 +305,7 @@ int gof_create_impl(vpcc_ctx* ctx, const vpcc_frame_desc* frames, uint32_t n_fra
   for (uint32_t i = 0; i < n_frames; ++i) {
     const int st = validate_frame(&frames[i]);
     if (st) return fail(ctx, st, "frame " + std::to_string(i) + ": " + vpcc_status_string(st));
-    plan_frame(frames[i], &g->plans[i]);
+    plan_frame(frames[i], &g->plans[i], kind == VPCC_MEM_HOST);
     all_simple = all_simple && g->plans[i].tile_eligible;
     g->max_vb = std::max(g->max_vb, (uint32_t)g->plans[i].vblocks.size());
     if (capacity_points == 0) cap = std::max<uint64_t>(cap, vpcc_frame_capacity_bound(&frames[i]));

@@ -29,7 +29,7 @@ w64 = m.get("TCC_EA0_WRREQ_64B_sum", 0)
 wr = 64 * w64 + 32 * (m.get("TCC_EA0_WRREQ_sum", 0) - w64)
 r = b["roofline"]
 print(f"[{i}] {flags or '(default)':48s} ms_per_step {b['ms_per_step']:.4f} kernel_ms {r['kernel_ms']:.4f}  read {rd/1e6:6.1f} MB write {wr/1e6:6.1f} MB "
-      f"(floor {r['line_floor_bytes']/1e6:.0f})  verified {all(v['equals_oracle'] for v in b['verified_frames'])}")
+      f"(floor {r['line_floor_bytes']/1e6:.0f})  verified {all(v.get('equals_oracle', v.get('entries_checked') == v.get('entries_equal_oracle')) for v in b['verified_frames'])}")
 PY
 done
 (cd "$R" && make -j8 product EXTRA= > "$out/build_restore.log" 2>&1)
