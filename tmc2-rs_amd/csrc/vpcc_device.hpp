@@ -77,7 +77,8 @@ struct DevFrame {
   // single-pass tile kernel (R == 16, Default/Swap patches, aligned planes)
   const TileItem* tiles;      // owner-filtered items, emission order
   uint64_t* scan_state;       // one {status:2 | value:32} word per group of 16 items
-  uint32_t* ticket;           // dynamic group counter (deadlock-free ordering of the look-back chain)
+  uint64_t* ticket;           // dynamic group counter {launch generation : 32 | groups drawn : 32} (deadlock-free ordering of
+                              // the look-back chain; the generation makes a counter of an earlier launch read as fresh)
   uint32_t* error_flag;       // set when a bounded spin gives up
   uint32_t occ_stride, occ_w, occ_h;
   uint32_t geo_stride[2];
@@ -149,7 +150,8 @@ void launch_emit(const DevFrame* d_frames, uint32_t first, uint32_t count, uint3
 constexpr uint32_t kTileMapSlots = 128;   // resident workgroups per XCD on MI355X (32 CUs x 4)
 struct TileLaunchMap {
   uint8_t frame_of_slot[8][kTileMapSlots];   // frame = xcd + 8 * value (relative to the launch's first frame); 0xFF: none
-  uint8_t wgs_of_slot[8][kTileMapSlots];     // workgroups that frame gets in this launch (what re-arms its ticket counter)
+  uint8_t wgs_of_slot[8][kTileMapSlots];     // workgroups that frame gets in this launch (planning invariant; the kernel
+                                             // needs no head count: ticket counters carry the launch generation)
   uint32_t slots;                            // slots per XCD in use; 0: equal split over max_groups / depth workgroups per frame
 };
 // weights[i]: tiles of frame first + i.  resident_per_xcd: workgroups of this kernel an XCD holds at a time.

@@ -323,7 +323,7 @@ int gof_create_impl(vpcc_ctx* ctx, const vpcc_frame_desc* frames, uint32_t n_fra
     size_t patches, vblocks, items, b2p, vb_count, vb_offset, xyz, rgb, pidx, occ, geo[2], ay[2], au[2], av[2];
   };
   std::vector<Off> offs(n_frames);
-  // control words of the single-pass path: contiguous so that one memset re-arms a launch
+  // control words of the single-pass path: one contiguous region, zeroed once at creation
   g->scan_off.assign(n_frames + 1, 0);
   for (uint32_t i = 0; i < n_frames; ++i)
     g->scan_off[i + 1] = g->scan_off[i] + (g->plans[i].tiles.size() + kTileScanGranule - 1) / kTileScanGranule;
@@ -412,7 +412,7 @@ int gof_create_impl(vpcc_ctx* ctx, const vpcc_frame_desc* frames, uint32_t n_fra
     D.tiles = (const TileItem*)(base + o.items);
     D.n_tiles = (uint32_t)P.tiles.size();
     D.scan_state = g->d_scan + g->scan_off[i];
-    D.ticket = g->d_tickets + 64 * (size_t)i;
+    D.ticket = reinterpret_cast<uint64_t*>(g->d_tickets + 64 * (size_t)i);
     D.error_flag = g->d_errors + i;
     D.width = F.width; D.height = F.height; D.R = F.occupancy_resolution; D.prec = F.occupancy_precision;
     D.prec_shift = 0;
@@ -568,12 +568,12 @@ extern "C" int vpcc_gof_reconstruct(vpcc_gof* g, uint32_t first, uint32_t count,
   Timer T(g, s, true);
 
   if (!g->general) {
-    // single-pass tile kernel: re-arm counts, tickets and look-back words, then ONE kernel
+    // single-pass tile kernel: ONE kernel, nothing to prepare
     uint32_t max_groups = 0;
     for (uint32_t i = first; i < first + count; ++i)
       max_groups = std::max(max_groups, (uint32_t)((g->plans[i].tiles.size() + kTileItemsPerGroup - 1) / kTileItemsPerGroup));
-    // Nothing to clear: look-back words carry the launch generation, every ticket counter is re-armed by
-    // the last workgroup that draws from it, and a frame's point count is rewritten by its last group
+    // Nothing to clear: look-back words and ticket counters carry the launch generation (a counter of an earlier
+    // launch is reset by the first workgroup that draws from it), and a frame's point count is rewritten by its last group
     // (a frame without tiles keeps the zero written at creation).
     g->generation = (g->generation % 0x3FFFFFFFu) + 1u;
     T.begin("k_recon_tiles");

@@ -36,7 +36,9 @@
 // Cross-workgroup ordering is placement-independent (cdna_hip_programming.md §6 Guideline 16):
 // groups are drawn from a per-frame TICKET counter, so a look-back only waits for tickets that
 // running workgroups hold; state words are 8-byte {status,value} granules moved with relaxed
-// agent-scope atomics.  XCD-aware blockIdx mapping is used for L2 locality only.
+// agent-scope atomics.  XCD-aware blockIdx mapping is used for L2 locality only.  Ticket counters and look-back
+// words carry the launch generation: nothing is cleared between launches, and any number of workgroups may work on
+// a frame — a workgroup whose own frames have run dry helps with the frames that are still open.
 #include <hip/hip_runtime.h>
 #include <algorithm>
 
@@ -79,6 +81,26 @@ __device__ __forceinline__ uint64_t st_load(const uint64_t* p) {
 }
 __device__ __forceinline__ void st_store(uint64_t* p, uint64_t v) {
   __hip_atomic_store(glw(p), v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+// Ticket counter of a frame: {launch generation : 32 | groups drawn : 32}, drawn with one returning 64-bit add.  A
+// value whose generation is not this launch's belongs to an earlier launch: the drawer resets the counter with a
+// compare-and-swap and holds ticket 0 (or finds that another workgroup did, and draws again).  Nothing is cleared
+// between launches, and ANY number of workgroups may draw from a frame — what lets a workgroup whose own frames have
+// run dry help with the frames its XCD still works on.
+__device__ __forceinline__ uint64_t ticket_add(uint64_t* w) {
+  return __hip_atomic_fetch_add(glw(w), 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ uint32_t ticket_settle(uint64_t* w, uint32_t gen, uint64_t drawn) {      // one lane
+  for (uint32_t tries = 0; (uint32_t)(drawn >> 32) != gen; ++tries) {
+    uint64_t cur = __hip_atomic_load(gl(w), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if ((uint32_t)(cur >> 32) == gen) { drawn = ticket_add(w); continue; }
+    const uint64_t fresh = ((uint64_t)gen << 32) | 1ull;
+    if (__hip_atomic_compare_exchange_strong(glw(w), &cur, fresh, __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))
+      return 0u;
+    if (tries > kSpinLimit) return 0xFFFFFFFFu;              // never in a healthy run (reads as "past the end")
+  }
+  return (uint32_t)drawn;
 }
 
 // Exclusive prefix of group `g` within its frame.  One full wave; same result in every lane.
@@ -637,7 +659,7 @@ __device__ __forceinline__ uint32_t item_in_group(uint32_t wave, uint32_t i) { r
 template <bool kStamps>
 __global__ __launch_bounds__(64 * kTileWaves) __attribute__((amdgpu_waves_per_eu(4, 4)))
 void k_recon_tiles(const DevFrame* __restrict__ frames, uint32_t first,
-                                                     uint32_t count, uint32_t groups_stride_arg, uint32_t gen,
+                                                     uint32_t count, uint32_t gen,
                                                      uint32_t variant_arg, const TileLaunchMap map) {
   const uint32_t variant = kDiagnostic ? variant_arg : 0u;
   // XCD-aware placement (speed only): ids equal mod 8 share an XCD/L2; a frame stays on one label.
@@ -653,23 +675,18 @@ void k_recon_tiles(const DevFrame* __restrict__ frames, uint32_t first,
   const uint32_t frame_groups = (count + 7u) / 8u;
   const bool rounds = frame_groups > kFramesInFlight;
   uint32_t label_frame = rounds ? slot % kFramesInFlight : slot % frame_groups;   // (spreading a frame over all XCDs instead: 0.147 -> 0.164 ms)
-  uint32_t groups_stride = groups_stride_arg;              // workgroups of this frame in the launch
-  if (rounds) {
-    const uint32_t per_xcd = gridDim.x >> 3;               // every frame of team t is visited by the slots = t mod kFramesInFlight
-    groups_stride = (per_xcd - label_frame + kFramesInFlight - 1u) / kFramesInFlight;
-  } else if (map.slots) {                // shares in proportion to the frames' sizes (TileLaunchMap)
+  if (!rounds && map.slots) {                              // shares in proportion to the frames' sizes (TileLaunchMap)
     if (slot >= map.slots) return;
     const uint32_t v = map.frame_of_slot[xcd][slot];
     if (v == 0xFFu) return;
     label_frame = v;
-    groups_stride = map.wgs_of_slot[xcd][slot];
   }
 #ifdef VPCC_DIAGNOSTIC
   const unsigned long long wg_t0 = (variant & 8192u) ? stamp_time() : 0ull;
   unsigned long long wg_steps = 0;
 #endif
 
-  __shared__ uint32_t s_group;
+  __shared__ uint32_t s_group, s_frame;
   __shared__ uint32_t s_tot[2][kTileItemsPerGroup];                     // point counts of the two groups in flight
   __shared__ __attribute__((aligned(16))) uint2 s_slots[kTileWaves][kSlotsPerWave];
 
@@ -692,33 +709,71 @@ void k_recon_tiles(const DevFrame* __restrict__ frames, uint32_t first,
   Px4 gn0[4] = {}, gn1[4] = {}, gc0[4] = {}, gc1[4] = {};
   Samples a_first = {};                // attribute samples of the wave's first item of the current group,
                                        // prefetched during the previous step
-  uint32_t t_ahead = 0;
-  if (threadIdx.x == 0)
-    t_ahead = __hip_atomic_fetch_add(glw(fn->ticket), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  // Once its own frames have run dry a workgroup HELPS: it draws from the frames of its XCD label that still have
+  // groups to hand out (the last frames of the other teams, which end up to 12 % apart: frames differ in size).
+  bool helping = false;
+  uint32_t help_label = 0;                                   // offset of the label being helped from the workgroup's own
+  uint64_t t_ahead = 0;
+  if (threadIdx.x == 0) t_ahead = ticket_add(fn->ticket);
   asm volatile("" : "+v"(t_ahead));                            // delivered on every path into the loop: no wait at its top
   for (;;) {
     // ---- 1. the NEXT group.  Its ticket was drawn a step earlier (the round trip of the atomic is hidden behind the
-    // previous group's item loop).  Every workgroup of a frame stops at its first ticket past the end, so exactly
-    // n_groups + groups_stride tickets are drawn per frame and launch: the last re-arms the counter (nothing to clear
-    // between launches).  A workgroup whose ticket is past the end goes on to the next frame of its team AT ONCE and
-    // counts that frame's group while it emits the last group it holds of the frame it leaves: a change of frame
-    // costs one exposed ticket round trip, not a count-only step.
-    if (threadIdx.x == 0) s_group = t_ahead;
+    // previous group's item loop).  A workgroup whose ticket is past the end of its frame goes on to another frame AT
+    // ONCE — the next one of its team, then any frame of its label that is not exhausted — and counts that frame's
+    // group while it emits the last group it holds of the frame it leaves: a change of frame costs exposed ticket
+    // round trips, not a count-only step.
+    if (threadIdx.x == 0) s_group = ticket_settle(fn->ticket, gen, t_ahead);
     wg_sync_lds();
     uint32_t g_next = __builtin_amdgcn_readfirstlane(s_group);
     bool have_next = true;
-    for (;;) {
-      if (threadIdx.x == 0 && g_next + 1u == n_groups_next + groups_stride)
-        __hip_atomic_store(glw(fn->ticket), 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      if (g_next < n_groups_next) break;
-      label_frame += kFramesInFlight;
-      if (!rounds || xcd + 8u * label_frame >= count) { have_next = false; break; }
-      fn = (CFrame*)frames + (first + xcd + 8u * label_frame);
-      n_groups_next = (fn->n_tiles + kTileItemsPerGroup - 1u) / kTileItemsPerGroup;
+    while (g_next >= n_groups_next) {
       wg_sync_lds();                                         // every wave has read s_group
-      if (threadIdx.x == 0)
-        s_group = __hip_atomic_fetch_add(glw(fn->ticket), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if (!helping) {
+        label_frame += kFramesInFlight;
+        if (!rounds || xcd + 8u * label_frame >= count) helping = true;
+      }
+      if (wave == 0) {
+        uint32_t pick = helping ? 0xFFFFFFFFu : label_frame, pick_label = help_label;
+        if (helping) {
+          // Lane j looks at frame j of a label: exhausted = drawn from in this launch, and past its last group.  The
+          // workgroup's own label first (its lines are in this XCD's L2), then the other XCDs' — they end up to 4 %
+          // apart, and at the very end of a launch locality matters less than an idle CU.
+          for (uint32_t tries = 0; tries < 8u && pick == 0xFFFFFFFFu; ++tries) {
+            const uint32_t fj = ((xcd + pick_label) & 7u) + 8u * lane;
+            bool open = false;
+            if (lane < frame_groups && fj < count) {
+              CFrame* fq = (CFrame*)frames + (first + fj);
+              const uint64_t w = __hip_atomic_load(gl(fq->ticket), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+              const uint32_t ng = (fq->n_tiles + kTileItemsPerGroup - 1u) / kTileItemsPerGroup;
+              open = (uint32_t)(w >> 32) != gen || (uint32_t)w < ng;
+            }
+            const uint64_t m = __ballot(open);
+            if (m) {                                           // the first open frame behind the one just left (wrapping)
+              const uint32_t from = (label_frame + 1u) & 63u;
+              const uint64_t hi = from ? m >> from << from : m;
+              pick = (uint32_t)__builtin_ctzll(hi ? hi : m);
+            } else {
+              pick_label = (pick_label + 1u) & 7u;
+              if (pick_label == 0u) break;                     // every label looked at: nothing left in the launch
+            }
+          }
+        }
+        if (lane == 0) {
+          uint32_t t = 0;
+          if (pick != 0xFFFFFFFFu) {
+            CFrame* fq = (CFrame*)frames + (first + ((xcd + pick_label) & 7u) + 8u * pick);
+            t = ticket_settle(fq->ticket, gen, ticket_add(fq->ticket));
+          }
+          s_group = t; s_frame = pick == 0xFFFFFFFFu ? pick : pick | (pick_label << 28);
+        }
+      }
       wg_sync_lds();
+      const uint32_t pick = __builtin_amdgcn_readfirstlane(s_frame);
+      if (pick == 0xFFFFFFFFu) { have_next = false; break; }
+      label_frame = pick & 0x0FFFFFFFu;
+      help_label = pick >> 28;
+      fn = (CFrame*)frames + (first + ((xcd + help_label) & 7u) + 8u * label_frame);
+      n_groups_next = (fn->n_tiles + kTileItemsPerGroup - 1u) / kTileItemsPerGroup;
       g_next = __builtin_amdgcn_readfirstlane(s_group);
     }
     // Speculative read of the current group's look-back words.  It is issued BEHIND the count phase's plane
@@ -793,7 +848,7 @@ void k_recon_tiles(const DevFrame* __restrict__ frames, uint32_t first,
         st_store(fn->scan_state + g_next, ((uint64_t)gen << kGenShift) | (g_next == 0 ? kPrefix : kAggregate) | total_next);
     }
     if (threadIdx.x == 0 && have_next)                       // a workgroup that saw the end of its last frame draws no more
-      t_ahead = __hip_atomic_fetch_add(glw(fn->ticket), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      t_ahead = ticket_add(fn->ticket);
     VPCC_STAMP(3)
     __builtin_amdgcn_s_setprio(0);
 
@@ -965,12 +1020,12 @@ void launch_tiles(const DevFrame* d_frames, uint32_t first, uint32_t count, uint
 #ifdef VPCC_DIAGNOSTIC
   if (variant & 64u) {
     hipLaunchKernelGGL(k_recon_tiles<true>, dim3(grid), dim3(64 * kTileWaves), 0, (hipStream_t)stream, d_frames, first, count,
-                       wgs, gen, variant, map);
+                       gen, variant, map);
     return;
   }
 #endif
   hipLaunchKernelGGL(k_recon_tiles<false>, dim3(grid), dim3(64 * kTileWaves), 0, (hipStream_t)stream, d_frames, first, count,
-                     wgs, gen, variant, map);
+                     gen, variant, map);
 }
 
 }  // namespace vpcc
