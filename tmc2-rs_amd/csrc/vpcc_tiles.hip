@@ -502,24 +502,12 @@ __device__ __forceinline__ void out_store(VPCC_GLOBAL unsigned char* p, T v) {
   __builtin_nontemporal_store(v, (VPCC_GLOBAL T*)p);
 }
 
-// One point's 6 B (dword + short) / one colour's 3 B at a 32-bit byte offset from a uniform base:
-// consecutive lanes write consecutive points, so a wave covers 384 / 192 contiguous bytes.
-__device__ __forceinline__ void store_xyz(VPCC_GLOBAL unsigned char* base, uint32_t byte_off, uint2 p) {
-  out_store<u32_a2>(base + byte_off, p.x);
-  out_store<u16_a2>(base + byte_off + 4, (uint16_t)p.y);
-}
+// Two points' 12 B at a 32-bit byte offset from a uniform base: consecutive lanes write consecutive pairs, a wave
+// covers 768 contiguous bytes.
 __device__ __forceinline__ void store_xyz2(VPCC_GLOBAL unsigned char* base, uint32_t byte_off, uint2 p, uint2 q) {
   u32x3 o;
   o.x = p.x; o.y = (p.y & 0xFFFFu) | (q.x << 16); o.z = (q.x >> 16) | (q.y << 16);
-  out_store<u32x3_a2>(base + byte_off, o);               // one unaligned dwordx3
-}
-__device__ __forceinline__ void store_rgb2(VPCC_GLOBAL unsigned char* base, uint32_t byte_off, uint32_t c0, uint32_t c1) {
-  out_store<u32_a2>(base + byte_off, (c0 & 0xFFFFFFu) | (c1 << 24));
-  out_store<u16_a2>(base + byte_off + 4, (uint16_t)(c1 >> 8));
-}
-__device__ __forceinline__ void store_rgb(VPCC_GLOBAL unsigned char* base, uint32_t byte_off, uint32_t rgb) {
-  out_store<u16_a2>(base + byte_off, (uint16_t)rgb);
-  out_store<uint8_t>(base + byte_off + 2, (uint8_t)(rgb >> 16));
+  out_store<u32x3_a2>(base + byte_off, o);
 }
 
 }  // namespace
@@ -598,52 +586,66 @@ __device__ __forceinline__ void emit_item(CFrame& f, const Item& it, const Sampl
   // takes one scalar operand: with two, the compiler re-materialises one as v_mov inside the loop), the
   // mode-1 clamp is a plain unsigned min against d1 (mode 0: against 2^32-1).
   const PointConsts pc = point_consts(it);
-  // Two consecutive points per lane (one 12-B xyz store per lane, one 12-B rgb store per even lane for FOUR points).
-  // The lane <-> point map is aligned to the frame's ABSOLUTE point index, not to the item's first point: lane l of
-  // trip t handles the points abs0 + 128 t + 2 l, +1 with abs0 a multiple of 128, so that every store instruction
-  // between the item's first and last covers whole 128-byte lines (128 points = 768 B of positions = 384 B of
-  // colours = 256 B of partition entries) and every dwordx3 is dword-aligned.  Lanes before the item's first point
-  // (first trip) and behind its last one (last trip) store nothing.
-  const uint32_t shift = base & 127u, abs0 = base - shift;
-  for (uint32_t kk = 2u * lane; kk < nw + shift; kk += 128u) {
-    const uint32_t k = kk - shift;                             // record index of the lane's first point (wraps below 0)
-    const bool v0 = k < nw, v1 = k + 1u < nw;                  // unsigned: "negative" indices are >= nw
-    const uint2 r0 = slots[v0 ? k : 0u], r1 = slots[v1 ? k + 1u : 0u];
-    uint2 p0 = pack_point(pc, r0.x), p1 = pack_point(pc, r1.x);
-    if (!f.absolute_d1) {                                   // wave-uniform; relative D1: the D0 record of the pixel precedes it
-      if (v0 && (r0.x >> 24) != 0)
-        p0 = relative_point(it.axes & 3u, it.flags & kTileMode1, pack_point(pc, (slots[k - 1u].x & 0xFFFFu) | (r0.x & 0xFF0000u)), r0.x & 0xFFFFu);
-      if (v1 && (r1.x >> 24) != 0)
-        p1 = relative_point(it.axes & 3u, it.flags & kTileMode1, pack_point(pc, (slots[k].x & 0xFFFFu) | (r1.x & 0xFF0000u)), r1.x & 0xFFFFu);
-    }
-    if ((variant & 32u) && p0.x != 0xFFFFFFFEu) continue;               // ablation: all the arithmetic, no stores
-    const uint32_t c2 = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)r0.y, 0xF5, 0xF, 0xF, false);   // quad_perm:[1,1,3,3]
-    const uint32_t c3 = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)r1.y, 0xF5, 0xF, 0xF, false);
-    const bool odd = lane & 1u;
-    const bool quad = !odd && v0 && k + 3u < nw;               // this even lane stores its own and its odd neighbour's colours
-    const bool covered = odd && k - 2u < nw && v1;             // ... and for an odd lane: its even neighbour does
-    const uint32_t a = abs0 + kk;                              // absolute index of the lane's first point (even)
-    if (v0 && v1) {
+  // The item's points B .. E-1 (absolute indices in the frame) leave in two parts:
+  //   bulk  : the whole QUADS of points, [b4, e4) with b4 = B rounded up and e4 = E rounded down to a multiple of four.
+  //           Two consecutive points per lane: one 12-B xyz store per lane, one 12-B rgb store per even lane for four
+  //           points — never a partial pair or quad, hence no edge cases and exactly two store instructions per trip.
+  //           The lane <-> point map is aligned to the ABSOLUTE point index (lane l of trip t: points abs0 + 128 t + 2 l, +1
+  //           with abs0 a multiple of 128), so that every store instruction between the first and the last covers whole
+  //           128-byte lines (128 points = 768 B of positions = 384 B of colours = 256 B of partition entries) and
+  //           every dwordx3 is dword-aligned.
+  //   edges : the up to three points in front of b4 and the up to three behind e4 — at most 54 bytes — with ONE byte-store
+  //           instruction, lane <-> byte (lanes 0..26: head, 32..58: tail).  The pair / single / quad-remainder stores
+  //           these points used to need were 5.7 of the 12.4 store instructions per item, each with one to three
+  //           active lanes (profiles/r03/insts_per_variant.txt).
+  const uint32_t B = base, E = base + nw;
+  const uint32_t b4 = (B + 3u) & ~3u, e4 = E & ~3u;
+  auto point_of = [&](uint32_t r, uint32_t rx) -> uint2 {
+    uint2 p = pack_point(pc, rx);
+    if (!f.absolute_d1 && (rx >> 24) != 0)                 // relative D1: the D0 record of the pixel precedes it
+      p = relative_point(it.axes & 3u, it.flags & kTileMode1, pack_point(pc, (slots[r - 1u].x & 0xFFFFu) | (rx & 0xFF0000u)), rx & 0xFFFFu);
+    return p;
+  };
+  if (b4 < e4)
+    for (uint32_t a = (b4 & ~127u) + 2u * lane; a < e4; a += 128u) {
+      if (a < b4) continue;                                    // (first trip: lanes in front of the bulk; whole lane pairs)
+      const uint32_t k = a - B;                                // record index of the lane's first point
+      const uint2 r0 = slots[k], r1 = slots[k + 1u];
+      uint2 p0 = pack_point(pc, r0.x), p1 = pack_point(pc, r1.x);
+      if (!f.absolute_d1) {                                    // wave-uniform
+        if ((r0.x >> 24) != 0)
+          p0 = relative_point(it.axes & 3u, it.flags & kTileMode1, pack_point(pc, (slots[k - 1u].x & 0xFFFFu) | (r0.x & 0xFF0000u)), r0.x & 0xFFFFu);
+        if ((r1.x >> 24) != 0)
+          p1 = relative_point(it.axes & 3u, it.flags & kTileMode1, pack_point(pc, (r0.x & 0xFFFFu) | (r1.x & 0xFF0000u)), r1.x & 0xFFFFu);
+      }
+      if ((variant & 32u) && p0.x != 0xFFFFFFFEu) continue;               // ablation: all the arithmetic, no stores
+      const uint32_t c2 = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)r0.y, 0xF5, 0xF, 0xF, false);   // quad_perm:[1,1,3,3]
+      const uint32_t c3 = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)r1.y, 0xF5, 0xF, 0xF, false);
       store_xyz2(gx, a * 6u, p0, p1);
       if (gp) out_store<uint32_t>((VPCC_GLOBAL unsigned char*)gp + a * 2u, it.patch | (it.patch << 16));   // partition, codec.rs:452
-    } else if (v0) {
-      store_xyz(gx, a * 6u, p0);
-      if (gp) gp[a] = (uint16_t)it.patch;
-    } else if (v1) {
-      store_xyz(gx, (a + 1u) * 6u, p1);
-      if (gp) gp[a + 1u] = (uint16_t)it.patch;
-    }
-    if (f.has_attr) {
-      if (quad) {
+      if (f.has_attr && !(lane & 1u)) {                        // an even lane: its own and its odd neighbour's colours
         u32x3 o;
         o.x = (r0.y & 0xFFFFFFu) | (r1.y << 24); o.y = ((r1.y >> 8) & 0xFFFFu) | (c2 << 16); o.z = ((c2 >> 16) & 0xFFu) | (c3 << 8);
         out_store<u32x3>(gc + a * 3u, o);
-      } else if (!covered) {
-        if (v0 && v1) store_rgb2(gc, a * 3u, r0.y, r1.y);
-        else if (v0) store_rgb(gc, a * 3u, r0.y);
-        else if (v1) store_rgb(gc, (a + 1u) * 3u, r1.y);
       }
     }
+  {
+    const uint32_t t0 = e4 > b4 ? e4 : b4;                     // the first point behind the bulk
+    const uint32_t hn = (b4 < E ? b4 : E) - B, tn = E > t0 ? E - t0 : 0u;      // head / tail points, 0..3 each
+    const uint32_t j = lane & 31u, pt = (j * 57u) >> 9, byte = j - 9u * pt;    // pt = j / 9 for j < 64
+    const bool tail = lane >= 32u;
+    const uint32_t ap = (tail ? t0 : B) + pt;                  // the lane's point, absolute
+    const bool on = pt < (tail ? tn : hn) && (byte < 6u || f.has_attr) && !(variant & 32u);
+    if (on) {
+      const uint2 rec = slots[ap - B];
+      const uint2 p = point_of(ap - B, rec.x);
+      const uint32_t word = byte < 4u ? p.x : byte < 6u ? p.y : rec.y;
+      const uint32_t sh = 8u * (byte < 4u ? byte : byte < 6u ? byte - 4u : byte - 6u);
+      VPCC_GLOBAL unsigned char* dst = byte < 6u ? gx + (size_t)ap * 6u + byte : gc + (size_t)ap * 3u + (byte - 6u);
+      out_store<uint8_t>(dst, (uint8_t)(word >> sh));
+    }
+    if (gp && (lane & 31u) < 3u && (lane & 31u) < (tail ? tn : hn) && !(variant & 32u))
+      gp[(tail ? t0 : B) + (lane & 31u)] = (uint16_t)it.patch;
   }
   __builtin_amdgcn_s_setprio(0);
   wave_sync();                                      // the next item overwrites the slots
