@@ -97,3 +97,32 @@ def test_long_multi_sequence_stream_in_order(tmp_path):
     assert got == [ref[k] for k in order]
     assert zlib.crc32(np.array(got, np.uint32).tobytes()) == zlib.crc32(np.array([ref[k] for k in order], np.uint32).tobytes())
     d.close()
+
+
+def test_ctx_bind_thread_keeps_the_thread_inside_its_allowed_cpus():
+    """vpcc_ctx_bind_thread: the calling thread ends up on the CPUs of the GPU's NUMA node (or stays where it is when
+    the platform reports none) — never outside what the process may use; run on a thread of its own, like a lane."""
+    import ctypes as C
+    import os
+    import threading
+    from tmc2rs import _abi
+    lib = _abi.load_library()
+    out = {}
+
+    def lane():
+        before = os.sched_getaffinity(0)
+        ctx = C.c_void_p()
+        assert lib.vpcc_ctx_create(0, C.byref(ctx)) == 0
+        node = C.c_int(-7)
+        out["status"] = lib.vpcc_ctx_bind_thread(ctx, C.byref(node))
+        out["node"] = node.value
+        out["before"], out["after"] = before, os.sched_getaffinity(0)
+        lib.vpcc_ctx_destroy(ctx)
+
+    t = threading.Thread(target=lane)
+    t.start()
+    t.join()
+    assert out["status"] == 0 and out["node"] >= -1
+    assert out["after"] and out["after"] <= out["before"]
+    if out["node"] == -1:
+        assert out["after"] == out["before"]

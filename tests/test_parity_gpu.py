@@ -191,6 +191,25 @@ def test_launch_shapes(ctx, n_frames):
     g.close()
 
 
+def test_ticket_counters_survive_skipped_launches(ctx):
+    """Ticket counters carry the launch generation instead of being cleared or re-armed: frames that sit out some
+    launches of their gof (disjoint sub-ranges, repeated) must be found fresh when their turn comes again, and frames
+    helped by workgroups of other frames must come out the same."""
+    pool = [cases.medium_frame(i) for i in range(4)] + [synth.small_frame(i) for i in range(4)]
+    refs_pool = [ob.reconstruct(f)[1] for f in pool]
+    n = 40
+    pick = [(3 * i + i // 7) % len(pool) for i in range(n)]
+    g = ctx.gof([pool[k] for k in pick], flags=_abi.VPCC_GOF_WANT_PATCH_INDEX)
+    for first, count in [(0, 9), (9, 20), (9, 20), (29, 11), (9, 20), (0, 9), (0, 40), (17, 3), (0, 40)]:
+        g.reconstruct(first=first, count=count)
+        counts = g.point_counts()
+        for i in range(first, first + count):
+            assert counts[i] == refs_pool[pick[i]]["n"], (first, count, i)
+        for i in sorted({first, first + count // 2, first + count - 1}):
+            _check(g.download(i, want_patch_index=True), refs_pool[pick[i]])
+    g.close()
+
+
 def test_gof_is_deterministic_and_idempotent(ctx):
     frames = [synth.longdress_frame(i) for i in range(4)]
     g = ctx.gof(frames, capacity=1_000_000)

@@ -5,8 +5,9 @@
 // written down in oracle/vpcc_smoothing_spec.h and tested bit for bit against its CPU form.
 //
 // Four kernels per filter, one thread per point:
-//   k_smooth_stats : per occupied grid cell {count, 3 sums, max(65535 - patch), max(patch)} with atomics into
-//                    a dense w^3 grid that is all-zero between launches; keeps every point's cell index;
+//   k_smooth_stats : per occupied grid cell {count, 3 sums, sum of patch indices, sum of their squares} — every field
+//                    a sum, one atomic instruction per (wave, cell) — into a dense w^3 grid that is all-zero between
+//                    launches; keeps every point's cell index;
 //   k_smooth_mark  : paints a byte flag around every cell that mixes patches;
 //   k_smooth_apply : one flag load; only flagged points read their 2x2x2 cells -> integer trilinear weights
 //                    -> centroid / mean, thresholded replacement in place (a thread reads only its own point
