@@ -144,9 +144,9 @@ def test_gof_of_very_unequal_frames_on_the_tile_path(ctx):
 
 
 def test_large_launch_runs_in_rounds(ctx):
-    """Launches of more than 64 frames work through each XCD label's frames eight at a time, a workgroup moving on
+    """Launches of more than 128 frames work through each XCD label's frames sixteen at a time, a workgroup moving on
     to the next frame of its team when its frame has no ticket left (k_recon_tiles, kFramesInFlight): 150 frames of
-    different sizes (a partial third round, labels with 18 and 19 frames), launched twice and over a sub-range that
+    different sizes (a partial second round, labels with 18 and 19 frames), launched twice and over a sub-range that
     is itself more than one round."""
     makers = [lambda i: cases.medium_frame(i % 12), lambda i: synth.small_frame(i % 20),
               lambda i: cases.medium_frame(200 + i % 10, occupancy_values="random")]
@@ -169,10 +169,10 @@ def test_large_launch_runs_in_rounds(ctx):
     g.close()
 
 
-@pytest.mark.parametrize("n_frames", [1, 7, 8, 9, 31, 33, 63, 64, 65, 71, 129, 200])
+@pytest.mark.parametrize("n_frames", [1, 7, 8, 9, 31, 33, 63, 64, 65, 71, 127, 128, 129, 137, 200, 260])
 def test_launch_shapes(ctx, n_frames):
     """Every shape of a tile-kernel launch — fewer frames than XCDs, labels of unequal length, proportional shares up
-    to 64 frames, rounds above — on GOFs cycled from a few small and medium frames, full range and a sub-range."""
+    to 128 frames, rounds above — on GOFs cycled from a few small and medium frames, full range and a sub-range."""
     pool = [synth.small_frame(i) for i in range(6)] + [cases.medium_frame(i) for i in range(3)]
     refs_pool = [ob.reconstruct(f)[1] for f in pool]
     pick = [(i * 5 + i // 3) % len(pool) for i in range(n_frames)]

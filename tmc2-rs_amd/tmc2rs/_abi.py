@@ -18,6 +18,8 @@ LIB_PATH = os.path.join(PROJECT_DIR, "libvpcc_recon.so")
 # tile kernel).  tests/, bench.py and __graft_entry__ never set this.
 if os.environ.get("VPCC_DIAG_LIB") == "1":
     LIB_PATH = os.path.join(PROJECT_DIR, "libvpcc_recon_diag.so")
+elif os.environ.get("VPCC_DIAG_LIB"):                       # tools/ab_multi.sh: any other build of the library, by file name
+    LIB_PATH = os.path.join(PROJECT_DIR, os.path.basename(os.environ["VPCC_DIAG_LIB"]))
 
 VPCC_OK = 0
 VPCC_ERR_INVALID_ARG = 1

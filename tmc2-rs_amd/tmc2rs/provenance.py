@@ -43,4 +43,4 @@ def library():
     """{name, sha16, diagnostic} of the shared object this process loads."""
     path = _abi.LIB_PATH
     return {"name": os.path.relpath(path, _abi.REPO_ROOT), "sha16": _sha16([open(path, "rb").read()]),
-            "diagnostic": path.endswith("_diag.so"), "kernel_source_sha16": kernel_source_sha16()}
+            "diagnostic": os.path.basename(path) != "libvpcc_recon.so", "kernel_source_sha16": kernel_source_sha16()}
