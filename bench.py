@@ -91,6 +91,7 @@ def parse():
     ap.add_argument("--smooth", action="store_true",
                     help="BASELINE config 4: grid geometry + colour smoothing after reconstruction (own spec, see DESIGN.md)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-gpu-state", action="store_true", help="skip the rocm-smi reading of clocks and power under load")
     ap.add_argument("--no-other-configs", action="store_true", help="skip the S-owlii and smoothing legs (`other_configs`)")
     ap.add_argument("--diag", action="store_true",
                     help="allow the diagnostic library (VPCC_DIAG_LIB=1, tools/ only): its timings are not the product's")
@@ -241,6 +242,37 @@ def main():
             kernels[name] = kernels.get(name, 0.0) + ms * n_
         launches_averaged += n_
     kernels = {name: v / max(launches_averaged, 1) for name, v in kernels.items()}
+
+    # Clocks and power WHILE the kernel runs (rank 0, best effort): boxes and runs of one build differ by up to 10 %
+    # in `ms_per_step`; this says which state a run was measured in.  A short untimed burst of the same launches keeps
+    # the GPU busy while rocm-smi reads its sensors.
+    gpu_state = None
+    if rank == 0 and not args.no_gpu_state:
+        try:
+            import re
+            import subprocess
+            for _ in range(1500):
+                step()
+            txt = subprocess.run(["rocm-smi", "--showclocks", "--showpower", "--showbus", "--showcomputepartition",
+                                  "--showmemorypartition"], capture_output=True, text=True, timeout=20).stdout
+            sync_all()
+            gpu_state = {}
+            for name in ("sclk", "mclk", "fclk"):
+                m = re.search(r"GPU\[%d\]\s*:\s*%s clock level: \S+ \((\d+)Mhz\)" % (0, name), txt)
+                if m:
+                    gpu_state[name + "_MHz"] = int(m.group(1))
+            m = re.search(r"Power \(W\):\s*([0-9.]+)", txt)
+            if m:
+                gpu_state["socket_power_W"] = float(m.group(1))
+            for key, pat in (("pci_bus", r"PCI Bus:\s*(\S+)"), ("compute_partition", r"Compute Partition:\s*(\S+)"),
+                             ("memory_partition", r"Memory Partition:\s*(\S+)")):
+                m = re.search(pat, txt)
+                if m:
+                    gpu_state[key] = m.group(1)
+            gpu_state["note"] = "rocm-smi while an untimed burst of the same launches runs, right after the timed region"
+        except Exception as e:                                   # sensors are evidence, not a dependency
+            gpu_state = {"error": str(e)[:200]}
+            sync_all()
 
     # Launches of ONE 32-frame GOF, the step of round 1, for comparison (rank 0, never `value`): over three copies in
     # rotation (an HBM rate) and on one copy again and again (how round 1 was timed; part of its planes stays in the
@@ -577,6 +609,7 @@ def main():
                        "parallelism": f"frame-sharded x{world}, no collective on the data path"},
             "roofline": roofline,
             "library": lib_info,
+            "gpu_state_under_load": gpu_state,
             "other_configs": other,
             "launches_of_one_gof": one_gof,
             "repeat_one_batch": repeat,

@@ -91,14 +91,17 @@ __device__ __forceinline__ void st_store(uint64_t* p, uint64_t v) {
 __device__ __forceinline__ uint64_t ticket_add(uint64_t* w) {
   return __hip_atomic_fetch_add(glw(w), 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
-__device__ uint32_t ticket_settle(uint64_t* w, uint32_t gen, uint64_t drawn) {      // one lane
+__device__ uint32_t ticket_settle(uint64_t* w, uint32_t gen, uint64_t drawn, uint32_t* error_flag) {      // one lane
   for (uint32_t tries = 0; (uint32_t)(drawn >> 32) != gen; ++tries) {
     uint64_t cur = __hip_atomic_load(gl(w), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     if ((uint32_t)(cur >> 32) == gen) { drawn = ticket_add(w); continue; }
     const uint64_t fresh = ((uint64_t)gen << 32) | 1ull;
     if (__hip_atomic_compare_exchange_strong(glw(w), &cur, fresh, __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))
       return 0u;
-    if (tries > kSpinLimit) return 0xFFFFFFFFu;              // never in a healthy run (reads as "past the end")
+    if (tries > kSpinLimit) {                                // never in a healthy run; reported by the host
+      atomicOr(error_flag, 1u);
+      return 0xFFFFFFFFu;                                    // (reads as "past the end")
+    }
   }
   return (uint32_t)drawn;
 }
@@ -725,7 +728,7 @@ void k_recon_tiles(const DevFrame* __restrict__ frames, uint32_t first,
     // ONCE — the next one of its team, then any frame of its label that is not exhausted — and counts that frame's
     // group while it emits the last group it holds of the frame it leaves: a change of frame costs exposed ticket
     // round trips, not a count-only step.
-    if (threadIdx.x == 0) s_group = ticket_settle(fn->ticket, gen, t_ahead);
+    if (threadIdx.x == 0) s_group = ticket_settle(fn->ticket, gen, t_ahead, fn->error_flag);
     wg_sync_lds();
     uint32_t g_next = __builtin_amdgcn_readfirstlane(s_group);
     bool have_next = true;
@@ -765,7 +768,7 @@ void k_recon_tiles(const DevFrame* __restrict__ frames, uint32_t first,
           uint32_t t = 0;
           if (pick != 0xFFFFFFFFu) {
             CFrame* fq = (CFrame*)frames + (first + ((xcd + pick_label) & 7u) + 8u * pick);
-            t = ticket_settle(fq->ticket, gen, ticket_add(fq->ticket));
+            t = ticket_settle(fq->ticket, gen, ticket_add(fq->ticket), fq->error_flag);
           }
           s_group = t; s_frame = pick == 0xFFFFFFFFu ? pick : pick | (pick_label << 28);
         }

@@ -13,7 +13,7 @@ for flags in "$@"; do
   (cd "$R" && make -j8 product EXTRA="$flags" > "$out/build_$i.log" 2>&1) || { echo "[$i] build failed: $flags"; tail -5 "$out/build_$i.log"; continue; }
   (cd "$R" && python3 bench.py --steps 200 --no-cpu-baseline --no-end-to-end --no-other-configs --no-compare $BENCH_ARGS > "$out/bench_$i.json" 2> "$out/bench_$i.err") || { echo "[$i] bench failed: $flags"; tail -3 "$out/bench_$i.err"; continue; }
   (cd /tmp && TMPDIR=/tmp rocprofv3 --kernel-trace --pmc TCC_EA0_RDREQ_128B_sum TCC_EA0_RDREQ_64B_sum TCC_EA0_WRREQ_sum TCC_EA0_WRREQ_64B_sum \
-     --output-format csv -d "$out/pmc_$i" -- python3 "$R/bench.py" --steps 3 --warmup 1 --ramp-ms 0 --min-seconds 0 --no-cpu-baseline --no-verify --no-end-to-end --no-other-configs --no-compare $BENCH_ARGS > "$out/pmc_$i.log" 2>&1) || echo "[$i] pmc failed"
+     --output-format csv -d "$out/pmc_$i" -- python3 "$R/bench.py" --steps 3 --warmup 1 --ramp-ms 0 --min-seconds 0 --no-cpu-baseline --no-verify --no-end-to-end --no-other-configs --no-gpu-state --no-compare $BENCH_ARGS > "$out/pmc_$i.log" 2>&1) || echo "[$i] pmc failed"
   python3 - "$out" "$i" "$flags" <<'PY'
 import csv, glob, json, sys, collections
 out, i, flags = sys.argv[1], sys.argv[2], sys.argv[3]

@@ -6,7 +6,7 @@
 n=${1:-8}; shift
 for i in $(seq $n); do
   for k in 0 1; do
-    VPCC_DIAG_LIB=$k python3 bench.py --diag --steps 200 --no-cpu-baseline --no-end-to-end --no-other-configs --no-compare --no-verify "$@" 2>/dev/null \
+    VPCC_DIAG_LIB=$k python3 bench.py --diag --steps 200 --no-cpu-baseline --no-end-to-end --no-other-configs --no-gpu-state --no-compare --no-verify "$@" 2>/dev/null \
       | python3 -c "import sys,json; d=json.loads(sys.stdin.read()); print($k, d['roofline']['kernel_ms'])"
   done
 done | python3 -c "

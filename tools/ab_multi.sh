@@ -16,7 +16,7 @@ for r in $(seq $n); do
   i=0
   for flags in "$@"; do
     i=$((i+1))
-    VPCC_DIAG_LIB=libvpcc_ab_$i.so python3 bench.py --diag --steps 200 --no-cpu-baseline --no-end-to-end --no-other-configs --no-compare --no-verify $BENCH_ARGS 2>/dev/null \
+    VPCC_DIAG_LIB=libvpcc_ab_$i.so python3 bench.py --diag --steps 200 --no-cpu-baseline --no-end-to-end --no-other-configs --no-gpu-state --no-compare --no-verify $BENCH_ARGS 2>/dev/null \
       | python3 -c "import sys,json; d=json.loads(sys.stdin.read()); print($i, d['roofline']['kernel_ms'])"
   done
 done > /tmp/ab_multi_runs.txt

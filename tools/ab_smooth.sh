@@ -7,7 +7,7 @@ i=0
 for flags in "$@"; do
   i=$((i+1))
   (cd "$R" && make -j8 product EXTRA="$flags" > /tmp/ab_smooth_build_$i.log 2>&1) || { echo "[$i] build failed: $flags"; tail -5 /tmp/ab_smooth_build_$i.log; continue; }
-  (cd "$R" && python3 bench.py --smooth --steps 100 --no-cpu-baseline --no-end-to-end --no-other-configs $([ "$VERIFY" = 0 ] && echo --no-verify) 2>/dev/null) | python3 -c "
+  (cd "$R" && python3 bench.py --smooth --steps 100 --no-cpu-baseline --no-end-to-end --no-other-configs --no-gpu-state $([ "$VERIFY" = 0 ] && echo --no-verify) 2>/dev/null) | python3 -c "
 import sys, json
 d = json.loads(sys.stdin.read())
 k = d['roofline']['all_kernels_ms']

@@ -14,7 +14,7 @@ export VPCC_DIAG_LIB=1
 pass() {  # name counters...
   name=$1; shift
   rocprofv3 --kernel-trace --pmc "$@" --output-format csv -d "$out/$name" -- \
-    python3 "$R/bench.py" --diag --steps 3 --warmup 1 --ramp-ms 0 --no-cpu-baseline --profile-steps 1 --no-verify --no-end-to-end --no-other-configs --no-compare \
+    python3 "$R/bench.py" --diag --steps 3 --warmup 1 --ramp-ms 0 --no-cpu-baseline --profile-steps 1 --no-verify --no-end-to-end --no-other-configs --no-gpu-state --no-compare \
     > "$out/$name.log" 2>&1 || echo "pass $name failed"
 }
 for v in $variants; do

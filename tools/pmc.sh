@@ -8,7 +8,7 @@ cd /tmp && export TMPDIR=/tmp
 run() {
   name=$1; shift
   rocprofv3 --kernel-trace --pmc "$@" --output-format csv -d "$out/$name" -- \
-    python3 "$GRAFT_REPO_ROOT/bench.py" --steps 3 --warmup 1 --ramp-ms 0 --no-cpu-baseline --no-verify --no-end-to-end --no-other-configs --no-compare --min-seconds 0 $BENCH_ARGS \
+    python3 "$GRAFT_REPO_ROOT/bench.py" --steps 3 --warmup 1 --ramp-ms 0 --no-cpu-baseline --no-verify --no-end-to-end --no-other-configs --no-gpu-state --no-compare --min-seconds 0 $BENCH_ARGS \
     > "$out/$name.log" 2>&1 || echo "pass $name failed"
 }
 run sq1 SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS

@@ -4,7 +4,7 @@ out=$1; mkdir -p "$out"; out=$(cd "$out" && pwd)
 R=$GRAFT_REPO_ROOT
 cd /tmp; export TMPDIR=/tmp
 pass() { name=$1; shift
-  rocprofv3 --kernel-trace --pmc "$@" --output-format csv -d "$out/$name" -- python3 $R/bench.py --smooth --steps 3 --warmup 1 --ramp-ms 0 --min-seconds 0 --no-cpu-baseline --no-verify --no-end-to-end --no-other-configs > "$out/$name.log" 2>&1 || echo "pass $name failed"; }
+  rocprofv3 --kernel-trace --pmc "$@" --output-format csv -d "$out/$name" -- python3 $R/bench.py --smooth --steps 3 --warmup 1 --ramp-ms 0 --min-seconds 0 --no-cpu-baseline --no-verify --no-end-to-end --no-other-configs --no-gpu-state > "$out/$name.log" 2>&1 || echo "pass $name failed"; }
 pass a SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_WAVES SQ_INSTS_VMEM_WR
 pass b SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_ACTIVE_INST_VALU SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_ACTIVE_INST_ANY
 python3 - "$out" <<'PY'
