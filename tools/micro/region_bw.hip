@@ -15,6 +15,18 @@ __global__ __launch_bounds__(256) void kr(const uint4* __restrict__ src, unsigne
   }
   if (acc == 0x12345u) out[0] = acc;
 }
+// one 16-B read per 4 KB page, pages visited in a scattered order: bound by address translation, not by bandwidth
+__global__ __launch_bounds__(256) void kp(const unsigned char* __restrict__ src, unsigned* __restrict__ out, size_t pages) {
+  size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+  const size_t stride = (size_t)gridDim.x * 256;
+  unsigned acc = 0;
+  for (; i < pages; i += stride) {
+    const size_t pg = (i * 2654435761ull) % pages;
+    const uint4 v = *(const uint4*)(src + pg * 4096 + (i & 255) * 16);
+    acc += v.x ^ v.y;
+  }
+  if (acc == 0x12345u) out[0] = acc;
+}
 __global__ __launch_bounds__(256) void k(const uint4* __restrict__ src, uint4* __restrict__ dst, size_t n) {
   size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
   const size_t stride = (size_t)gridDim.x * 256;
@@ -41,6 +53,13 @@ int main(int argc, char** argv) {
     hipLaunchKernelGGL(kr, 2048, 256, 0, 0, (const uint4*)p, (unsigned*)(p + half), win, 8);
     hipEventRecord(b); hipEventSynchronize(b);
     float ms2; hipEventElapsedTime(&ms2, a, b);
+    const size_t pages = half / 4096;
+    hipLaunchKernelGGL(kp, 2048, 256, 0, 0, p, (unsigned*)(p + half), pages);
+    hipEventRecord(a);
+    for (int w = 0; w < 5; ++w) hipLaunchKernelGGL(kp, 2048, 256, 0, 0, p, (unsigned*)(p + half), pages);
+    hipEventRecord(b); hipEventSynchronize(b);
+    float ms3; hipEventElapsedTime(&ms3, a, b); ms3 /= 5;
+    printf("   scattered page reads %.1f G pages/s  |  ", pages / ms3 / 1e6);
     printf("buffer %2d at +%3zu GiB (%p): copy %.0f GB/s   re-read of a 128 MB window %.0f GB/s\n", i, (size_t)i * 4, (void*)p,
            2.0 * half / ms / 1e6, 8.0 * (128ull << 20) / ms2 / 1e6);
   }
