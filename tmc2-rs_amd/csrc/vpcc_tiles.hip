@@ -1005,7 +1005,7 @@ void launch_tiles(const DevFrame* d_frames, uint32_t first, uint32_t count, uint
   // groups each workgroup is expected to pipeline (tickets are drawn dynamically; this only sizes the grid)
   uint32_t depth = 3, variant = 0;
 #ifdef VPCC_DIAGNOSTIC
-  static const uint32_t env_variant = [] {
+  const uint32_t env_variant = [] {                          // read at every launch: tools switch ablations within a process
     const char* e = getenv("VPCC_TILES_VARIANT");
     return e ? (uint32_t)atoi(e) : 0u;
   }();
