@@ -7,6 +7,8 @@
 //   shape 2: positions dwordx2 per lane, colours dword per lane
 //   shape 3: positions dword + short per lane (one point per lane), colours short + byte
 //   shape 4: as 0, but every instruction's range starts on a 128-B line (what the aligned lane <-> point map gives)
+//   shape 5: as 1, but every item starts on a 128-B line and covers whole lines only (1920 B + 1024 B per item): no line is
+//            shared between two waves
 // nt = non-temporal stores.  Reports GB/s of stored bytes.
 #include <hip/hip_runtime.h>
 #include <cstdio>
@@ -40,6 +42,11 @@ __global__ __launch_bounds__(256) void k(unsigned char* xyz, unsigned char* rgb,
       } else if (SHAPE == 1) {
         for (int o = 16 * lane; o < 1824; o += 1024) { u32x4 v = {(unsigned)o, 1u, 2u, 3u}; st<u32x4, NT>(px + o, v); }
         for (int o = 16 * lane; o < 912; o += 1024) { u32x4 v = {(unsigned)o, 1u, 2u, 3u}; st<u32x4, NT>(pc + o, v); }
+      } else if (SHAPE == 5) {
+        unsigned char* qx = xyz + (size_t)i * 1920;
+        unsigned char* qc = rgb + (size_t)i * 1024;
+        for (int o = 16 * lane; o < 1920; o += 1024) { u32x4 v = {(unsigned)o, 1u, 2u, 3u}; st<u32x4, NT>(qx + o, v); }
+        { u32x4 v = {(unsigned)lane, 1u, 2u, 3u}; st<u32x4, NT>(qc + 16 * lane, v); }
       } else if (SHAPE == 2) {
         for (int o = 8 * lane; o < 1824; o += 512) { u32x2 v = {(unsigned)o, 1u}; st<u32x2, NT>(px + o, v); }
         for (int o = 4 * lane; o < 912; o += 256) st<unsigned, NT>(pc + o, (unsigned)o);
@@ -51,19 +58,32 @@ __global__ __launch_bounds__(256) void k(unsigned char* xyz, unsigned char* rgb,
       }
     }
 }
+static bool g_compact = false;
 template <int SHAPE, bool NT> void run(unsigned char* xyz, unsigned char* rgb, int items, hipEvent_t a, hipEvent_t b) {
   for (int w = 0; w < 2; ++w) hipLaunchKernelGGL((k<SHAPE, NT>), 1024, 256, 0, 0, xyz, rgb, items);
   hipEventRecord(a);
   for (int w = 0; w < 5; ++w) hipLaunchKernelGGL((k<SHAPE, NT>), 1024, 256, 0, 0, xyz, rgb, items);
   hipEventRecord(b); hipEventSynchronize(b);
   float ms; hipEventElapsedTime(&ms, a, b); ms /= 5;
-  printf("shape %d %s: %.3f ms  %.0f GB/s\n", SHAPE, NT ? "nt   " : "plain", ms, (double)items * 2736 / ms / 1e6);
+  printf("shape %d %s: %.3f ms  %.0f GB/s   ", SHAPE, NT ? "nt   " : "plain", ms, (double)items * (SHAPE == 5 ? 2944 : 2736) / ms / 1e6);
+  if (!g_compact) printf("\n");
 }
-int main() {
+int main(int argc, char** argv) {
   const int items = 333000;                       // one 128-frame S-longdress launch: 911 MB of output
   unsigned char *xyz, *rgb;
-  hipMalloc(&xyz, (size_t)items * 1824 + 4096); hipMalloc(&rgb, (size_t)items * 912 + 4096);
   hipEvent_t a, b; hipEventCreate(&a); hipEventCreate(&b);
+  if (argc > 1) {                                 // "regions N": the kernel's shape on N output buffers one after the other in VRAM
+    const int n = atoi(argv[1]);
+    for (int i = 0; i < n; ++i) {
+      g_compact = true;
+      hipMalloc(&xyz, (size_t)items * 1920 + 4096); hipMalloc(&rgb, (size_t)items * 1024 + 4096);
+      unsigned char* pad; hipMalloc(&pad, 3ull << 30);      // (kept: the next pair lies 4 GB further on)
+      printf("region %2d: ", i); run<4, true>(xyz, rgb, items, a, b); run<4, false>(xyz, rgb, items, a, b);
+      run<1, true>(xyz, rgb, items, a, b); run<5, true>(xyz, rgb, items, a, b); run<5, false>(xyz, rgb, items, a, b); printf("\n");
+    }
+    return 0;
+  }
+  hipMalloc(&xyz, (size_t)items * 1824 + 4096); hipMalloc(&rgb, (size_t)items * 912 + 4096);
   run<0, true>(xyz, rgb, items, a, b); run<4, true>(xyz, rgb, items, a, b); run<1, true>(xyz, rgb, items, a, b);
   run<2, true>(xyz, rgb, items, a, b); run<3, true>(xyz, rgb, items, a, b);
   run<0, false>(xyz, rgb, items, a, b); run<4, false>(xyz, rgb, items, a, b); run<1, false>(xyz, rgb, items, a, b);
