@@ -59,10 +59,11 @@ __global__ __launch_bounds__(256) void k(unsigned char* xyz, unsigned char* rgb,
     }
 }
 static bool g_compact = false;
+static int g_wgs = 1024;
 template <int SHAPE, bool NT> void run(unsigned char* xyz, unsigned char* rgb, int items, hipEvent_t a, hipEvent_t b) {
-  for (int w = 0; w < 2; ++w) hipLaunchKernelGGL((k<SHAPE, NT>), 1024, 256, 0, 0, xyz, rgb, items);
+  for (int w = 0; w < 2; ++w) hipLaunchKernelGGL((k<SHAPE, NT>), g_wgs, 256, 0, 0, xyz, rgb, items);
   hipEventRecord(a);
-  for (int w = 0; w < 5; ++w) hipLaunchKernelGGL((k<SHAPE, NT>), 1024, 256, 0, 0, xyz, rgb, items);
+  for (int w = 0; w < 5; ++w) hipLaunchKernelGGL((k<SHAPE, NT>), g_wgs, 256, 0, 0, xyz, rgb, items);
   hipEventRecord(b); hipEventSynchronize(b);
   float ms; hipEventElapsedTime(&ms, a, b); ms /= 5;
   printf("shape %d %s: %.3f ms  %.0f GB/s   ", SHAPE, NT ? "nt   " : "plain", ms, (double)items * (SHAPE == 5 ? 2944 : 2736) / ms / 1e6);
@@ -78,7 +79,13 @@ int main(int argc, char** argv) {
       g_compact = true;
       hipMalloc(&xyz, (size_t)items * 1920 + 4096); hipMalloc(&rgb, (size_t)items * 1024 + 4096);
       unsigned char* pad; hipMalloc(&pad, 3ull << 30);      // (kept: the next pair lies 4 GB further on)
-      printf("region %2d: ", i); run<4, true>(xyz, rgb, items, a, b); run<4, false>(xyz, rgb, items, a, b);
+      printf("region %2d: ", i);
+      if (argc > 2) {                               // "regions N wgs": shape 4 nt by the number of workgroups (concurrent write streams)
+        for (int wg : {128, 256, 512, 1024, 2048}) { g_wgs = wg; printf("[%d wgs] ", wg); run<4, true>(xyz, rgb, items, a, b); }
+        printf("\n");
+        continue;
+      }
+      run<4, true>(xyz, rgb, items, a, b); run<4, false>(xyz, rgb, items, a, b);
       run<1, true>(xyz, rgb, items, a, b); run<5, true>(xyz, rgb, items, a, b); run<5, false>(xyz, rgb, items, a, b); printf("\n");
     }
     return 0;
