@@ -93,6 +93,8 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-gpu-state", action="store_true", help="skip the rocm-smi reading of clocks and power under load")
     ap.add_argument("--no-other-configs", action="store_true", help="skip the S-owlii and smoothing legs (`other_configs`)")
+    ap.add_argument("--no-tune-placement", action="store_true",
+                    help="create the resident batches without VPCC_GOF_TUNE_PLACEMENT (blocks stay where hipMalloc put them)")
     ap.add_argument("--diag", action="store_true",
                     help="allow the diagnostic library (VPCC_DIAG_LIB=1, tools/ only): its timings are not the product's")
     ap.add_argument("--no-compare", action="store_true",
@@ -173,6 +175,10 @@ def main():
 
     ctx = recon.Context(local_rank)
     flags = (_abi.VPCC_GOF_FORCE_GENERAL if args.general else 0) | _abi.VPCC_GOF_PROFILE
+    # the timed batches are resident and launched thousands of times: what VPCC_GOF_TUNE_PLACEMENT is for (the
+    # measurement runs inside the first launch, in the warm-up; `config.placement` reports what it found and cost)
+    tune = 0 if args.no_tune_placement else _abi.VPCC_GOF_TUNE_PLACEMENT
+    flags |= tune
     if args.smooth:
         flags |= _abi.VPCC_GOF_WANT_PATCH_INDEX
     bitdepth = 10 if args.workload == "longdress" else 11
@@ -474,7 +480,7 @@ def main():
         mk = synth.longdress_frame if workload == "longdress" else synth.owlii_frame
         fr2 = frames[:n_distinct] if workload == args.workload else [mk(i) for i in range(n_distinct)]
         cap2 = 1_000_000 if workload == "longdress" else 2_400_000
-        fl = _abi.VPCC_GOF_PROFILE | (_abi.VPCC_GOF_WANT_PATCH_INDEX if smooth else 0)
+        fl = _abi.VPCC_GOF_PROFILE | tune | (_abi.VPCC_GOF_WANT_PATCH_INDEX if smooth else 0)
         g2 = ctx.gof(fr2 * cycles_, capacity=cap2, flags=fl)
         g2.profile_interval(4)
         nb = n_distinct * cycles_
@@ -528,9 +534,11 @@ def main():
                          "frac_traffic": round(tro["hbm_bytes_per_launch"] / (km * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4) if tro else None,
                          "traffic_stale": (tro.get("kernel_source_sha16") != lib_info["kernel_source_sha16"]) if tro else None,
                          "entries_checked": 2 * n_distinct, "equals_oracle": bool(eq)})
+        out2["placement"] = g2.placement() if tune else "as allocated"
         g2.close()
         return out2
 
+    placement_info = [g_.placement() for g_ in gofs] if tune else "as allocated"
     other = None
     if rank == 0 and world == 1 and not args.no_other_configs and not args.smooth and not args.general and args.workload == "longdress":
         for g_ in gofs:                                          # their 5 GB are not needed any more
@@ -604,6 +612,7 @@ def main():
                        "frames_per_step_per_gpu": n_batch, "points_per_step_per_gpu": points_per_step,
                        "distinct_frames": args.frames, "gofs_per_launch": max(args.cycles, 1),
                        "batches_in_rotation": len(gofs),
+                       "placement": placement_info,
                        "kernel_path": "general" if args.general else "default",
                        "smoothing": smooth_kw if args.smooth else None,
                        "parallelism": f"frame-sharded x{world}, no collective on the data path"},

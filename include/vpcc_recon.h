@@ -34,7 +34,7 @@
 extern "C" {
 #endif
 
-#define VPCC_ABI_VERSION 2   /* 2: vpcc_ctx_bind_thread, vpcc_decoder_stats, vpcc_gof_profile_interval / _kernel_time_means; portable page-locking */
+#define VPCC_ABI_VERSION 3   /* 2: vpcc_ctx_bind_thread, vpcc_decoder_stats, vpcc_gof_profile_interval / _kernel_time_means; portable page-locking */
 
 /* ------------------------------------------------------------------ status */
 typedef enum vpcc_status {
@@ -212,6 +212,27 @@ void vpcc_gof_destroy(vpcc_gof* gof);
                                            overlapping the previous GOF's kernels).  The planes must be pinned
                                            (vpcc_host_pin) and stay valid until the first vpcc_gof_sync /
                                            vpcc_gof_point_counts / vpcc_gof_download of this gof.          */
+
+#define VPCC_GOF_TUNE_PLACEMENT   0x10u /* for a gof that will be launched many times (a resident batch).  How fast
+                                           the memory system takes the tile kernel's streams depends on where in VRAM
+                                           the gof's two big blocks lie — its ingested planes and its output arrays —
+                                           by about 10 % of the kernel's time, and nothing but the kernel predicts it.
+                                           With this flag the first whole-gof vpcc_gof_reconstruct measures the kernel
+                                           on candidate allocations of each block (up to VPCC_PLACEMENT_CANDIDATES,
+                                           default 16, alive together; no new one once VPCC_PLACEMENT_BUDGET_MS,
+                                           default 250, have passed), keeps the fastest and frees the rest.  The blocks move during that call:
+                                           vpcc_gof_device_outputs before it pins them where they are (no measurement).
+                                           Not for a gof launched once (the streaming Decoder does not set it).   */
+
+/* What VPCC_GOF_TUNE_PLACEMENT did for this gof (all zero when it did not run). */
+typedef struct vpcc_placement_info {
+  uint32_t tuned;            /* 1: the measurement ran for this gof, 2: the gof reuses a measured pair of blocks */
+  uint32_t candidates;       /* placements measured                                                            */
+  float    ms_as_allocated;  /* per launch with the blocks as hipMalloc returned them                          */
+  float    ms_kept;          /* per launch with the blocks kept                                                */
+  float    ms_spent;         /* wall clock of the measurement (inside the first whole-gof reconstruct)         */
+} vpcc_placement_info;
+int vpcc_gof_placement(vpcc_gof* gof, vpcc_placement_info* out);
 
 /* Enqueues the reconstruction of frames [first, first+count) on `hip_stream`
  * (a hipStream_t passed as void*; NULL = the context's own stream).  Returns

@@ -210,6 +210,51 @@ def test_ticket_counters_survive_skipped_launches(ctx):
     g.close()
 
 
+def test_tuned_placement_moves_blocks_not_results(ctx):
+    """VPCC_GOF_TUNE_PLACEMENT: the first whole-gof launch measures the kernel on candidate allocations of the planes
+    block and the output block and keeps the fastest pair; the results are those of an untuned gof and of the oracle,
+    partial launches before it do not trigger it, and a later gof of the same shape reuses the measured pair."""
+    frames = [synth.longdress_frame(i) for i in range(6)]
+    refs = [ob.reconstruct(f)[1] for f in frames]
+    flags = _abi.VPCC_GOF_WANT_PATCH_INDEX | _abi.VPCC_GOF_TUNE_PLACEMENT
+    g = ctx.gof(frames, capacity=1_000_000, flags=flags)
+    g.reconstruct(first=0, count=3)
+    assert g.placement()["tuned"] == 0
+    for i in range(3):
+        _check(g.download(i, want_patch_index=True), refs[i])
+    g.reconstruct()
+    p = g.placement()
+    assert p["tuned"] == 1 and p["candidates"] >= 2 and 0 < p["ms_kept"] <= 1.05 * p["ms_as_allocated"], p
+    for i in range(6):
+        _check(g.download(i, want_patch_index=True), refs[i])
+    g.reconstruct(first=2, count=3)
+    g.reconstruct()
+    for i in range(6):
+        _check(g.download(i, want_patch_index=True), refs[i])
+    g.smooth(10, grid_size=8, threshold=4)                      # the filters follow the blocks
+    g.sync()
+    g.close()
+    g = ctx.gof(frames, capacity=1_000_000, flags=flags)           # the pair kept by the context
+    g.reconstruct()
+    assert g.placement()["tuned"] == 2
+    for i in (0, 5):
+        _check(g.download(i, want_patch_index=True), refs[i])
+    g.close()
+
+
+def test_device_outputs_pin_the_blocks(ctx):
+    """Pointers handed out by vpcc_gof_device_outputs stay valid: asking for them before the first launch switches the
+    placement measurement off for that gof."""
+    frames = [synth.longdress_frame(i) for i in range(4)]
+    g = ctx.gof(frames, capacity=1_000_000, flags=_abi.VPCC_GOF_TUNE_PLACEMENT)
+    before = [g.device_outputs(i) for i in range(4)]
+    g.reconstruct()
+    assert g.placement()["tuned"] == 0
+    assert [g.device_outputs(i) for i in range(4)] == before
+    _check(g.download(3), ob.reconstruct(frames[3])[1])
+    g.close()
+
+
 def test_gof_is_deterministic_and_idempotent(ctx):
     frames = [synth.longdress_frame(i) for i in range(4)]
     g = ctx.gof(frames, capacity=1_000_000)

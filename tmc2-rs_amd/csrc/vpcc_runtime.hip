@@ -11,6 +11,7 @@
 
 #include <algorithm>
 #include <cctype>
+#include <chrono>
 #include <cstdio>
 #include <cstring>
 #include <string>
@@ -33,6 +34,15 @@ struct vpcc_ctx {
   // Arenas of destroyed GOFs are kept for the next GOF of the same shape: hipMalloc/hipFree cost
   // milliseconds and hipFree synchronises the whole device, which would stall a GOF pipeline.
   std::vector<std::pair<void*, size_t>> arena_cache;
+  // The two big blocks of a gof — the video planes it ingested and its output arrays — are allocations of their own,
+  // chosen by measurement (place_blocks below); the pairs of destroyed gofs are kept with their score.
+  struct Placement {
+    void* planes = nullptr; size_t planes_bytes = 0;     // ingested planes (VPCC_MEM_HOST gofs only)
+    void* out = nullptr; size_t out_bytes = 0;           // positions, colours, partition of all frames
+    float score = 0.f;                                   // 1 / ms of the launch that chose the pair (0 = never measured)
+    vpcc_placement_info info{};
+  };
+  std::vector<Placement> placement_cache;
 };
 
 struct KernelTiming {
@@ -58,6 +68,8 @@ struct vpcc_gof {
   std::vector<DevFrame> h_frames;      // host mirror of d_frames
   void* arena = nullptr;
   size_t arena_bytes = 0;
+  vpcc_ctx::Placement mem;             // the planes block and the output block
+  bool placed = false;                 // the blocks are final (place_blocks ran, or the caller holds pointers into them)
   DevFrame* d_frames = nullptr;
   uint32_t* d_counts = nullptr;        // n_frames contiguous point counters
   uint32_t* d_b2p = nullptr;           // all frames' block_to_patch, contiguous
@@ -161,6 +173,7 @@ extern "C" void vpcc_ctx_destroy(vpcc_ctx* ctx) {
   if (!ctx) return;
   (void)hipSetDevice(ctx->device);
   for (auto& a : ctx->arena_cache) (void)hipFree(a.first);
+  for (auto& b : ctx->placement_cache) { (void)hipFree(b.planes); (void)hipFree(b.out); }
   if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
   if (ctx->copy_stream) (void)hipStreamDestroy(ctx->copy_stream);
   if (ctx->d2h_stream) (void)hipStreamDestroy(ctx->d2h_stream);
@@ -273,6 +286,17 @@ extern "C" void vpcc_gof_destroy(vpcc_gof* gof) {
     if (cache.size() < 4) cache.emplace_back(gof->arena, gof->arena_bytes);
     else (void)hipFree(gof->arena);
   }
+  if (gof->mem.out) {
+    auto& cache = gof->ctx->placement_cache;                     // at most four pairs: the slowest (unmeasured first,
+    cache.push_back(gof->mem);                                    // oldest among equals) goes
+    if (cache.size() > 4) {
+      size_t worst = 0;
+      for (size_t k = 1; k < cache.size(); ++k) if (cache[k].score < cache[worst].score) worst = k;
+      (void)hipFree(cache[worst].planes);
+      (void)hipFree(cache[worst].out);
+      cache.erase(cache.begin() + worst);
+    }
+  }
   if (gof->h_counts) (void)hipHostFree(gof->h_counts);
   delete gof;
 }
@@ -288,6 +312,124 @@ int copy_plane(vpcc_ctx* ctx, void* dst, const void* src, size_t elem, uint32_t 
     HIP_TRY(ctx, hipMemcpy2DAsync(dst, (size_t)width * elem, src, (size_t)stride * elem, (size_t)width * elem, height,
                                   hipMemcpyHostToDevice, s));
   }
+  return VPCC_OK;
+}
+
+// Placement of the two big blocks.  How fast the memory system takes the tile kernel's streams depends on WHERE in
+// VRAM the planes and the output arrays lie, by about 10 % of the kernel's time (profiles/r03/placement.txt); no
+// simpler access pattern predicts it, so the kernel itself is the probe: the first whole-gof launch of a gof whose
+// blocks are new runs on a few candidate output blocks (alive together, so they lie in different places), keeps the
+// fastest, does the same for the planes block (device-to-device copies), and once more for the output block if the
+// planes moved.  VPCC_PLACEMENT_CANDIDATES=1 takes the allocations as they come.
+void rebase_frames(vpcc_gof* g, const void* from, size_t bytes, void* to) {
+  const char* lo = (const char*)from;
+  const ptrdiff_t d = (char*)to - lo;
+  auto mv = [&](auto& p) {
+    const char* c = (const char*)p;
+    if (c && c >= lo && c < lo + bytes) p = (std::remove_reference_t<decltype(p)>)(c + d);
+  };
+  for (DevFrame& D : g->h_frames) {
+    mv(D.occ);
+    for (int m = 0; m < 2; ++m) { mv(D.geo[m]); mv(D.attr_y[m]); mv(D.attr_u[m]); mv(D.attr_v[m]); }
+    mv(D.out_xyz); mv(D.out_rgb); mv(D.out_patch);
+  }
+}
+
+int place_blocks(vpcc_gof* g, uint32_t max_groups, hipStream_t s) {
+  vpcc_ctx* ctx = g->ctx;
+  g->placed = true;
+  static const int wanted = [] {
+    const char* e = getenv("VPCC_PLACEMENT_CANDIDATES");
+    const int v = e ? atoi(e) : 16;
+    return v < 1 ? 1 : v > 32 ? 32 : v;
+  }();
+  static const double budget_ms = [] {                 // no new candidate once the measurement has taken this long
+    const char* e = getenv("VPCC_PLACEMENT_BUDGET_MS");
+    return e ? atof(e) : 250.0;
+  }();
+  vpcc_ctx::Placement& M = g->mem;
+  if (M.score > 0.f) { M.info.tuned = 2; return VPCC_OK; }                     // a pair measured by an earlier gof
+  if (wanted <= 1 || M.out_bytes < (size_t(32) << 20)) return VPCC_OK;          // too small to matter
+  const bool trace = getenv("VPCC_RUNTIME_TRACE") != nullptr;
+  const uint32_t nf = g->n_frames;
+  hipEvent_t a, b;
+  HIP_TRY(ctx, hipEventCreate(&a));
+  HIP_TRY(ctx, hipEventCreate(&b));
+  auto launch = [&] {
+    g->generation = (g->generation % 0x3FFFFFFFu) + 1u;
+    launch_tiles(g->d_frames, 0, nf, max_groups, g->generation, g->tile_map, ctx->resident_tile_wgs_per_xcd, s);
+  };
+  // ms per launch with the descriptors as they stand in h_frames (first launch untimed: first touch of a new block)
+  auto measure = [&](float* ms) -> int {
+    HIP_TRY(ctx, hipMemcpyAsync(g->d_frames, g->h_frames.data(), sizeof(DevFrame) * nf, hipMemcpyHostToDevice, s));
+    launch();
+    *ms = 1e30f;
+    for (int rep = 0; rep < 2; ++rep) {
+      (void)hipEventRecord(a, s);
+      launch();
+      (void)hipEventRecord(b, s);
+      HIP_TRY(ctx, hipEventSynchronize(b));
+      float t = 0.f;
+      if (hipEventElapsedTime(&t, a, b) == hipSuccess && t > 0.f) *ms = std::min(*ms, t);
+    }
+    return VPCC_OK;
+  };
+  const auto t0 = std::chrono::steady_clock::now();
+  auto spent_ms = [&] { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count(); };
+  // One round over a block: the current allocation, then fresh ones (all alive until the round ends, so that each lies
+  // somewhere else) while the budget lasts; *moved tells whether another one than the current won.
+  auto round = [&](void** block, size_t bytes, bool copy, const char* what, float* best_ms, bool* moved) -> int {
+    size_t free_b = 0, total_b = 0;
+    (void)hipMemGetInfo(&free_b, &total_b);
+    std::vector<void*> cand{*block};
+    std::vector<float> ms;
+    size_t best = 0;
+    for (size_t c = 0; c < (size_t)wanted; ++c) {
+      if (c) {
+        if ((c >= 2 && spent_ms() > budget_ms) || (c + 1) * bytes > free_b / 2) break;    // half of what is free, at most
+        void* p = nullptr;
+        if (hipMalloc(&p, bytes) != hipSuccess) { (void)hipGetLastError(); break; }
+        cand.push_back(p);
+        if (copy) HIP_TRY(ctx, hipMemcpyAsync(p, cand[0], bytes, hipMemcpyDeviceToDevice, s));
+        rebase_frames(g, cand[c - 1], bytes, p);
+      }
+      ms.push_back(0.f);
+      const int st = measure(&ms[c]);
+      if (st) return st;
+      if (ms[c] < ms[best]) best = c;
+    }
+    rebase_frames(g, cand.back(), bytes, cand[best]);
+    HIP_TRY(ctx, hipMemcpyAsync(g->d_frames, g->h_frames.data(), sizeof(DevFrame) * nf, hipMemcpyHostToDevice, s));
+    HIP_TRY(ctx, hipStreamSynchronize(s));
+    for (size_t c = 0; c < cand.size(); ++c) if (c != best) (void)hipFree(cand[c]);
+    *block = cand[best];
+    *best_ms = ms[best];
+    if (M.info.candidates == 0) M.info.ms_as_allocated = ms[0];
+    M.info.candidates += (uint32_t)cand.size();
+    *moved = best != 0;
+    if (trace) {
+      std::string all;
+      for (float t : ms) { char buf[32]; snprintf(buf, sizeof buf, " %.3f", t); all += buf; }
+      fprintf(stderr, "[vpcc] placement, %s block %zu MB, %u frames: ms per launch by candidate%s -> kept %zu (%.0f ms so far)\n",
+              what, bytes >> 20, nf, all.c_str(), best, spent_ms());
+    }
+    return VPCC_OK;
+  };
+  float ms = 0.f;
+  bool moved = false;
+  int st = round(&M.out, M.out_bytes, false, "output", &ms, &moved);
+  if (!st && M.planes) {
+    st = round(&M.planes, M.planes_bytes, true, "planes", &ms, &moved);
+    if (!st && moved && spent_ms() < budget_ms) st = round(&M.out, M.out_bytes, false, "output", &ms, &moved);
+  }
+  (void)hipEventDestroy(a);
+  (void)hipEventDestroy(b);
+  if (st) return st;
+  M.score = 1.f / ms;
+  M.info.tuned = 1;
+  M.info.ms_kept = ms;
+  M.info.ms_spent = (float)spent_ms();
+  if (trace) fprintf(stderr, "[vpcc] placement took %.1f ms\n", M.info.ms_spent);
   return VPCC_OK;
 }
 
@@ -346,6 +488,7 @@ int gof_create_impl(vpcc_ctx* ctx, const vpcc_frame_desc* frames, uint32_t n_fra
   }
   g->b2p_words = (L.total - b2p_begin) / sizeof(uint32_t);
   L.total = align_up(L.total, 256);
+  ArenaLayout LO, LP;                                           // the output block's and the planes block's own layouts
   for (uint32_t i = 0; i < n_frames; ++i) {
     const vpcc_frame_desc& F = frames[i];
     const FramePlan& P = g->plans[i];
@@ -355,17 +498,17 @@ int gof_create_impl(vpcc_ctx* ctx, const vpcc_frame_desc* frames, uint32_t n_fra
     o.items = L.take(sizeof(TileItem) * (((P.tiles.size() + kTileItemsPerGroup - 1) / kTileItemsPerGroup) * kTileItemsPerGroup + kTileItemsPerGroup));
     o.vb_count = L.take(sizeof(uint32_t) * std::max<size_t>(P.vblocks.size(), 1));
     o.vb_offset = L.take(sizeof(uint32_t) * std::max<size_t>(P.vblocks.size(), 1));
-    o.xyz = L.take(sizeof(vpcc_point3) * cap);
-    o.rgb = F.attribute_count ? L.take(sizeof(vpcc_color3) * cap) : 0;
-    o.pidx = (gof_flags & VPCC_GOF_WANT_PATCH_INDEX) ? L.take(sizeof(uint16_t) * cap) : 0;
+    o.xyz = LO.take(sizeof(vpcc_point3) * cap);                    // (output block: positions, colours, partition in
+    o.rgb = F.attribute_count ? LO.take(sizeof(vpcc_color3) * cap) : 0;   //  this order — the smoothing kernels' 8-byte loads
+    o.pidx = (gof_flags & VPCC_GOF_WANT_PATCH_INDEX) ? LO.take(sizeof(uint16_t) * cap) : 0;   // read a few bytes past an element)
     if (kind == VPCC_MEM_HOST) {
-      o.occ = L.take((size_t)F.occupancy.width * F.occupancy.height);
+      o.occ = LP.take((size_t)F.occupancy.width * F.occupancy.height);
       for (uint32_t m = 0; m < F.map_count; ++m) {
-        o.geo[m] = L.take((size_t)F.geometry[m].width * F.geometry[m].height * 2);
+        o.geo[m] = LP.take((size_t)F.geometry[m].width * F.geometry[m].height * 2);
         if (F.attribute_count) {
-          o.ay[m] = L.take((size_t)F.attribute[m].width * F.attribute[m].height * 2);
-          o.au[m] = L.take(chroma_elems(F.attribute[m]) * 2);
-          o.av[m] = L.take(chroma_elems(F.attribute[m]) * 2);
+          o.ay[m] = LP.take((size_t)F.attribute[m].width * F.attribute[m].height * 2);
+          o.au[m] = LP.take(chroma_elems(F.attribute[m]) * 2);
+          o.av[m] = LP.take(chroma_elems(F.attribute[m]) * 2);
         }
       }
     }
@@ -381,7 +524,30 @@ int gof_create_impl(vpcc_ctx* ctx, const vpcc_frame_desc* frames, uint32_t n_fra
     }
   }
   if (!g->arena) HIP_TRY(ctx, hipMalloc(&g->arena, g->arena_bytes));
+  const size_t out_bytes = LO.total + 256, planes_bytes = LP.total ? LP.total + 256 : 0;
+  {
+    auto fits = [](size_t have, size_t need) { return need ? have >= need && have <= need + need / 4 : have == 0; };
+    auto& cache = ctx->placement_cache;
+    size_t pick = cache.size();
+    for (size_t k = 0; k < cache.size(); ++k)                     // a kept pair that fits, the fastest first
+      if (fits(cache[k].out_bytes, out_bytes) && fits(cache[k].planes_bytes, planes_bytes) &&
+          (pick == cache.size() || cache[k].score > cache[pick].score))
+        pick = k;
+    if (pick < cache.size()) {
+      g->mem = cache[pick];
+      cache.erase(cache.begin() + pick);
+    } else {
+      HIP_TRY(ctx, hipMalloc(&g->mem.out, out_bytes));
+      g->mem.out_bytes = out_bytes;
+      if (planes_bytes) {
+        HIP_TRY(ctx, hipMalloc(&g->mem.planes, planes_bytes));
+        g->mem.planes_bytes = planes_bytes;
+      }
+    }
+  }
   char* base = (char*)g->arena;
+  char* obase = (char*)g->mem.out;
+  char* pbase = (char*)g->mem.planes;
   g->d_frames = (DevFrame*)(base + off_frames);
   g->d_counts = (uint32_t*)(base + off_counts);
   g->d_b2p = (uint32_t*)(base + b2p_begin);
@@ -405,9 +571,9 @@ int gof_create_impl(vpcc_ctx* ctx, const vpcc_frame_desc* frames, uint32_t n_fra
     D.block_to_patch = (uint32_t*)(base + o.b2p);
     D.vb_count = (uint32_t*)(base + o.vb_count);
     D.vb_offset = (uint32_t*)(base + o.vb_offset);
-    D.out_xyz = (vpcc_point3*)(base + o.xyz);
-    D.out_rgb = F.attribute_count ? (vpcc_color3*)(base + o.rgb) : nullptr;
-    D.out_patch = (gof_flags & VPCC_GOF_WANT_PATCH_INDEX) ? (uint16_t*)(base + o.pidx) : nullptr;
+    D.out_xyz = (vpcc_point3*)(obase + o.xyz);
+    D.out_rgb = F.attribute_count ? (vpcc_color3*)(obase + o.rgb) : nullptr;
+    D.out_patch = (gof_flags & VPCC_GOF_WANT_PATCH_INDEX) ? (uint16_t*)(obase + o.pidx) : nullptr;
     D.n_points = g->d_counts + i;
     D.tiles = (const TileItem*)(base + o.items);
     D.n_tiles = (uint32_t)P.tiles.size();
@@ -433,28 +599,28 @@ int gof_create_impl(vpcc_ctx* ctx, const vpcc_frame_desc* frames, uint32_t n_fra
         }
       }
     } else {
-      D.occ = (const uint8_t*)(base + o.occ); D.occ_stride = F.occupancy.width;
-      int st = copy_plane(ctx, base + o.occ, F.occupancy.y, 1, F.occupancy.width, F.occupancy.height,
+      D.occ = (const uint8_t*)(pbase + o.occ); D.occ_stride = F.occupancy.width;
+      int st = copy_plane(ctx, pbase + o.occ, F.occupancy.y, 1, F.occupancy.width, F.occupancy.height,
                           F.occupancy.stride, s);
       if (st) return st;
       for (uint32_t m = 0; m < F.map_count; ++m) {
         const vpcc_image_u16& G = F.geometry[m];
-        D.geo[m] = (const uint16_t*)(base + o.geo[m]); D.geo_stride[m] = G.width;
-        st = copy_plane(ctx, base + o.geo[m], G.y, 2, G.width, G.height, G.stride, s);
+        D.geo[m] = (const uint16_t*)(pbase + o.geo[m]); D.geo_stride[m] = G.width;
+        st = copy_plane(ctx, pbase + o.geo[m], G.y, 2, G.width, G.height, G.stride, s);
         if (st) return st;
         if (F.attribute_count) {
           const vpcc_image_u16& A = F.attribute[m];
-          D.attr_y[m] = (const uint16_t*)(base + o.ay[m]);
-          D.attr_u[m] = (const uint16_t*)(base + o.au[m]);
-          D.attr_v[m] = (const uint16_t*)(base + o.av[m]);
+          D.attr_y[m] = (const uint16_t*)(pbase + o.ay[m]);
+          D.attr_u[m] = (const uint16_t*)(pbase + o.au[m]);
+          D.attr_v[m] = (const uint16_t*)(pbase + o.av[m]);
           D.attr_stride[m] = A.width; D.attr_cstride[m] = A.cstride;
-          st = copy_plane(ctx, base + o.ay[m], A.y, 2, A.width, A.height, A.stride, s);
+          st = copy_plane(ctx, pbase + o.ay[m], A.y, 2, A.width, A.height, A.stride, s);
           if (st) return st;
           // chroma keeps its source stride: the reference indexes it as a flat array
           // (v/2)*(width/2)+(u/2), src/decoder.rs:977, which for odd widths runs across rows
           const size_t ce = chroma_elems(A);
-          HIP_TRY(ctx, hipMemcpyAsync(base + o.au[m], A.u, ce * 2, hipMemcpyHostToDevice, s));
-          HIP_TRY(ctx, hipMemcpyAsync(base + o.av[m], A.v, ce * 2, hipMemcpyHostToDevice, s));
+          HIP_TRY(ctx, hipMemcpyAsync(pbase + o.au[m], A.u, ce * 2, hipMemcpyHostToDevice, s));
+          HIP_TRY(ctx, hipMemcpyAsync(pbase + o.av[m], A.v, ce * 2, hipMemcpyHostToDevice, s));
         }
       }
     }
@@ -575,14 +741,18 @@ extern "C" int vpcc_gof_reconstruct(vpcc_gof* g, uint32_t first, uint32_t count,
     // Nothing to clear: look-back words and ticket counters carry the launch generation (a counter of an earlier
     // launch is reset by the first workgroup that draws from it), and a frame's point count is rewritten by its last group
     // (a frame without tiles keeps the zero written at creation).
-    g->generation = (g->generation % 0x3FFFFFFFu) + 1u;
-    T.begin("k_recon_tiles");
     if (!g->tile_map_valid || g->tile_map_first != first || g->tile_map_count != count) {
       std::vector<uint32_t> tiles(count);
       for (uint32_t i = 0; i < count; ++i) tiles[i] = (uint32_t)g->plans[first + i].tiles.size();
       plan_tile_launch(tiles.data(), count, ctx->resident_tile_wgs_per_xcd, 3, g->tile_map);
       g->tile_map_first = first; g->tile_map_count = count; g->tile_map_valid = true;
     }
+    if (!g->placed && (g->flags & VPCC_GOF_TUNE_PLACEMENT) && first == 0 && count == g->n_frames) {
+      const int st = place_blocks(g, max_groups, s);
+      if (st) return st;
+    }
+    g->generation = (g->generation % 0x3FFFFFFFu) + 1u;
+    T.begin("k_recon_tiles");
     launch_tiles(g->d_frames, first, count, max_groups, g->generation, g->tile_map, ctx->resident_tile_wgs_per_xcd, s);
     T.end();
     HIP_TRY(ctx, hipGetLastError());
@@ -656,6 +826,7 @@ extern "C" int vpcc_gof_device_outputs(vpcc_gof* g, uint32_t frame, void** d_xyz
                                        void** d_count) {
   if (!g || frame >= g->n_frames) return VPCC_ERR_INVALID_ARG;
   const DevFrame& D = g->h_frames[frame];
+  g->placed = true;                     // the caller holds these pointers from now on
   if (d_xyz) *d_xyz = D.out_xyz;
   if (d_rgb) *d_rgb = D.out_rgb;
   if (d_patch_index) *d_patch_index = D.out_patch;
@@ -694,6 +865,12 @@ extern "C" int vpcc_gof_download(vpcc_gof* g, uint32_t frame, vpcc_point3* xyz_o
     }
     HIP_TRY(ctx, hipStreamSynchronize(s));
   }
+  return VPCC_OK;
+}
+
+extern "C" int vpcc_gof_placement(vpcc_gof* g, vpcc_placement_info* out) {
+  if (!g || !out) return VPCC_ERR_INVALID_ARG;
+  *out = g->placed ? g->mem.info : vpcc_placement_info{};
   return VPCC_OK;
 }
 

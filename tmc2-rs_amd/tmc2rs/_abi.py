@@ -37,6 +37,8 @@ VPCC_MEM_DEVICE = 1
 VPCC_GOF_WANT_PATCH_INDEX = 0x1
 VPCC_GOF_FORCE_GENERAL = 0x2
 VPCC_GOF_PROFILE = 0x4
+VPCC_GOF_ASYNC_UPLOAD = 0x8
+VPCC_GOF_TUNE_PLACEMENT = 0x10
 
 ORIENT_DEFAULT, ORIENT_SWAP, ORIENT_ROT90, ORIENT_ROT180, ORIENT_ROT270 = 0, 1, 2, 3, 4
 ORIENT_MIRROR, ORIENT_MROT90, ORIENT_MROT180, ORIENT_MROT270 = 5, 6, 7, 8
@@ -161,6 +163,11 @@ def host_frame_desc(frame):
 _lib = None
 
 
+class PlacementInfo(C.Structure):         # vpcc_placement_info
+    _fields_ = [("tuned", C.c_uint32), ("candidates", C.c_uint32), ("ms_as_allocated", C.c_float),
+                ("ms_kept", C.c_float), ("ms_spent", C.c_float)]
+
+
 class DecoderStats(C.Structure):          # vpcc_decoder_stats_t
     _fields_ = [("launches", C.c_uint64), ("frames", C.c_uint64), ("max_frames_per_launch", C.c_uint32),
                 ("lanes", C.c_uint32), ("kernel_seconds", C.c_double), ("launch_seconds", C.c_double),
@@ -219,6 +226,7 @@ def load_library():
     lib.vpcc_gof_frame_status.argtypes = [vp, u32]
     lib.vpcc_gof_kernel_times.argtypes = [vp, C.POINTER(C.c_char_p), C.POINTER(C.c_float), C.c_int]
     lib.vpcc_gof_profile_interval.argtypes = [vp, u32]
+    lib.vpcc_gof_placement.argtypes = [vp, C.POINTER(PlacementInfo)]
     lib.vpcc_gof_kernel_time_means.argtypes = [vp, u32, C.POINTER(C.c_char_p), C.POINTER(C.c_float),
                                                C.POINTER(u32), C.c_int]
     lib.vpcc_gof_algorithmic_bytes.argtypes = [vp, u32, C.POINTER(u64)]

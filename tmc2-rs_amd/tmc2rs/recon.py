@@ -147,6 +147,13 @@ class Gof:
     def sync(self):
         self.ctx._check(self.lib.vpcc_gof_sync(self.h), "vpcc_gof_sync")
 
+    def placement(self):
+        """vpcc_gof_placement: what VPCC_GOF_TUNE_PLACEMENT measured for this gof (zeros when it did not run)."""
+        p = _abi.PlacementInfo()
+        self.ctx._check(self.lib.vpcc_gof_placement(self.h, C.byref(p)), "vpcc_gof_placement")
+        return {"tuned": int(p.tuned), "candidates": int(p.candidates), "ms_as_allocated": round(p.ms_as_allocated, 4),
+                "ms_kept": round(p.ms_kept, 4), "ms_spent": round(p.ms_spent, 1)}
+
     def point_counts(self):
         out = np.zeros(self.n_frames, dtype=np.uint32)
         self.ctx._check(self.lib.vpcc_gof_point_counts(self.h, out.ctypes.data), "vpcc_gof_point_counts")
