@@ -259,8 +259,8 @@ def main():
             import subprocess
             for _ in range(1500):
                 step()
-            txt = subprocess.run(["rocm-smi", "--showclocks", "--showpower", "--showbus", "--showcomputepartition",
-                                  "--showmemorypartition"], capture_output=True, text=True, timeout=20).stdout
+            txt = subprocess.run(["rocm-smi", "--showclocks", "--showpower", "--showbus", "--showtemp",
+                                  "--showcomputepartition", "--showmemorypartition"], capture_output=True, text=True, timeout=20).stdout
             sync_all()
             gpu_state = {}
             for name in ("sclk", "mclk", "fclk"):
@@ -275,7 +275,27 @@ def main():
                 m = re.search(pat, txt)
                 if m:
                     gpu_state[key] = m.group(1)
+            for key, pat in (("junction_C", r"Temperature \(Sensor junction\) \(C\):\s*([0-9.]+)"),
+                             ("memory_C", r"Temperature \(Sensor (?:memory|HBM \d)\) \(C\):\s*([0-9.]+)")):
+                m = re.search(pat, txt)
+                if m:
+                    gpu_state[key] = float(m.group(1))
             gpu_state["note"] = "rocm-smi while an untimed burst of the same launches runs, right after the timed region"
+            # what this GPU's memory system gives a plain copy (1 GiB read + 1 GiB written per copy): a reference for
+            # the box, next to which the kernel's rate can be read (GPUs of this pool differ by 10 % here as well)
+            dev_ = torch.device("cuda", local_rank)
+            a_ = torch.empty(1 << 30, dtype=torch.uint8, device=dev_)
+            b_ = torch.empty_like(a_)
+            e0_, e1_ = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            for _ in range(3):
+                b_.copy_(a_)
+            e0_.record()
+            for _ in range(10):
+                b_.copy_(a_)
+            e1_.record()
+            e1_.synchronize()
+            gpu_state["copy_1GiB_GBps_read_plus_write"] = round(10 * 2 * (1 << 30) / (e0_.elapsed_time(e1_) * 1e-3) / 1e9, 0)
+            del a_, b_
         except Exception as e:                                   # sensors are evidence, not a dependency
             gpu_state = {"error": str(e)[:200]}
             sync_all()

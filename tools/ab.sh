@@ -2,7 +2,8 @@
 # A/B of compile-time variants of the product library on the GPU box: for every EXTRA flag set rebuilds
 # libvpcc_recon.so, runs bench.py (timing, output verified against the oracle) and one counter pass for
 # the exact memory-side read/write bytes of the tile kernel.  The default build is restored at the end.
-# Usage: tools/ab.sh <outdir> "<flags A>" "<flags B>" ...      ("" = default build)
+# Usage: tools/ab.sh <outdir> "<flags A>" "<flags B>" ...      ("" = default build; "env:A=1 B=2" = default build run
+# with these environment variables, e.g. the VPCC_BENCH_* workload diagnostics of bench.py)
 out=$1; shift
 mkdir -p "$out"; out=$(cd "$out" && pwd)
 R=$GRAFT_REPO_ROOT
@@ -10,11 +11,13 @@ export PATH=/opt/rocm/bin:$PATH
 i=0
 for flags in "$@"; do
   i=$((i+1))
+  label=$flags; envs=""
+  case "$flags" in env:*) envs="${flags#env:}"; flags="";; esac
   (cd "$R" && make -j8 product EXTRA="$flags" > "$out/build_$i.log" 2>&1) || { echo "[$i] build failed: $flags"; tail -5 "$out/build_$i.log"; continue; }
-  (cd "$R" && python3 bench.py --steps 200 --no-cpu-baseline --no-end-to-end --no-other-configs --no-compare $BENCH_ARGS > "$out/bench_$i.json" 2> "$out/bench_$i.err") || { echo "[$i] bench failed: $flags"; tail -3 "$out/bench_$i.err"; continue; }
-  (cd /tmp && TMPDIR=/tmp rocprofv3 --kernel-trace --pmc TCC_EA0_RDREQ_128B_sum TCC_EA0_RDREQ_64B_sum TCC_EA0_WRREQ_sum TCC_EA0_WRREQ_64B_sum \
+  (cd "$R" && export $envs BENCH_AB=1 && python3 bench.py --steps 200 --no-cpu-baseline --no-end-to-end --no-other-configs --no-compare $BENCH_ARGS > "$out/bench_$i.json" 2> "$out/bench_$i.err") || { echo "[$i] bench failed: $flags"; tail -3 "$out/bench_$i.err"; continue; }
+  (cd /tmp && export $envs BENCH_AB=1 && TMPDIR=/tmp rocprofv3 --kernel-trace --pmc TCC_EA0_RDREQ_128B_sum TCC_EA0_RDREQ_64B_sum TCC_EA0_WRREQ_sum TCC_EA0_WRREQ_64B_sum \
      --output-format csv -d "$out/pmc_$i" -- python3 "$R/bench.py" --steps 3 --warmup 1 --ramp-ms 0 --min-seconds 0 --no-cpu-baseline --no-verify --no-end-to-end --no-other-configs --no-gpu-state --no-compare $BENCH_ARGS > "$out/pmc_$i.log" 2>&1) || echo "[$i] pmc failed"
-  python3 - "$out" "$i" "$flags" <<'PY'
+  python3 - "$out" "$i" "$label" <<'PY'
 import csv, glob, json, sys, collections
 out, i, flags = sys.argv[1], sys.argv[2], sys.argv[3]
 b = json.load(open(f"{out}/bench_{i}.json"))
