@@ -220,7 +220,7 @@ void vpcc_gof_destroy(vpcc_gof* gof);
                                            With this flag the first whole-gof vpcc_gof_reconstruct measures the kernel
                                            on candidate allocations of each block (up to VPCC_PLACEMENT_CANDIDATES,
                                            default 16, alive together; no new one once VPCC_PLACEMENT_BUDGET_MS,
-                                           default 250, have passed), keeps the fastest and frees the rest.  The blocks move during that call:
+                                           default 300, have passed), keeps the fastest and frees the rest.  The blocks move during that call:
                                            vpcc_gof_device_outputs before it pins them where they are (no measurement).
                                            Not for a gof launched once (the streaming Decoder does not set it).   */
 

@@ -343,9 +343,13 @@ int place_blocks(vpcc_gof* g, uint32_t max_groups, hipStream_t s) {
     const int v = e ? atoi(e) : 16;
     return v < 1 ? 1 : v > 32 ? 32 : v;
   }();
+  static const float flat_ratio = [] {                // (diagnostic: 9 makes every round look flat)
+    const char* e = getenv("VPCC_PLACEMENT_FLAT");
+    return e ? (float)atof(e) : 1.04f;
+  }();
   static const double budget_ms = [] {                 // no new candidate once the measurement has taken this long
     const char* e = getenv("VPCC_PLACEMENT_BUDGET_MS");
-    return e ? atof(e) : 250.0;
+    return e ? atof(e) : 300.0;
   }();
   vpcc_ctx::Placement& M = g->mem;
   if (M.score > 0.f) { M.info.tuned = 2; return VPCC_OK; }                     // a pair measured by an earlier gof
@@ -378,17 +382,39 @@ int place_blocks(vpcc_gof* g, uint32_t max_groups, hipStream_t s) {
   auto spent_ms = [&] { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count(); };
   // One round over a block: the current allocation, then fresh ones (all alive until the round ends, so that each lies
   // somewhere else) while the budget lasts; *moved tells whether another one than the current won.
-  auto round = [&](void** block, size_t bytes, bool copy, const char* what, float* best_ms, bool* moved) -> int {
+  auto round = [&](void** block, size_t bytes, bool copy, bool skip_ahead, const char* what, float* best_ms, bool* moved) -> int {
     size_t free_b = 0, total_b = 0;
     (void)hipMemGetInfo(&free_b, &total_b);
-    std::vector<void*> cand{*block};
+    std::vector<void*> cand{*block}, spacers;
     std::vector<float> ms;
-    size_t best = 0;
-    for (size_t c = 0; c < (size_t)wanted; ++c) {
+    size_t best = 0, worst = 0, limit = (size_t)wanted, held = 0;
+    int skips = 0;
+    for (size_t c = 0;; ++c) {
+      if (c == limit) {
+        // Every candidate within 4 % of the others: a stretch of memory that is all alike (on some GPUs of the pool the
+        // first 40 GB are, and slow).  Look further away, twice at most: 16 GB of allocations nobody uses (of the
+        // block's own size: hipMalloc hands those out in about a millisecond each, while 2-GiB and larger round sizes
+        // took 100 ms and more), then eight more candidates.
+        const bool flat = ms[worst] < flat_ratio * ms[best];
+        if (!skip_ahead || !flat || skips == 2 || spent_ms() > budget_ms) break;
+        for (size_t skipped = 0; skipped < (size_t(16) << 30) && held + bytes + (c + 1) * bytes <= free_b / 2 &&
+                                 spent_ms() < budget_ms; skipped += bytes) {
+          void* sp = nullptr;
+          const double t_a = spent_ms();
+          if (hipMalloc(&sp, bytes) != hipSuccess) { (void)hipGetLastError(); break; }
+          if (trace && spent_ms() - t_a > 10.0) fprintf(stderr, "[vpcc] placement: hipMalloc of %zu MB took %.0f ms (%zu MB held)\n", bytes >> 20, spent_ms() - t_a, (held + (c + 1) * bytes) >> 20);
+          spacers.push_back(sp);
+          held += bytes;
+        }
+        ++skips;
+        limit += 8;
+      }
       if (c) {
-        if ((c >= 2 && spent_ms() > budget_ms) || (c + 1) * bytes > free_b / 2) break;    // half of what is free, at most
+        if ((c >= 2 && spent_ms() > budget_ms) || held + (c + 1) * bytes > free_b / 2) break;    // half of what is free, at most
         void* p = nullptr;
+        const double t_a = spent_ms();
         if (hipMalloc(&p, bytes) != hipSuccess) { (void)hipGetLastError(); break; }
+        if (trace && spent_ms() - t_a > 10.0) fprintf(stderr, "[vpcc] placement: hipMalloc of %zu MB took %.0f ms (%zu MB held)\n", bytes >> 20, spent_ms() - t_a, (held + (c + 1) * bytes) >> 20);
         cand.push_back(p);
         if (copy) HIP_TRY(ctx, hipMemcpyAsync(p, cand[0], bytes, hipMemcpyDeviceToDevice, s));
         rebase_frames(g, cand[c - 1], bytes, p);
@@ -397,7 +423,9 @@ int place_blocks(vpcc_gof* g, uint32_t max_groups, hipStream_t s) {
       const int st = measure(&ms[c]);
       if (st) return st;
       if (ms[c] < ms[best]) best = c;
+      if (ms[c] > ms[worst]) worst = c;
     }
+    for (void* sp : spacers) (void)hipFree(sp);
     rebase_frames(g, cand.back(), bytes, cand[best]);
     HIP_TRY(ctx, hipMemcpyAsync(g->d_frames, g->h_frames.data(), sizeof(DevFrame) * nf, hipMemcpyHostToDevice, s));
     HIP_TRY(ctx, hipStreamSynchronize(s));
@@ -417,10 +445,10 @@ int place_blocks(vpcc_gof* g, uint32_t max_groups, hipStream_t s) {
   };
   float ms = 0.f;
   bool moved = false;
-  int st = round(&M.out, M.out_bytes, false, "output", &ms, &moved);
+  int st = round(&M.out, M.out_bytes, false, true, "output", &ms, &moved);
   if (!st && M.planes) {
-    st = round(&M.planes, M.planes_bytes, true, "planes", &ms, &moved);
-    if (!st && moved && spent_ms() < budget_ms) st = round(&M.out, M.out_bytes, false, "output", &ms, &moved);
+    st = round(&M.planes, M.planes_bytes, true, true, "planes", &ms, &moved);
+    if (!st && moved && spent_ms() < budget_ms) st = round(&M.out, M.out_bytes, false, false, "output", &ms, &moved);
   }
   (void)hipEventDestroy(a);
   (void)hipEventDestroy(b);
