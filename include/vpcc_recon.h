@@ -213,20 +213,23 @@ void vpcc_gof_destroy(vpcc_gof* gof);
                                            (vpcc_host_pin) and stay valid until the first vpcc_gof_sync /
                                            vpcc_gof_point_counts / vpcc_gof_download of this gof.          */
 
-#define VPCC_GOF_TUNE_PLACEMENT   0x10u /* for a gof that will be launched many times (a resident batch).  How fast
-                                           the memory system takes the tile kernel's streams depends on where in VRAM
-                                           the gof's two big blocks lie — its ingested planes and its output arrays —
-                                           by about 10 % of the kernel's time, and nothing but the kernel predicts it.
-                                           With this flag the first whole-gof vpcc_gof_reconstruct measures the kernel
-                                           on candidate allocations of each block (up to VPCC_PLACEMENT_CANDIDATES,
-                                           default 16, alive together; no new one once VPCC_PLACEMENT_BUDGET_MS,
-                                           default 300, have passed), keeps the fastest and frees the rest.  The blocks move during that call:
+#define VPCC_GOF_TUNE_PLACEMENT   0x10u /* for a gof that will be launched many times (a resident batch).  VRAM consists
+                                           of kinds of regions (tens of GB each), and the memory system is fastest when
+                                           a launch's traffic is spread evenly over them: the same launch takes 0.45 ms
+                                           or 0.52 ms depending on where the gof's big arrays lie (DESIGN.md 4.1,
+                                           "Placement").  Nothing tells the kinds apart but a measurement.  With this
+                                           flag the gof keeps its ingested planes and its output arrays in two parts each
+                                           (by frame), and the first whole-gof vpcc_gof_reconstruct measures the kernel on
+                                           candidate allocations of every part (up to VPCC_PLACEMENT_CANDIDATES, default
+                                           16, per block size; no new ones once VPCC_PLACEMENT_BUDGET_MS, default 500,
+                                           have passed), keeps the fastest and frees the rest: 0.2-0.5 s once, up to
+                                           ~30 GB of transient allocations.  The blocks move during that call:
                                            vpcc_gof_device_outputs before it pins them where they are (no measurement).
                                            Not for a gof launched once (the streaming Decoder does not set it).   */
 
 /* What VPCC_GOF_TUNE_PLACEMENT did for this gof (all zero when it did not run). */
 typedef struct vpcc_placement_info {
-  uint32_t tuned;            /* 1: the measurement ran for this gof, 2: the gof reuses a measured pair of blocks */
+  uint32_t tuned;            /* 1: the measurement ran for this gof, 2: the gof reuses a measured set of blocks  */
   uint32_t candidates;       /* placements measured                                                            */
   float    ms_as_allocated;  /* per launch with the blocks as hipMalloc returned them                          */
   float    ms_kept;          /* per launch with the blocks kept                                                */

@@ -212,24 +212,27 @@ def test_ticket_counters_survive_skipped_launches(ctx):
 
 def test_tuned_placement_moves_blocks_not_results(ctx):
     """VPCC_GOF_TUNE_PLACEMENT: the first whole-gof launch measures the kernel on candidate allocations of the planes
-    block and the output block and keeps the fastest pair; the results are those of an untuned gof and of the oracle,
+    blocks and the output blocks (two parts each, by frame) and keeps the fastest set; the results are those of an untuned gof and of the oracle,
     partial launches before it do not trigger it, and a later gof of the same shape reuses the measured pair."""
-    frames = [synth.longdress_frame(i) for i in range(6)]
-    refs = [ob.reconstruct(f)[1] for f in frames]
+    distinct = [synth.longdress_frame(i) for i in range(5)]
+    refs5 = [ob.reconstruct(f)[1] for f in distinct]
+    n = 20                                                        # frames 0-7 and 16-19: part 0, frames 8-15: part 1
+    frames = [distinct[i % 5] for i in range(n)]
+    refs = [refs5[i % 5] for i in range(n)]
     flags = _abi.VPCC_GOF_WANT_PATCH_INDEX | _abi.VPCC_GOF_TUNE_PLACEMENT
     g = ctx.gof(frames, capacity=1_000_000, flags=flags)
-    g.reconstruct(first=0, count=3)
+    g.reconstruct(first=6, count=5)
     assert g.placement()["tuned"] == 0
-    for i in range(3):
+    for i in range(6, 11):
         _check(g.download(i, want_patch_index=True), refs[i])
     g.reconstruct()
     p = g.placement()
-    assert p["tuned"] == 1 and p["candidates"] >= 2 and 0 < p["ms_kept"] <= 1.05 * p["ms_as_allocated"], p
-    for i in range(6):
+    assert p["tuned"] == 1 and p["candidates"] >= 4 and 0 < p["ms_kept"] <= 1.05 * p["ms_as_allocated"], p
+    for i in range(n):
         _check(g.download(i, want_patch_index=True), refs[i])
-    g.reconstruct(first=2, count=3)
+    g.reconstruct(first=7, count=3)
     g.reconstruct()
-    for i in range(6):
+    for i in (0, 7, 8, 15, 16, 19):
         _check(g.download(i, want_patch_index=True), refs[i])
     g.smooth(10, grid_size=8, threshold=4)                      # the filters follow the blocks
     g.sync()
@@ -237,7 +240,7 @@ def test_tuned_placement_moves_blocks_not_results(ctx):
     g = ctx.gof(frames, capacity=1_000_000, flags=flags)           # the pair kept by the context
     g.reconstruct()
     assert g.placement()["tuned"] == 2
-    for i in (0, 5):
+    for i in (0, 9, 19):
         _check(g.download(i, want_patch_index=True), refs[i])
     g.close()
 

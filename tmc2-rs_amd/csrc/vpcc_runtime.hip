@@ -34,13 +34,18 @@ struct vpcc_ctx {
   // Arenas of destroyed GOFs are kept for the next GOF of the same shape: hipMalloc/hipFree cost
   // milliseconds and hipFree synchronises the whole device, which would stall a GOF pipeline.
   std::vector<std::pair<void*, size_t>> arena_cache;
-  // The two big blocks of a gof — the video planes it ingested and its output arrays — are allocations of their own,
-  // chosen by measurement (place_blocks below); the pairs of destroyed gofs are kept with their score.
+  // The big blocks of a gof — the video planes it ingested and its output arrays, each in kParts parts by frame —
+  // are allocations of their own, chosen by measurement (place_blocks below); the sets of destroyed gofs are kept with
+  // their score.
+  static constexpr int kParts = 2;
+  struct Block { void* ptr = nullptr; size_t bytes = 0; };
   struct Placement {
-    void* planes = nullptr; size_t planes_bytes = 0;     // ingested planes (VPCC_MEM_HOST gofs only)
-    void* out = nullptr; size_t out_bytes = 0;           // positions, colours, partition of all frames
-    float score = 0.f;                                   // 1 / ms of the launch that chose the pair (0 = never measured)
+    Block block[2 * kParts];                             // [2 * part]: ingested planes (VPCC_MEM_HOST gofs only),
+                                                         // [2 * part + 1]: positions, colours, partition
+    float score = 0.f;                                   // 1 / ms of the launch that chose the set (0 = never measured)
     vpcc_placement_info info{};
+    bool any() const { for (const Block& b : block) if (b.ptr) return true; return false; }
+    void release() { for (Block& b : block) { if (b.ptr) (void)hipFree(b.ptr); b = Block{}; } }
   };
   std::vector<Placement> placement_cache;
 };
@@ -68,7 +73,7 @@ struct vpcc_gof {
   std::vector<DevFrame> h_frames;      // host mirror of d_frames
   void* arena = nullptr;
   size_t arena_bytes = 0;
-  vpcc_ctx::Placement mem;             // the planes block and the output block
+  vpcc_ctx::Placement mem;             // the planes blocks and the output blocks
   bool placed = false;                 // the blocks are final (place_blocks ran, or the caller holds pointers into them)
   DevFrame* d_frames = nullptr;
   uint32_t* d_counts = nullptr;        // n_frames contiguous point counters
@@ -173,7 +178,7 @@ extern "C" void vpcc_ctx_destroy(vpcc_ctx* ctx) {
   if (!ctx) return;
   (void)hipSetDevice(ctx->device);
   for (auto& a : ctx->arena_cache) (void)hipFree(a.first);
-  for (auto& b : ctx->placement_cache) { (void)hipFree(b.planes); (void)hipFree(b.out); }
+  for (auto& b : ctx->placement_cache) b.release();
   if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
   if (ctx->copy_stream) (void)hipStreamDestroy(ctx->copy_stream);
   if (ctx->d2h_stream) (void)hipStreamDestroy(ctx->d2h_stream);
@@ -286,14 +291,13 @@ extern "C" void vpcc_gof_destroy(vpcc_gof* gof) {
     if (cache.size() < 4) cache.emplace_back(gof->arena, gof->arena_bytes);
     else (void)hipFree(gof->arena);
   }
-  if (gof->mem.out) {
-    auto& cache = gof->ctx->placement_cache;                     // at most four pairs: the slowest (unmeasured first,
+  if (gof->mem.any()) {
+    auto& cache = gof->ctx->placement_cache;                     // at most four sets: the slowest (unmeasured first,
     cache.push_back(gof->mem);                                    // oldest among equals) goes
     if (cache.size() > 4) {
       size_t worst = 0;
       for (size_t k = 1; k < cache.size(); ++k) if (cache[k].score < cache[worst].score) worst = k;
-      (void)hipFree(cache[worst].planes);
-      (void)hipFree(cache[worst].out);
+      cache[worst].release();
       cache.erase(cache.begin() + worst);
     }
   }
@@ -349,11 +353,13 @@ int place_blocks(vpcc_gof* g, uint32_t max_groups, hipStream_t s) {
   }();
   static const double budget_ms = [] {                 // no new candidate once the measurement has taken this long
     const char* e = getenv("VPCC_PLACEMENT_BUDGET_MS");
-    return e ? atof(e) : 300.0;
+    return e ? atof(e) : 500.0;
   }();
   vpcc_ctx::Placement& M = g->mem;
-  if (M.score > 0.f) { M.info.tuned = 2; return VPCC_OK; }                     // a pair measured by an earlier gof
-  if (wanted <= 1 || M.out_bytes < (size_t(32) << 20)) return VPCC_OK;          // too small to matter
+  if (M.score > 0.f) { M.info.tuned = 2; return VPCC_OK; }                     // a set measured by an earlier gof
+  size_t total_bytes = 0;
+  for (const vpcc_ctx::Block& B : M.block) total_bytes += B.bytes;
+  if (wanted <= 1 || total_bytes < (size_t(64) << 20)) return VPCC_OK;          // too small to matter
   const bool trace = getenv("VPCC_RUNTIME_TRACE") != nullptr;
   const uint32_t nf = g->n_frames;
   hipEvent_t a, b;
@@ -380,76 +386,105 @@ int place_blocks(vpcc_gof* g, uint32_t max_groups, hipStream_t s) {
   };
   const auto t0 = std::chrono::steady_clock::now();
   auto spent_ms = [&] { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count(); };
-  // One round over a block: the current allocation, then fresh ones (all alive until the round ends, so that each lies
-  // somewhere else) while the budget lasts; *moved tells whether another one than the current won.
+  // Candidate allocations are kept in a pool per block size for the whole measurement and given back at its end
+  // (parts of a kind are equally big and share their candidates): VRAM that is freed gets wiped by the driver before
+  // it is handed out again, at about 40 GB/s, and whoever allocates next waits for it — a first version that took fresh
+  // candidates for every round freed 140 GB and made a later 0.5-GB hipMalloc take 3.6 s.
+  struct Pool { size_t bytes; std::vector<void*> blocks; int skips = 0; };
+  std::vector<Pool> pools;
+  std::vector<void*> spacers;
+  size_t held = 0;
+  size_t free_b = 0, total_b = 0;
+  (void)hipMemGetInfo(&free_b, &total_b);
+  auto grow = [&](Pool& P, size_t n) {                          // up to n more blocks, while budget and memory last
+    for (size_t k = 0; k < n; ++k) {
+      if ((!P.blocks.empty() && spent_ms() > budget_ms) || held + P.bytes > free_b / 2) return;
+      void* p = nullptr;
+      const double t_a = spent_ms();
+      if (hipMalloc(&p, P.bytes) != hipSuccess) { (void)hipGetLastError(); return; }
+      if (trace && spent_ms() - t_a > 10.0) fprintf(stderr, "[vpcc] placement: hipMalloc of %zu MB took %.0f ms (%zu MB held)\n", P.bytes >> 20, spent_ms() - t_a, held >> 20);
+      P.blocks.push_back(p);
+      held += P.bytes;
+    }
+  };
+  // One round over a block: its current allocation against the pool's (the pool is filled up to wanted - 1 first);
+  // the loser goes (back) into the pool.
   auto round = [&](void** block, size_t bytes, bool copy, bool skip_ahead, const char* what, float* best_ms, bool* moved) -> int {
-    size_t free_b = 0, total_b = 0;
-    (void)hipMemGetInfo(&free_b, &total_b);
-    std::vector<void*> cand{*block}, spacers;
+    size_t pi = 0;
+    while (pi < pools.size() && pools[pi].bytes != bytes) ++pi;
+    if (pi == pools.size()) pools.push_back(Pool{bytes, {}});
+    Pool& P = pools[pi];
+    if (P.blocks.size() + 1 < (size_t)wanted) grow(P, (size_t)wanted - 1 - P.blocks.size());
     std::vector<float> ms;
-    size_t best = 0, worst = 0, limit = (size_t)wanted, held = 0;
-    int skips = 0;
+    size_t best = 0, worst = 0;
+    void* cur = *block;                                            // where the descriptors point
     for (size_t c = 0;; ++c) {
-      if (c == limit) {
+      if (c == P.blocks.size() + 1) {
         // Every candidate within 4 % of the others: a stretch of memory that is all alike (on some GPUs of the pool the
-        // first 40 GB are, and slow).  Look further away, twice at most: 16 GB of allocations nobody uses (of the
-        // block's own size: hipMalloc hands those out in about a millisecond each, while 2-GiB and larger round sizes
-        // took 100 ms and more), then eight more candidates.
+        // first 40 GB are, and slow).  Look further away, twice at most per block size: 16 GB of allocations nobody
+        // uses (of the block's own size: hipMalloc hands those out in about a millisecond each, while 2-GiB and larger
+        // round sizes took 100 ms and more), then eight more candidates.
         const bool flat = ms[worst] < flat_ratio * ms[best];
-        if (!skip_ahead || !flat || skips == 2 || spent_ms() > budget_ms) break;
-        for (size_t skipped = 0; skipped < (size_t(16) << 30) && held + bytes + (c + 1) * bytes <= free_b / 2 &&
-                                 spent_ms() < budget_ms; skipped += bytes) {
+        if (!skip_ahead || !flat || P.skips == 2 || spent_ms() > budget_ms) break;
+        for (size_t skipped = 0; skipped < (size_t(16) << 30) && held + bytes <= free_b / 2 && spent_ms() < budget_ms; skipped += bytes) {
           void* sp = nullptr;
-          const double t_a = spent_ms();
           if (hipMalloc(&sp, bytes) != hipSuccess) { (void)hipGetLastError(); break; }
-          if (trace && spent_ms() - t_a > 10.0) fprintf(stderr, "[vpcc] placement: hipMalloc of %zu MB took %.0f ms (%zu MB held)\n", bytes >> 20, spent_ms() - t_a, (held + (c + 1) * bytes) >> 20);
           spacers.push_back(sp);
           held += bytes;
         }
-        ++skips;
-        limit += 8;
+        ++P.skips;
+        const size_t before = P.blocks.size();
+        grow(P, 8);
+        if (P.blocks.size() == before) break;
       }
-      if (c) {
-        if ((c >= 2 && spent_ms() > budget_ms) || held + (c + 1) * bytes > free_b / 2) break;    // half of what is free, at most
-        void* p = nullptr;
-        const double t_a = spent_ms();
-        if (hipMalloc(&p, bytes) != hipSuccess) { (void)hipGetLastError(); break; }
-        if (trace && spent_ms() - t_a > 10.0) fprintf(stderr, "[vpcc] placement: hipMalloc of %zu MB took %.0f ms (%zu MB held)\n", bytes >> 20, spent_ms() - t_a, (held + (c + 1) * bytes) >> 20);
-        cand.push_back(p);
-        if (copy) HIP_TRY(ctx, hipMemcpyAsync(p, cand[0], bytes, hipMemcpyDeviceToDevice, s));
-        rebase_frames(g, cand[c - 1], bytes, p);
-      }
+      void* to = c ? P.blocks[c - 1] : *block;
+      if (c && copy) HIP_TRY(ctx, hipMemcpyAsync(to, *block, bytes, hipMemcpyDeviceToDevice, s));
+      rebase_frames(g, cur, bytes, to);
+      cur = to;
       ms.push_back(0.f);
       const int st = measure(&ms[c]);
       if (st) return st;
       if (ms[c] < ms[best]) best = c;
       if (ms[c] > ms[worst]) worst = c;
     }
-    for (void* sp : spacers) (void)hipFree(sp);
-    rebase_frames(g, cand.back(), bytes, cand[best]);
+    void* keep = best ? P.blocks[best - 1] : *block;
+    rebase_frames(g, cur, bytes, keep);
     HIP_TRY(ctx, hipMemcpyAsync(g->d_frames, g->h_frames.data(), sizeof(DevFrame) * nf, hipMemcpyHostToDevice, s));
     HIP_TRY(ctx, hipStreamSynchronize(s));
-    for (size_t c = 0; c < cand.size(); ++c) if (c != best) (void)hipFree(cand[c]);
-    *block = cand[best];
+    if (best) { P.blocks[best - 1] = *block; *block = keep; }      // the old place becomes a candidate
     *best_ms = ms[best];
     if (M.info.candidates == 0) M.info.ms_as_allocated = ms[0];
-    M.info.candidates += (uint32_t)cand.size();
+    M.info.candidates += (uint32_t)ms.size();
     *moved = best != 0;
     if (trace) {
       std::string all;
       for (float t : ms) { char buf[32]; snprintf(buf, sizeof buf, " %.3f", t); all += buf; }
-      fprintf(stderr, "[vpcc] placement, %s block %zu MB, %u frames: ms per launch by candidate%s -> kept %zu (%.0f ms so far)\n",
+      fprintf(stderr, "[vpcc] placement, %s (%zu MB; %u frames in the launch): ms per launch by candidate%s -> kept %zu (%.0f ms so far)\n",
               what, bytes >> 20, nf, all.c_str(), best, spent_ms());
     }
     return VPCC_OK;
   };
+  // Coordinate descent over the blocks: the output and the planes of part 0, of part 1, ...; then once more over
+  // all of them (without looking further away) if the first sweep moved anything and the budget lasts.
+  static const char* const names[2] = {"planes", "output"};
   float ms = 0.f;
-  bool moved = false;
-  int st = round(&M.out, M.out_bytes, false, true, "output", &ms, &moved);
-  if (!st && M.planes) {
-    st = round(&M.planes, M.planes_bytes, true, true, "planes", &ms, &moved);
-    if (!st && moved && spent_ms() < budget_ms) st = round(&M.out, M.out_bytes, false, false, "output", &ms, &moved);
+  int st = VPCC_OK;
+  bool moved_any = false;
+  for (int sweep = 0; sweep < 2 && !st; ++sweep) {
+    if (sweep && (!moved_any || spent_ms() > budget_ms)) break;
+    for (int part = 0; part < vpcc_ctx::kParts && !st; ++part)
+      for (int kind = 1; kind >= 0 && !st; --kind) {
+        vpcc_ctx::Block& B = M.block[2 * part + kind];
+        if (!B.ptr || B.bytes < (size_t(16) << 20) || (sweep && spent_ms() > budget_ms)) continue;
+        bool moved = false;
+        char what[32];
+        snprintf(what, sizeof what, "%s %d", names[kind], part);
+        st = round(&B.ptr, B.bytes, kind == 0, sweep == 0, what, &ms, &moved);
+        moved_any = moved_any || moved;
+      }
   }
+  for (Pool& P : pools) for (void* q : P.blocks) (void)hipFree(q);
+  for (void* q : spacers) (void)hipFree(q);
   (void)hipEventDestroy(a);
   (void)hipEventDestroy(b);
   if (st) return st;
@@ -516,7 +551,24 @@ int gof_create_impl(vpcc_ctx* ctx, const vpcc_frame_desc* frames, uint32_t n_fra
   }
   g->b2p_words = (L.total - b2p_begin) / sizeof(uint32_t);
   L.total = align_up(L.total, 256);
-  ArenaLayout LO, LP;                                           // the output block's and the planes block's own layouts
+  // The big blocks' own layouts: [2 * part] planes, [2 * part + 1] outputs.  A gof that tunes its placement splits both
+  // in kParts parts by frame — eight frames (one per XCD) to part 0, the next eight to part 1, and so on — so that
+  // the parts can lie in different places: the memory system is fastest when a launch's traffic is spread evenly over
+  // the kinds of regions VRAM consists of (DESIGN.md §4.1 "Placement").
+  ArenaLayout LB[2 * vpcc_ctx::kParts];
+  const bool split = (gof_flags & VPCC_GOF_TUNE_PLACEMENT) != 0;
+  auto part_of = [&](uint32_t i) { return split ? (int)((i >> 3) % vpcc_ctx::kParts) : 0; };
+  // Diagnostic layout (tools/exp_slab.py, exp_slab2.py): VPCC_DIAG_SLAB="geo,attr,xyz,rgb" puts the four kinds of
+  // arrays at these offsets (GB) of ONE allocation of VPCC_DIAG_SLAB_GB GB.
+  ArenaLayout LX[4];
+  double slab_off[4] = {0, 0, 0, 0};
+  const char* slab_env = getenv("VPCC_DIAG_SLAB");
+  const bool slab = !split && slab_env && sscanf(slab_env, "%lf,%lf,%lf,%lf", &slab_off[0], &slab_off[1], &slab_off[2], &slab_off[3]) == 4;
+  auto slab_at = [&](int k) { return (size_t)(slab_off[k] * (double)(size_t(1) << 30)) & ~size_t(4095); };
+  // kind 0 planes / 1 outputs; sub 0 geometry + occupancy or positions + partition / 1 attributes or colours
+  auto takek = [&](uint32_t i, int kind, int sub, size_t bytes) {
+    return slab ? LX[2 * kind + sub].take(bytes) : LB[2 * part_of(i) + kind].take(bytes);
+  };
   for (uint32_t i = 0; i < n_frames; ++i) {
     const vpcc_frame_desc& F = frames[i];
     const FramePlan& P = g->plans[i];
@@ -526,17 +578,17 @@ int gof_create_impl(vpcc_ctx* ctx, const vpcc_frame_desc* frames, uint32_t n_fra
     o.items = L.take(sizeof(TileItem) * (((P.tiles.size() + kTileItemsPerGroup - 1) / kTileItemsPerGroup) * kTileItemsPerGroup + kTileItemsPerGroup));
     o.vb_count = L.take(sizeof(uint32_t) * std::max<size_t>(P.vblocks.size(), 1));
     o.vb_offset = L.take(sizeof(uint32_t) * std::max<size_t>(P.vblocks.size(), 1));
-    o.xyz = LO.take(sizeof(vpcc_point3) * cap);                    // (output block: positions, colours, partition in
-    o.rgb = F.attribute_count ? LO.take(sizeof(vpcc_color3) * cap) : 0;   //  this order — the smoothing kernels' 8-byte loads
-    o.pidx = (gof_flags & VPCC_GOF_WANT_PATCH_INDEX) ? LO.take(sizeof(uint16_t) * cap) : 0;   // read a few bytes past an element)
+    o.xyz = takek(i, 1, 0, sizeof(vpcc_point3) * cap);                    // (output block: positions, colours, partition in
+    o.rgb = F.attribute_count ? takek(i, 1, 1, sizeof(vpcc_color3) * cap) : 0;   //  this order — the smoothing kernels' 8-byte loads
+    o.pidx = (gof_flags & VPCC_GOF_WANT_PATCH_INDEX) ? takek(i, 1, 0, sizeof(uint16_t) * cap) : 0;   // read a few bytes past an element)
     if (kind == VPCC_MEM_HOST) {
-      o.occ = LP.take((size_t)F.occupancy.width * F.occupancy.height);
+      o.occ = takek(i, 0, 0, (size_t)F.occupancy.width * F.occupancy.height);
       for (uint32_t m = 0; m < F.map_count; ++m) {
-        o.geo[m] = LP.take((size_t)F.geometry[m].width * F.geometry[m].height * 2);
+        o.geo[m] = takek(i, 0, 0, (size_t)F.geometry[m].width * F.geometry[m].height * 2);
         if (F.attribute_count) {
-          o.ay[m] = LP.take((size_t)F.attribute[m].width * F.attribute[m].height * 2);
-          o.au[m] = LP.take(chroma_elems(F.attribute[m]) * 2);
-          o.av[m] = LP.take(chroma_elems(F.attribute[m]) * 2);
+          o.ay[m] = takek(i, 0, 1, (size_t)F.attribute[m].width * F.attribute[m].height * 2);
+          o.au[m] = takek(i, 0, 1, chroma_elems(F.attribute[m]) * 2);
+          o.av[m] = takek(i, 0, 1, chroma_elems(F.attribute[m]) * 2);
         }
       }
     }
@@ -552,30 +604,36 @@ int gof_create_impl(vpcc_ctx* ctx, const vpcc_frame_desc* frames, uint32_t n_fra
     }
   }
   if (!g->arena) HIP_TRY(ctx, hipMalloc(&g->arena, g->arena_bytes));
-  const size_t out_bytes = LO.total + 256, planes_bytes = LP.total ? LP.total + 256 : 0;
   {
-    auto fits = [](size_t have, size_t need) { return need ? have >= need && have <= need + need / 4 : have == 0; };
+    size_t need[2 * vpcc_ctx::kParts];
+    for (int k = 0; k < 2 * vpcc_ctx::kParts; ++k) need[k] = LB[k].total ? LB[k].total + 256 : 0;
+    if (slab) {                                                   // everything in "outputs, part 0"
+      for (int k = 0; k < 4; ++k) need[1] = std::max(need[1], slab_at(k) + LX[k].total + 4096);
+      if (getenv("VPCC_DIAG_SLAB_GB")) need[1] = std::max(need[1], (size_t)atoi(getenv("VPCC_DIAG_SLAB_GB")) << 30);
+    }
+    auto fits = [](size_t have, size_t want) { return want ? have >= want && have <= want + want / 4 : have == 0; };
     auto& cache = ctx->placement_cache;
     size_t pick = cache.size();
-    for (size_t k = 0; k < cache.size(); ++k)                     // a kept pair that fits, the fastest first
-      if (fits(cache[k].out_bytes, out_bytes) && fits(cache[k].planes_bytes, planes_bytes) &&
-          (pick == cache.size() || cache[k].score > cache[pick].score))
-        pick = k;
+    for (size_t k = 0; k < cache.size(); ++k) {                   // a kept set that fits, the fastest first
+      bool ok = true;
+      for (int j = 0; j < 2 * vpcc_ctx::kParts; ++j) ok = ok && fits(cache[k].block[j].bytes, need[j]);
+      if (ok && (pick == cache.size() || cache[k].score > cache[pick].score)) pick = k;
+    }
     if (pick < cache.size()) {
       g->mem = cache[pick];
       cache.erase(cache.begin() + pick);
     } else {
-      HIP_TRY(ctx, hipMalloc(&g->mem.out, out_bytes));
-      g->mem.out_bytes = out_bytes;
-      if (planes_bytes) {
-        HIP_TRY(ctx, hipMalloc(&g->mem.planes, planes_bytes));
-        g->mem.planes_bytes = planes_bytes;
-      }
+      for (int j = 0; j < 2 * vpcc_ctx::kParts; ++j)
+        if (need[j]) {
+          HIP_TRY(ctx, hipMalloc(&g->mem.block[j].ptr, need[j]));
+          g->mem.block[j].bytes = need[j];
+        }
     }
   }
   char* base = (char*)g->arena;
-  char* obase = (char*)g->mem.out;
-  char* pbase = (char*)g->mem.planes;
+  auto kb = [&](uint32_t i, int kind, int sub) {
+    return slab ? (char*)g->mem.block[1].ptr + slab_at(2 * kind + sub) : (char*)g->mem.block[2 * part_of(i) + kind].ptr;
+  };
   g->d_frames = (DevFrame*)(base + off_frames);
   g->d_counts = (uint32_t*)(base + off_counts);
   g->d_b2p = (uint32_t*)(base + b2p_begin);
@@ -599,9 +657,9 @@ int gof_create_impl(vpcc_ctx* ctx, const vpcc_frame_desc* frames, uint32_t n_fra
     D.block_to_patch = (uint32_t*)(base + o.b2p);
     D.vb_count = (uint32_t*)(base + o.vb_count);
     D.vb_offset = (uint32_t*)(base + o.vb_offset);
-    D.out_xyz = (vpcc_point3*)(obase + o.xyz);
-    D.out_rgb = F.attribute_count ? (vpcc_color3*)(obase + o.rgb) : nullptr;
-    D.out_patch = (gof_flags & VPCC_GOF_WANT_PATCH_INDEX) ? (uint16_t*)(obase + o.pidx) : nullptr;
+    D.out_xyz = (vpcc_point3*)(kb(i, 1, 0) + o.xyz);
+    D.out_rgb = F.attribute_count ? (vpcc_color3*)(kb(i, 1, 1) + o.rgb) : nullptr;
+    D.out_patch = (gof_flags & VPCC_GOF_WANT_PATCH_INDEX) ? (uint16_t*)(kb(i, 1, 0) + o.pidx) : nullptr;
     D.n_points = g->d_counts + i;
     D.tiles = (const TileItem*)(base + o.items);
     D.n_tiles = (uint32_t)P.tiles.size();
@@ -627,28 +685,28 @@ int gof_create_impl(vpcc_ctx* ctx, const vpcc_frame_desc* frames, uint32_t n_fra
         }
       }
     } else {
-      D.occ = (const uint8_t*)(pbase + o.occ); D.occ_stride = F.occupancy.width;
-      int st = copy_plane(ctx, pbase + o.occ, F.occupancy.y, 1, F.occupancy.width, F.occupancy.height,
+      D.occ = (const uint8_t*)(kb(i, 0, 0) + o.occ); D.occ_stride = F.occupancy.width;
+      int st = copy_plane(ctx, kb(i, 0, 0) + o.occ, F.occupancy.y, 1, F.occupancy.width, F.occupancy.height,
                           F.occupancy.stride, s);
       if (st) return st;
       for (uint32_t m = 0; m < F.map_count; ++m) {
         const vpcc_image_u16& G = F.geometry[m];
-        D.geo[m] = (const uint16_t*)(pbase + o.geo[m]); D.geo_stride[m] = G.width;
-        st = copy_plane(ctx, pbase + o.geo[m], G.y, 2, G.width, G.height, G.stride, s);
+        D.geo[m] = (const uint16_t*)(kb(i, 0, 0) + o.geo[m]); D.geo_stride[m] = G.width;
+        st = copy_plane(ctx, kb(i, 0, 0) + o.geo[m], G.y, 2, G.width, G.height, G.stride, s);
         if (st) return st;
         if (F.attribute_count) {
           const vpcc_image_u16& A = F.attribute[m];
-          D.attr_y[m] = (const uint16_t*)(pbase + o.ay[m]);
-          D.attr_u[m] = (const uint16_t*)(pbase + o.au[m]);
-          D.attr_v[m] = (const uint16_t*)(pbase + o.av[m]);
+          D.attr_y[m] = (const uint16_t*)(kb(i, 0, 1) + o.ay[m]);
+          D.attr_u[m] = (const uint16_t*)(kb(i, 0, 1) + o.au[m]);
+          D.attr_v[m] = (const uint16_t*)(kb(i, 0, 1) + o.av[m]);
           D.attr_stride[m] = A.width; D.attr_cstride[m] = A.cstride;
-          st = copy_plane(ctx, pbase + o.ay[m], A.y, 2, A.width, A.height, A.stride, s);
+          st = copy_plane(ctx, kb(i, 0, 1) + o.ay[m], A.y, 2, A.width, A.height, A.stride, s);
           if (st) return st;
           // chroma keeps its source stride: the reference indexes it as a flat array
           // (v/2)*(width/2)+(u/2), src/decoder.rs:977, which for odd widths runs across rows
           const size_t ce = chroma_elems(A);
-          HIP_TRY(ctx, hipMemcpyAsync(pbase + o.au[m], A.u, ce * 2, hipMemcpyHostToDevice, s));
-          HIP_TRY(ctx, hipMemcpyAsync(pbase + o.av[m], A.v, ce * 2, hipMemcpyHostToDevice, s));
+          HIP_TRY(ctx, hipMemcpyAsync(kb(i, 0, 1) + o.au[m], A.u, ce * 2, hipMemcpyHostToDevice, s));
+          HIP_TRY(ctx, hipMemcpyAsync(kb(i, 0, 1) + o.av[m], A.v, ce * 2, hipMemcpyHostToDevice, s));
         }
       }
     }
