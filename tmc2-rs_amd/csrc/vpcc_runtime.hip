@@ -479,7 +479,7 @@ int place_blocks(vpcc_gof* g, uint32_t max_groups, hipStream_t s) {
         bool moved = false;
         char what[32];
         snprintf(what, sizeof what, "%s %d", names[kind], part);
-        st = round(&B.ptr, B.bytes, kind == 0, sweep == 0, what, &ms, &moved);
+        st = round(&B.ptr, B.bytes, kind == 0, sweep == 0 && part == 0, what, &ms, &moved);   // (later rounds are flat when all is well)
         moved_any = moved_any || moved;
       }
   }
