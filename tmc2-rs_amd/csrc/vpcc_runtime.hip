@@ -353,7 +353,7 @@ int place_blocks(vpcc_gof* g, uint32_t max_groups, hipStream_t s) {
   }();
   static const double budget_ms = [] {                 // no new candidate once the measurement has taken this long
     const char* e = getenv("VPCC_PLACEMENT_BUDGET_MS");
-    return e ? atof(e) : 500.0;
+    return e ? atof(e) : 800.0;
   }();
   vpcc_ctx::Placement& M = g->mem;
   if (M.score > 0.f) { M.info.tuned = 2; return VPCC_OK; }                     // a set measured by an earlier gof
@@ -421,12 +421,14 @@ int place_blocks(vpcc_gof* g, uint32_t max_groups, hipStream_t s) {
     for (size_t c = 0;; ++c) {
       if (c == P.blocks.size() + 1) {
         // Every candidate within 4 % of the others: a stretch of memory that is all alike (on some GPUs of the pool the
-        // first 40 GB are, and slow).  Look further away, twice at most per block size: 16 GB of allocations nobody
-        // uses (of the block's own size: hipMalloc hands those out in about a millisecond each, while 2-GiB and larger
-        // round sizes took 100 ms and more), then eight more candidates.
+        // first 60 GB are, and slow).  Look further away, three times at most per block size: 16, 32, 48 GB of
+        // allocations nobody uses (of the block's own size: hipMalloc hands those out in about a millisecond each, while
+        // 2-GiB and larger round sizes took 100 ms and more; kept until the measurement ends, so that the pools of the
+        // blocks that follow start beyond them), then eight more candidates.
         const bool flat = ms[worst] < flat_ratio * ms[best];
-        if (!skip_ahead || !flat || P.skips == 2 || spent_ms() > budget_ms) break;
-        for (size_t skipped = 0; skipped < (size_t(16) << 30) && held + bytes <= free_b / 2 && spent_ms() < budget_ms; skipped += bytes) {
+        if (!skip_ahead || !flat || P.skips == 3 || spent_ms() > budget_ms) break;
+        const size_t distance = size_t(16 * (P.skips + 1)) << 30;                  // 16, 32, 48 GB
+        for (size_t skipped = 0; skipped < distance && held + bytes <= free_b / 2 && spent_ms() < budget_ms; skipped += bytes) {
           void* sp = nullptr;
           if (hipMalloc(&sp, bytes) != hipSuccess) { (void)hipGetLastError(); break; }
           spacers.push_back(sp);
