@@ -418,6 +418,16 @@ int place_blocks(vpcc_gof* g, uint32_t max_groups, hipStream_t s) {
     std::vector<float> ms;
     size_t best = 0, worst = 0;
     void* cur = *block;                                            // where the descriptors point
+    // on an error the descriptors go back to the block's own allocation (the candidates are freed at the end)
+    auto bail = [&](int status) {
+      rebase_frames(g, cur, bytes, *block);
+      (void)hipMemcpyAsync(g->d_frames, g->h_frames.data(), sizeof(DevFrame) * nf, hipMemcpyHostToDevice, s);
+      (void)hipStreamSynchronize(s);
+      return status;
+    };
+    auto hip_failed = [&](hipError_t e, const char* what_failed) {
+      return bail(fail(ctx, VPCC_ERR_DEVICE, std::string(what_failed) + ": " + hipGetErrorString(e)));
+    };
     for (size_t c = 0;; ++c) {
       if (c == P.blocks.size() + 1) {
         // Every candidate within 4 % of the others: a stretch of memory that is all alike (on some GPUs of the pool the
@@ -440,19 +450,24 @@ int place_blocks(vpcc_gof* g, uint32_t max_groups, hipStream_t s) {
         if (P.blocks.size() == before) break;
       }
       void* to = c ? P.blocks[c - 1] : *block;
-      if (c && copy) HIP_TRY(ctx, hipMemcpyAsync(to, *block, bytes, hipMemcpyDeviceToDevice, s));
+      if (c && copy) {
+        const hipError_t e = hipMemcpyAsync(to, *block, bytes, hipMemcpyDeviceToDevice, s);
+        if (e != hipSuccess) return hip_failed(e, "placement: copy of the planes");
+      }
       rebase_frames(g, cur, bytes, to);
       cur = to;
       ms.push_back(0.f);
       const int st = measure(&ms[c]);
-      if (st) return st;
+      if (st) return bail(st);
       if (ms[c] < ms[best]) best = c;
       if (ms[c] > ms[worst]) worst = c;
     }
     void* keep = best ? P.blocks[best - 1] : *block;
     rebase_frames(g, cur, bytes, keep);
-    HIP_TRY(ctx, hipMemcpyAsync(g->d_frames, g->h_frames.data(), sizeof(DevFrame) * nf, hipMemcpyHostToDevice, s));
-    HIP_TRY(ctx, hipStreamSynchronize(s));
+    cur = keep;
+    hipError_t e = hipMemcpyAsync(g->d_frames, g->h_frames.data(), sizeof(DevFrame) * nf, hipMemcpyHostToDevice, s);
+    if (e == hipSuccess) e = hipStreamSynchronize(s);
+    if (e != hipSuccess) return hip_failed(e, "placement: descriptor upload");
     if (best) { P.blocks[best - 1] = *block; *block = keep; }      // the old place becomes a candidate
     *best_ms = ms[best];
     if (M.info.candidates == 0) M.info.ms_as_allocated = ms[0];
