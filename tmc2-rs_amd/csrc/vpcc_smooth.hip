@@ -98,10 +98,12 @@ __device__ __forceinline__ void smooth_stats_chunk(const DevFrame& f, uint32_t f
   if (chunk * 256u >= n) return;
   const bool active = i < n;
   const uint32_t lane = threadIdx.x & 63u;
-  uint32_t key = 0xFFFFFFFFu, v[3] = {0, 0, 0}, patch = 0;
+  uint32_t key = 0xFFFFFFFFu, v[3] = {0, 0, 0}, patch = 0, cslot = 0;
   if (active) {
     const vpcc_point3 p = gload(f.out_xyz + i);
-    key = (cell_coord(p.z, G, w) * w + cell_coord(p.y, G, w)) * w + cell_coord(p.x, G, w);
+    const uint32_t cx = cell_coord(p.x, G, w), cy = cell_coord(p.y, G, w), cz = cell_coord(p.z, G, w);
+    key = (cz * w + cy) * w + cx;
+    cslot = (cx & 3u) | ((cy & 3u) << 2) | ((cz & 3u) << 4);
     v[0] = p.x; v[1] = p.y; v[2] = p.z;
     if (mode) {
       const vpcc_color3 col = gload(f.out_rgb + i);
@@ -116,6 +118,61 @@ __device__ __forceinline__ void smooth_stats_chunk(const DevFrame& f, uint32_t f
   // colours, and for coordinates of 10-bit content.
   const bool pack = __ballot((v[0] | v[1]) > 1023u) == 0;
   const uint32_t v01 = v[0] | (v[1] << 16);
+  // Fast path: no loop at all.  The cells of 64 consecutive points are neighbours in the grid, so the low two bits of
+  // each cell coordinate give every cell of the wave a slot of its own among 64 (two cells collide only if they are a
+  // multiple of four cells apart in every axis).  The first lane of every run of equal cell indices writes the index
+  // (and its patch, and its lane number) to its slot and every lane reads the slot back: if every lane finds its own
+  // index and patch, the slots are collision-free and every cell's points share one patch; the lane whose number
+  // stayed in a slot is elected for it.  Then every lane adds its values to its slot with LDS atomics (lanes of one
+  // slot are served one after the other, slots side by side; the point count rides in the upper bits of the third
+  // sum), the elected lanes line their slots up in a list, and lane 4 j + t carries word t of the j-th cell: the four
+  // words of a cell leave as ONE 32-byte atomic request.  A wave with a collision, or with points of two patches in
+  // one cell (rare), takes the loop below.  Per 128 S-longdress frames: geometry 0.93 -> 0.58 ms, colour 1.02 -> 0.68
+  // (profiles/r03/ab_smooth_stats.txt; with four separate atomic instructions issued by the elected lanes 1.73 ms —
+  // it is the number of atomic REQUESTS that counts; numbering the cells in a loop first and adding into numbered
+  // slots 0.74 ms).
+  {
+    struct StatTable { uint32_t key[64], pl[64], lid[64], acc[3][64]; };
+    __shared__ StatTable s_tab[4];
+    StatTable& T = s_tab[threadIdx.x >> 6];
+    const uint32_t slot = cslot;
+    const bool head = active && row_shr<1>(key, ~key) != key;
+    if (head) {
+      T.key[slot] = key; T.pl[slot] = patch; T.lid[slot] = lane;
+      T.acc[0][slot] = 0u; T.acc[1][slot] = 0u; T.acc[2][slot] = 0u;
+    }
+    __builtin_amdgcn_wave_barrier();                         // (LDS operations of one wave execute in order)
+    const bool clash = active && (T.key[slot] != key || T.pl[slot] != patch);
+    if (__ballot(clash) == 0) {
+      if (active) {
+        if (pack) atomicAdd(&T.acc[0][slot], v01);
+        else { atomicAdd(&T.acc[0][slot], v[0]); atomicAdd(&T.acc[1][slot], v[1]); }
+        atomicAdd(&T.acc[2][slot], v[2] + (1u << 22));         // 64 x 65535 < 2^22: the count above the sum
+      }
+      __builtin_amdgcn_wave_barrier();
+      const bool elected = head && T.lid[slot] == lane;
+      const uint64_t em = __ballot(elected);
+      __builtin_amdgcn_wave_barrier();
+      if (elected) T.lid[__builtin_popcountll(em & ((1ull << lane) - 1ull))] = slot;   // (the election is over: reuse)
+      __builtin_amdgcn_wave_barrier();
+      const uint32_t ncell = (uint32_t)__builtin_popcountll(em);
+      for (uint32_t base = 0; base < ncell; base += 16u) {
+        const uint32_t j = base + (lane >> 2), t = lane & 3u;
+        if (j < ncell) {
+          const uint32_t sl = T.lid[j];
+          const uint32_t k = T.key[sl], pl = T.pl[sl], a0 = T.acc[0][sl], a2 = T.acc[2][sl];
+          const uint32_t cnt = a2 >> 22, s2 = a2 & 0x3FFFFFu;
+          const uint32_t s0 = pack ? a0 & 0xFFFFu : a0, s1 = pack ? a0 >> 16 : T.acc[1][sl];
+          const uint32_t sp = cnt * pl;
+          const uint64_t val = t == 0 ? (uint64_t)cnt | ((uint64_t)s0 << 32)
+                             : t == 1 ? (uint64_t)s1 | ((uint64_t)s2 << 32)
+                             : t == 2 ? (uint64_t)sp * pl : (uint64_t)sp;
+          atomicAdd(reinterpret_cast<unsigned long long*>(grid + k) + t, (unsigned long long)val);
+        }
+      }
+      return;
+    }
+  }
   while (todo) {                                           // one trip per distinct cell of the wave
     const uint32_t k = (uint32_t)__builtin_amdgcn_readlane((int)key, (int)__builtin_ctzll(todo));
     const bool in = active && key == k;
