@@ -115,15 +115,20 @@ static_assert(sizeof(SmoothCell) == 32, "SmoothCell is 32 B");
 // Scratch of the smoothing filters for a chunk of frames: per frame a dense grid of w^3 cells (all-zero between
 // launches) and the cell index of every point as the statistics kernel saw it (the geometry filter moves
 // points in place, so the cells to clear afterwards cannot be recomputed from the positions).
+constexpr uint32_t kSmoothListLen = 16, kSmoothNoCell = 0xFFFFFFFFu, kSmoothListOverflow = 0xFFFFFFFEu;
 struct SmoothGrid {
   unsigned char* base;        // frame slot j at base + j * slot_bytes: [w^3 cells | w^3 flag bytes], all-zero between launches
   size_t slot_bytes;
   size_t flags_offset;        // bytes from the slot's start to its flags
-  uint32_t* key_base;         // cell indices of frame slot j at key_base + j * key_stride (their own allocation: no zero invariant)
-  size_t key_stride;
+  uint32_t* key_base;         // cell indices of frame slot j at key_base + j * key_stride (their own allocation: no zero invariant);
+  size_t key_stride;          //   written only for the waves (64 consecutive points) whose cells do not fit their list
+  uint32_t* list_base;        // cell lists of frame slot j at list_base + j * list_stride: kSmoothListLen entries per wave of 64
+  size_t list_stride;         //   points — the distinct cells the wave's points fall into, kSmoothNoCell where unused; or
+                              //   kSmoothListOverflow in entry 0: the cells of these 64 points are in the key array instead
   VPCC_HD SmoothCell* cells(uint32_t j) const { return reinterpret_cast<SmoothCell*>(base + j * slot_bytes); }
   VPCC_HD unsigned char* flags(uint32_t j) const { return base + j * slot_bytes + flags_offset; }
   VPCC_HD uint32_t* keys(uint32_t j) const { return key_base + j * key_stride; }
+  VPCC_HD uint32_t* lists(uint32_t j) const { return list_base + j * list_stride; }
 };
 
 void launch_smooth_stats(const DevFrame* d_frames, uint32_t first, uint32_t count, uint32_t max_points, SmoothGrid sg,

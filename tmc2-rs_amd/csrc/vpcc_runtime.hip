@@ -104,7 +104,7 @@ struct vpcc_gof {
   void* smooth_grid = nullptr;         // smoothing scratch (on demand): dense cell grids + touched lists + list lengths
   size_t smooth_bytes = 0;
   bool smooth_clean = false;           // the scratch is all-zero (the invariant between launches)
-  void* smooth_keys = nullptr;         // cell index of every point of every frame (capacity words per frame)
+  void* smooth_keys = nullptr;         // cell index of every point of every frame (capacity words per frame), then the cell lists
 };
 
 namespace {
@@ -1077,8 +1077,10 @@ extern "C" int vpcc_gof_smooth(vpcc_gof* g, uint32_t first, uint32_t count, cons
     sg.flags_offset = align_up(cells * sizeof(SmoothCell), 256);
     sg.slot_bytes = align_up(sg.flags_offset + cells, 256);
     sg.key_stride = align_up(g->capacity, 4);                // 16-byte loads of four cell indices
-    if (!g->smooth_keys) HIP_TRY(ctx, hipMalloc(&g->smooth_keys, sizeof(uint32_t) * sg.key_stride * g->n_frames));
+    sg.list_stride = align_up((g->capacity + 63) / 64 * kSmoothListLen, 64);
+    if (!g->smooth_keys) HIP_TRY(ctx, hipMalloc(&g->smooth_keys, sizeof(uint32_t) * (sg.key_stride + sg.list_stride) * g->n_frames));
     sg.key_base = (uint32_t*)g->smooth_keys;
+    sg.list_base = sg.key_base + sg.key_stride * g->n_frames;
     const uint32_t chunk = (uint32_t)std::max<size_t>(1, std::min<size_t>(count, (size_t(16) << 30) / sg.slot_bytes));
     const size_t need = sg.slot_bytes * chunk;
     if (g->smooth_bytes < need) {

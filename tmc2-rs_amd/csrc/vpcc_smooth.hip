@@ -46,6 +46,27 @@ __device__ __forceinline__ void axis_setup(uint32_t p, uint32_t G, uint32_t w, i
 
 }  // namespace
 
+// A point / a colour with ONE 8-byte load (4-byte aligned) instead of three 2-byte / 1-byte loads: element i starts
+// 0 or 2 (points), 0-3 (colours) bytes into the aligned pair of dwords, which therefore reaches up to 2 / 5 bytes
+// past the element — into the next element, or into the padding every output array ends with (vpcc_runtime.hip).
+__device__ __forceinline__ vpcc_point3 load_point(const vpcc_point3* base, uint32_t i) {
+  typedef uint32_t v2 __attribute__((ext_vector_type(2)));
+  const uint32_t off = i * 6u;
+  const v2 d = *(const VPCC_GLOBAL v2*)((const VPCC_GLOBAL unsigned char*)base + (off & ~3u));
+  const uint64_t v = (((uint64_t)d.y << 32) | d.x) >> ((off & 2u) * 8u);
+  vpcc_point3 p;
+  p.x = (uint16_t)v; p.y = (uint16_t)(v >> 16); p.z = (uint16_t)(v >> 32);
+  return p;
+}
+__device__ __forceinline__ vpcc_color3 load_color(const vpcc_color3* base, uint32_t i) {
+  typedef uint32_t v2 __attribute__((ext_vector_type(2)));
+  const uint32_t off = i * 3u;
+  const v2 d = *(const VPCC_GLOBAL v2*)((const VPCC_GLOBAL unsigned char*)base + (off & ~3u));
+  const uint64_t v = (((uint64_t)d.y << 32) | d.x) >> ((off & 3u) * 8u);
+  vpcc_color3 c;
+  c.r = (uint8_t)v; c.g = (uint8_t)(v >> 8); c.b = (uint8_t)(v >> 16);
+  return c;
+}
 typedef uint16_t u16x2 __attribute__((ext_vector_type(2)));
 // value of lane - kShift within the lane's row of 16 (DPP row_shr); `outside` where there is no such lane
 template <int kShift>
@@ -100,18 +121,19 @@ __device__ __forceinline__ void smooth_stats_chunk(const DevFrame& f, uint32_t f
   const uint32_t lane = threadIdx.x & 63u;
   uint32_t key = 0xFFFFFFFFu, v[3] = {0, 0, 0}, patch = 0, cslot = 0;
   if (active) {
-    const vpcc_point3 p = gload(f.out_xyz + i);
+    const vpcc_point3 p = load_point(f.out_xyz, i);
     const uint32_t cx = cell_coord(p.x, G, w), cy = cell_coord(p.y, G, w), cz = cell_coord(p.z, G, w);
     key = (cz * w + cy) * w + cx;
     cslot = (cx & 3u) | ((cy & 3u) << 2) | ((cz & 3u) << 4);
     v[0] = p.x; v[1] = p.y; v[2] = p.z;
     if (mode) {
-      const vpcc_color3 col = gload(f.out_rgb + i);
+      const vpcc_color3 col = load_color(f.out_rgb, i);
       v[0] = col.r; v[1] = col.g; v[2] = col.b;
     }
     patch = gl(f.out_patch)[i];
-    sg.keys(frame)[i] = key;
+    sg.keys(frame)[i] = key;                                 // for the apply kernels (one dword per point: cheaper than the point)
   }
+  uint32_t* list = sg.lists(frame) + (size_t)(i >> 6) * kSmoothListLen;   // this wave's cell list
   SmoothCell* grid = sg.cells(frame);
   uint64_t todo = __ballot(active);
   // Two of the three sums share one reduction when no value of the wave exceeds 1023 (64 x 1023 < 2^16): always for
@@ -153,9 +175,18 @@ __device__ __forceinline__ void smooth_stats_chunk(const DevFrame& f, uint32_t f
       const bool elected = head && T.lid[slot] == lane;
       const uint64_t em = __ballot(elected);
       __builtin_amdgcn_wave_barrier();
-      if (elected) T.lid[__builtin_popcountll(em & ((1ull << lane) - 1ull))] = slot;   // (the election is over: reuse)
-      __builtin_amdgcn_wave_barrier();
       const uint32_t ncell = (uint32_t)__builtin_popcountll(em);
+      const uint32_t rank = (uint32_t)__builtin_popcountll(em & ((1ull << lane) - 1ull));
+      if (elected) T.lid[rank] = slot;                        // (the election is over: reuse)
+      // the cells this wave touched, for the passes that follow (mark, clear): a list of 16, or — more cells than
+      // that — "see the cell index of every point"
+      if (ncell <= kSmoothListLen) {
+        if (elected) list[rank] = key;
+        if (lane >= ncell && lane < kSmoothListLen) list[lane] = kSmoothNoCell;
+      } else if (lane == 0) {
+        list[0] = kSmoothListOverflow;
+      }
+      __builtin_amdgcn_wave_barrier();
       for (uint32_t base = 0; base < ncell; base += 16u) {
         const uint32_t j = base + (lane >> 2), t = lane & 3u;
         if (j < ncell) {
@@ -173,6 +204,7 @@ __device__ __forceinline__ void smooth_stats_chunk(const DevFrame& f, uint32_t f
       return;
     }
   }
+  if (lane == 0) list[0] = kSmoothListOverflow;             // (rare path: mark and clear take the cells from the key array)
   while (todo) {                                           // one trip per distinct cell of the wave
     const uint32_t k = (uint32_t)__builtin_amdgcn_readlane((int)key, (int)__builtin_ctzll(todo));
     const bool in = active && key == k;
@@ -253,39 +285,54 @@ __device__ __forceinline__ uint32_t load_keys4(const uint32_t* keys, uint32_t i4
   return lead;
 }
 
+// The cells thread e of a frame's launch is responsible for: entry e of the frame's cell lists, or — where a wave's
+// list says "overflow" — the cells of four of that wave's points, taken from the key array (leader bits as above).
+// Returns the number of cells in k[] (0, 1 or up to 4).
+__device__ __forceinline__ uint32_t listed_cells(const SmoothGrid& sg, uint32_t frame, uint32_t e, uint32_t n, uint32_t k[4]) {
+  const uint32_t wave = e / kSmoothListLen, j = e % kSmoothListLen;
+  if (wave * 64u >= n) return 0;
+  const uint32_t* list = sg.lists(frame) + (size_t)wave * kSmoothListLen;
+  if (list[0] != kSmoothListOverflow) {
+    k[0] = list[j];
+    return k[0] != kSmoothNoCell ? 1u : 0u;
+  }
+  static_assert(kSmoothListLen * 4u == 64u, "four points per thread in an overflow wave");
+  uint32_t all[4];
+  const uint32_t lead = load_keys4(sg.keys(frame), wave * 64u + j * 4u, n, all);
+  uint32_t m = 0;
+#pragma unroll
+  for (uint32_t q = 0; q < 4; ++q) if ((lead >> q) & 1u) k[m++] = all[q];
+  return m;
+}
+
 __global__ __launch_bounds__(256) void k_smooth_mark(const DevFrame* __restrict__ frames, uint32_t first, SmoothGrid sg,
                                                      uint32_t w) {
   const DevFrame& f = frames[first + blockIdx.y];
   const uint32_t n = min(*gl(f.n_points), f.capacity);
-  const uint32_t i4 = (blockIdx.x * 256u + threadIdx.x) * 4u;
-  if (blockIdx.x * 1024u >= n) return;
+  if (blockIdx.x * 1024u >= n) return;                      // 256 entries = 16 waves = 1 024 points per workgroup
   uint32_t k[4];
-  const uint32_t lead = load_keys4(sg.keys(blockIdx.y), i4, n, k);
-#pragma unroll
-  for (uint32_t j = 0; j < 4; ++j)
-    if (((lead >> j) & 1u) && cell_mixed(gload(sg.cells(blockIdx.y) + k[j]))) {
-      paint_flags(sg.flags(blockIdx.y), k[j], w, 1);
-      (sg.cells(blockIdx.y) + k[j])->mixed = 1u;             // for the apply kernels: the 64-bit test once per cell, not per point
+  const uint32_t m = listed_cells(sg, blockIdx.y, blockIdx.x * 256u + threadIdx.x, n, k);
+  for (uint32_t q = 0; q < m; ++q)
+    if (cell_mixed(gload(sg.cells(blockIdx.y) + k[q]))) {
+      paint_flags(sg.flags(blockIdx.y), k[q], w, 1);
+      (sg.cells(blockIdx.y) + k[q])->mixed = 1u;             // for the apply kernels: the 64-bit test once per cell, not per point
     }
 }
 
-// Restores the all-zero state: the first point of every run of equal cell indices un-paints the flags of a mixed
-// cell and zeroes the cell (several runs may clear one cell; the first to read it still sees it mixed).
+// Restores the all-zero state: every listed cell is un-painted if it was mixed, and zeroed (several waves list the
+// same cell; the first to read it still sees it mixed).
 __global__ __launch_bounds__(256) void k_smooth_clear(const DevFrame* __restrict__ frames, uint32_t first, SmoothGrid sg,
                                                       uint32_t w) {
   const DevFrame& f = frames[first + blockIdx.y];
   const uint32_t n = min(*gl(f.n_points), f.capacity);
-  const uint32_t i4 = (blockIdx.x * 256u + threadIdx.x) * 4u;
   if (blockIdx.x * 1024u >= n) return;
   uint32_t k[4];
-  const uint32_t lead = load_keys4(sg.keys(blockIdx.y), i4, n, k);
-#pragma unroll
-  for (uint32_t j = 0; j < 4; ++j) {
-    if (!((lead >> j) & 1u)) continue;
-    SmoothCell* cell = sg.cells(blockIdx.y) + k[j];
+  const uint32_t m = listed_cells(sg, blockIdx.y, blockIdx.x * 256u + threadIdx.x, n, k);
+  for (uint32_t q = 0; q < m; ++q) {
+    SmoothCell* cell = sg.cells(blockIdx.y) + k[q];
     const SmoothCell seen = gload(cell);
-    if (seen.count == 0) continue;                            // an earlier run of the same cell has cleared it
-    if (seen.mixed) paint_flags(sg.flags(blockIdx.y), k[j], w, 0);
+    if (seen.count == 0) continue;                            // another wave's entry of the same cell has cleared it
+    if (seen.mixed) paint_flags(sg.flags(blockIdx.y), k[q], w, 0);
     uint4* c = reinterpret_cast<uint4*>(cell);
     c[0] = make_uint4(0u, 0u, 0u, 0u); c[1] = make_uint4(0u, 0u, 0u, 0u);
   }
