@@ -70,11 +70,19 @@ def test_spec_on_a_reconstructed_frame_moves_only_patch_boundaries():
     ("medium", dict(grid_size=4, threshold=0, color_grid_size=2, color_threshold_smoothing=0, color_threshold_difference=765)),
     ("medium", dict(grid_size=16, threshold=5)),
     ("longdress", dict(grid_size=8, threshold=3, color_grid_size=8, color_threshold_smoothing=20, color_threshold_difference=100)),
+    # depths drawn at random per pixel: the 64 consecutive points of a wave scatter over dozens of cells — more than a
+    # wave's cell list holds, and cells a multiple of four apart in every axis (the statistics kernel's slot collisions)
+    ("scattered", dict(grid_size=8, threshold=1, color_grid_size=8, color_threshold_smoothing=5, color_threshold_difference=200)),
 ])
 def test_hip_smoothing_matches_spec(frames, params):
     from tmc2rs import recon
-    fr = ([cases.overlapping_3d_frame(i) for i in range(3)] if frames == "medium"
+    fr = ([cases.overlapping_3d_frame(i) for i in range(3)] if frames in ("medium", "scattered")
           else [cases.overlapping_3d_frame(0, base=synth.longdress_frame(1))])
+    if frames == "scattered":
+        rng = np.random.RandomState(7)
+        for f in fr:
+            d0 = rng.randint(0, 800, size=f["geometry"][0].shape).astype(np.uint16)
+            f["geometry"] = [d0, (d0 + rng.randint(0, 64, size=d0.shape)).astype(np.uint16)]
     ctx = recon.Context(0)
     g = ctx.gof(fr, flags=_abi.VPCC_GOF_WANT_PATCH_INDEX)
     g.reconstruct()
