@@ -103,9 +103,16 @@ struct SmoothCell {
   uint32_t s[3];        // coordinate sums (geometry) or R,G,B sums (colour)
   uint64_t sp2;         // sum of squared patch indices
   uint32_t sp;          // sum of patch indices
-  uint32_t mixed;       // set by k_smooth_mark on the cells that hold more than one patch (the statistics kernel adds 0 here)
+  uint32_t mixed;       // kSmoothMixed: the cell holds more than one patch; kSmoothPainted: the flags around it are set
+                        // (k_smooth_mark, k_smooth_moved_mark; the statistics kernel adds 0 here)
 };
 static_assert(sizeof(SmoothCell) == 32, "SmoothCell is 32 B");
+constexpr uint32_t kSmoothMixed = 1u, kSmoothPainted = 2u;
+// R, G, B sums of a cell when ONE statistics pass serves both filters (same grid size): a parallel array.
+struct SmoothColorCell { uint32_t s[3], pad; };
+static_assert(sizeof(SmoothColorCell) == 16, "SmoothColorCell is 16 B");
+// A point the geometry filter moved into another cell: (point index, cell it left).
+struct SmoothMoved { uint32_t point, old_cell; };
 
 #if defined(__HIPCC__)
 #define VPCC_HD __host__ __device__
@@ -125,7 +132,13 @@ struct SmoothGrid {
   uint32_t* list_base;        // cell lists of frame slot j at list_base + j * list_stride: kSmoothListLen entries per wave of 64
   size_t list_stride;         //   points — the distinct cells the wave's points fall into, kSmoothNoCell where unused; or
                               //   kSmoothListOverflow in entry 0: the cells of these 64 points are in the key array instead
+  size_t color_offset;        // both filters in one pass: bytes from the slot's start to its w^3 colour cells (else 0)
+  SmoothMoved* moved_base;    //   ... the points the geometry filter moved to another cell, frame slot j at + j * moved_stride,
+  size_t moved_stride;        //   and how many (one counter per frame slot, zeroed by vpcc_gof_smooth)
+  uint32_t* moved_count;
   VPCC_HD SmoothCell* cells(uint32_t j) const { return reinterpret_cast<SmoothCell*>(base + j * slot_bytes); }
+  VPCC_HD SmoothColorCell* color_cells(uint32_t j) const { return reinterpret_cast<SmoothColorCell*>(base + j * slot_bytes + color_offset); }
+  VPCC_HD SmoothMoved* moved(uint32_t j) const { return moved_base + j * moved_stride; }
   VPCC_HD unsigned char* flags(uint32_t j) const { return base + j * slot_bytes + flags_offset; }
   VPCC_HD uint32_t* keys(uint32_t j) const { return key_base + j * key_stride; }
   VPCC_HD uint32_t* lists(uint32_t j) const { return list_base + j * list_stride; }
@@ -133,14 +146,18 @@ struct SmoothGrid {
 
 void launch_smooth_stats(const DevFrame* d_frames, uint32_t first, uint32_t count, uint32_t max_points, SmoothGrid sg,
                          uint32_t w, uint32_t G, uint32_t mode, void* stream);
+// mode of launch_smooth_stats: 0 coordinate sums, 1 colour sums, 2 both (colour sums into the colour cells); `both` of
+// the others: the launch belongs to a pass that serves both filters.
 void launch_smooth_apply_geometry(const DevFrame* d_frames, uint32_t first, uint32_t count, uint32_t max_points,
-                                  SmoothGrid sg, uint32_t w, uint32_t G, uint32_t T, void* stream);
+                                  SmoothGrid sg, uint32_t w, uint32_t G, uint32_t T, bool both, void* stream);
 void launch_smooth_apply_color(const DevFrame* d_frames, uint32_t first, uint32_t count, uint32_t max_points,
-                               SmoothGrid sg, uint32_t w, uint32_t G, uint32_t Ts, uint32_t Td, void* stream);
+                               SmoothGrid sg, uint32_t w, uint32_t G, uint32_t Ts, uint32_t Td, bool both, void* stream);
+void launch_smooth_moved(const DevFrame* d_frames, uint32_t first, uint32_t count, SmoothGrid sg, uint32_t w, uint32_t G,
+                         void* stream);
 void launch_smooth_mark(const DevFrame* d_frames, uint32_t first, uint32_t count, uint32_t max_points, SmoothGrid sg,
                         uint32_t w, void* stream);
 void launch_smooth_clear(const DevFrame* d_frames, uint32_t first, uint32_t count, uint32_t max_points, SmoothGrid sg,
-                         uint32_t w, void* stream);
+                         uint32_t w, bool both, void* stream);
 
 // Kernel launchers (vpcc_kernels.hip).  All asynchronous on `stream`.
 void launch_block_owner(const DevFrame* d_frames, uint32_t first, uint32_t count, uint32_t max_vb,

@@ -105,6 +105,7 @@ struct vpcc_gof {
   size_t smooth_bytes = 0;
   bool smooth_clean = false;           // the scratch is all-zero (the invariant between launches)
   void* smooth_keys = nullptr;         // cell index of every point of every frame (capacity words per frame), then the cell lists
+  void* smooth_moved = nullptr;        // both filters in one pass: points moved to another cell (capacity entries per frame), counters
 };
 
 namespace {
@@ -286,6 +287,7 @@ extern "C" void vpcc_gof_destroy(vpcc_gof* gof) {
   if (gof->results_ready) (void)hipEventDestroy(gof->results_ready);
   if (gof->smooth_grid) (void)hipFree(gof->smooth_grid);
   if (gof->smooth_keys) (void)hipFree(gof->smooth_keys);
+  if (gof->smooth_moved) (void)hipFree(gof->smooth_moved);
   if (gof->arena) {                                   // all work on it is complete (streams synchronised above)
     auto& cache = gof->ctx->arena_cache;
     if (cache.size() < 4) cache.emplace_back(gof->arena, gof->arena_bytes);
@@ -1056,16 +1058,21 @@ extern "C" int vpcc_gof_smooth(vpcc_gof* g, uint32_t first, uint32_t count, cons
   // No host synchronisation: the kernels read every frame's point count from device memory; the launches are
   // sized for the capacity and surplus workgroups leave at once.
   const uint32_t max_points = (uint32_t)g->capacity;
+  bool all_attr = true, any_attr = false;
+  for (uint32_t i = first; i < first + count; ++i) {
+    all_attr = all_attr && g->h_frames[i].has_attr != 0;
+    any_attr = any_attr || g->h_frames[i].has_attr != 0;
+  }
+  const bool want_geo = (p->flags & VPCC_SMOOTH_GEOMETRY) != 0, want_col = (p->flags & VPCC_SMOOTH_COLOR) != 0 && any_attr;
+  if (want_col && !all_attr) return fail(ctx, VPCC_ERR_INVALID_ARG, "colour smoothing on a frame without attribute");
+  // Both filters over the same grid: ONE statistics / mark / clear sequence serves both (coordinate sums in the cells,
+  // colour sums in a parallel array).  The colour filter's cells are those of the SMOOTHED positions: the few points
+  // the geometry filter moves into another cell take their count, colour and patch sums with them
+  // (k_smooth_moved_*), which keeps every sum what a second statistics pass would have produced.
+  const bool both = want_geo && want_col && p->grid_size == p->color_grid_size;
   for (int pass = 0; pass < 2; ++pass) {
     const bool geo = pass == 0;
-    if (!(p->flags & (geo ? VPCC_SMOOTH_GEOMETRY : VPCC_SMOOTH_COLOR))) continue;
-    if (!geo) {
-      bool any_attr = false;
-      for (uint32_t i = first; i < first + count; ++i) any_attr |= g->h_frames[i].has_attr != 0;
-      if (!any_attr) continue;
-      for (uint32_t i = first; i < first + count; ++i)
-        if (!g->h_frames[i].has_attr) return fail(ctx, VPCC_ERR_INVALID_ARG, "colour smoothing on a frame without attribute");
-    }
+    if (!(geo ? want_geo : want_col) || (both && !geo)) continue;
     const uint32_t G = geo ? p->grid_size : p->color_grid_size;
     const uint32_t w = ((1u << p->geometry_bitdepth_3d) + G - 1) / G;
     const size_t cells = (size_t)w * w * w;
@@ -1075,12 +1082,21 @@ extern "C" int vpcc_gof_smooth(vpcc_gof* g, uint32_t first, uint32_t count, cons
     // (re)allocated or after a failed launch.
     SmoothGrid sg{};
     sg.flags_offset = align_up(cells * sizeof(SmoothCell), 256);
-    sg.slot_bytes = align_up(sg.flags_offset + cells, 256);
+    sg.color_offset = both ? align_up(sg.flags_offset + cells, 256) : 0;
+    sg.slot_bytes = align_up(both ? sg.color_offset + cells * sizeof(SmoothColorCell) : sg.flags_offset + cells, 256);
     sg.key_stride = align_up(g->capacity, 4);                // 16-byte loads of four cell indices
     sg.list_stride = align_up((g->capacity + 63) / 64 * kSmoothListLen, 64);
     if (!g->smooth_keys) HIP_TRY(ctx, hipMalloc(&g->smooth_keys, sizeof(uint32_t) * (sg.key_stride + sg.list_stride) * g->n_frames));
     sg.key_base = (uint32_t*)g->smooth_keys;
     sg.list_base = sg.key_base + sg.key_stride * g->n_frames;
+    if (both) {
+      sg.moved_stride = g->capacity;
+      if (!g->smooth_moved)
+        HIP_TRY(ctx, hipMalloc(&g->smooth_moved, sizeof(SmoothMoved) * sg.moved_stride * g->n_frames + sizeof(uint32_t) * g->n_frames));
+      sg.moved_base = (SmoothMoved*)g->smooth_moved;
+      sg.moved_count = (uint32_t*)(sg.moved_base + sg.moved_stride * g->n_frames);
+      HIP_TRY(ctx, hipMemsetAsync(sg.moved_count, 0, sizeof(uint32_t) * g->n_frames, s));
+    }
     const uint32_t chunk = (uint32_t)std::max<size_t>(1, std::min<size_t>(count, (size_t(16) << 30) / sg.slot_bytes));
     const size_t need = sg.slot_bytes * chunk;
     if (g->smooth_bytes < need) {
@@ -1096,24 +1112,38 @@ extern "C" int vpcc_gof_smooth(vpcc_gof* g, uint32_t first, uint32_t count, cons
       g->smooth_clean = true;
     }
     sg.base = (unsigned char*)g->smooth_grid;
+    static const char* const kNames[3][3] = {
+        {"k_smooth_stats<geometry>", "k_smooth_stats<color>", "k_smooth_stats<both>"},
+        {"k_smooth_mark<geometry>", "k_smooth_mark<color>", "k_smooth_mark<both>"},
+        {"k_smooth_clear<geometry>", "k_smooth_clear<color>", "k_smooth_clear<both>"}};
+    const int tag = both ? 2 : geo ? 0 : 1;
     for (uint32_t c0 = first; c0 < first + count; c0 += chunk) {
       const uint32_t c = std::min(chunk, first + count - c0);
       g->smooth_clean = false;                              // until the clearing kernel of this chunk is enqueued
-      T.begin(geo ? "k_smooth_stats<geometry>" : "k_smooth_stats<color>");
-      launch_smooth_stats(g->d_frames, c0, c, max_points, sg, w, G, geo ? 0u : 1u, s);
+      T.begin(kNames[0][tag]);
+      launch_smooth_stats(g->d_frames, c0, c, max_points, sg, w, G, both ? 2u : geo ? 0u : 1u, s);
       T.end();
-      T.begin(geo ? "k_smooth_mark<geometry>" : "k_smooth_mark<color>");
+      T.begin(kNames[1][tag]);
       launch_smooth_mark(g->d_frames, c0, c, max_points, sg, w, s);
       T.end();
-      T.begin(geo ? "k_smooth_apply_geometry" : "k_smooth_apply_color");
-      if (geo)
-        launch_smooth_apply_geometry(g->d_frames, c0, c, max_points, sg, w, G, p->threshold, s);
-      else
+      if (geo) {
+        T.begin("k_smooth_apply_geometry");
+        launch_smooth_apply_geometry(g->d_frames, c0, c, max_points, sg, w, G, p->threshold, both, s);
+        T.end();
+      }
+      if (both) {
+        T.begin("k_smooth_moved");
+        launch_smooth_moved(g->d_frames, c0, c, sg, w, G, s);
+        T.end();
+      }
+      if (!geo || both) {
+        T.begin("k_smooth_apply_color");
         launch_smooth_apply_color(g->d_frames, c0, c, max_points, sg, w, G, p->color_threshold_smoothing,
-                                  p->color_threshold_difference, s);
-      T.end();
-      T.begin(geo ? "k_smooth_clear<geometry>" : "k_smooth_clear<color>");
-      launch_smooth_clear(g->d_frames, c0, c, max_points, sg, w, s);
+                                  p->color_threshold_difference, both, s);
+        T.end();
+      }
+      T.begin(kNames[2][tag]);
+      launch_smooth_clear(g->d_frames, c0, c, max_points, sg, w, both, s);
       T.end();
       HIP_TRY(ctx, hipGetLastError());
       g->smooth_clean = true;

@@ -119,7 +119,7 @@ __device__ __forceinline__ void smooth_stats_chunk(const DevFrame& f, uint32_t f
   if (chunk * 256u >= n) return;
   const bool active = i < n;
   const uint32_t lane = threadIdx.x & 63u;
-  uint32_t key = 0xFFFFFFFFu, v[3] = {0, 0, 0}, patch = 0, cslot = 0;
+  uint32_t key = 0xFFFFFFFFu, v[3] = {0, 0, 0}, patch = 0, cslot = 0, c01 = 0, c2 = 0;
   if (active) {
     const vpcc_point3 p = load_point(f.out_xyz, i);
     const uint32_t cx = cell_coord(p.x, G, w), cy = cell_coord(p.y, G, w), cz = cell_coord(p.z, G, w);
@@ -128,13 +128,15 @@ __device__ __forceinline__ void smooth_stats_chunk(const DevFrame& f, uint32_t f
     v[0] = p.x; v[1] = p.y; v[2] = p.z;
     if (mode) {
       const vpcc_color3 col = load_color(f.out_rgb, i);
-      v[0] = col.r; v[1] = col.g; v[2] = col.b;
+      if (mode == 1u) { v[0] = col.r; v[1] = col.g; v[2] = col.b; }
+      else { c01 = col.r | ((uint32_t)col.g << 16); c2 = col.b; }     // mode 2: colour sums next to the coordinate sums
     }
     patch = gl(f.out_patch)[i];
     sg.keys(frame)[i] = key;                                 // for the apply kernels (one dword per point: cheaper than the point)
   }
   uint32_t* list = sg.lists(frame) + (size_t)(i >> 6) * kSmoothListLen;   // this wave's cell list
   SmoothCell* grid = sg.cells(frame);
+  SmoothColorCell* cgrid = sg.color_cells(frame);           // (mode 2 only)
   uint64_t todo = __ballot(active);
   // Two of the three sums share one reduction when no value of the wave exceeds 1023 (64 x 1023 < 2^16): always for
   // colours, and for coordinates of 10-bit content.
@@ -154,7 +156,7 @@ __device__ __forceinline__ void smooth_stats_chunk(const DevFrame& f, uint32_t f
   // it is the number of atomic REQUESTS that counts; numbering the cells in a loop first and adding into numbered
   // slots 0.74 ms).
   {
-    struct StatTable { uint32_t key[64], pl[64], lid[64], acc[3][64]; };
+    struct StatTable { uint32_t key[64], pl[64], lid[64], acc[5][64]; };
     __shared__ StatTable s_tab[4];
     StatTable& T = s_tab[threadIdx.x >> 6];
     const uint32_t slot = cslot;
@@ -162,6 +164,7 @@ __device__ __forceinline__ void smooth_stats_chunk(const DevFrame& f, uint32_t f
     if (head) {
       T.key[slot] = key; T.pl[slot] = patch; T.lid[slot] = lane;
       T.acc[0][slot] = 0u; T.acc[1][slot] = 0u; T.acc[2][slot] = 0u;
+      if (mode == 2u) { T.acc[3][slot] = 0u; T.acc[4][slot] = 0u; }
     }
     __builtin_amdgcn_wave_barrier();                         // (LDS operations of one wave execute in order)
     const bool clash = active && (T.key[slot] != key || T.pl[slot] != patch);
@@ -170,6 +173,7 @@ __device__ __forceinline__ void smooth_stats_chunk(const DevFrame& f, uint32_t f
         if (pack) atomicAdd(&T.acc[0][slot], v01);
         else { atomicAdd(&T.acc[0][slot], v[0]); atomicAdd(&T.acc[1][slot], v[1]); }
         atomicAdd(&T.acc[2][slot], v[2] + (1u << 22));         // 64 x 65535 < 2^22: the count above the sum
+        if (mode == 2u) { atomicAdd(&T.acc[3][slot], c01); atomicAdd(&T.acc[4][slot], c2); }   // 64 x 255 < 2^16
       }
       __builtin_amdgcn_wave_barrier();
       const bool elected = head && T.lid[slot] == lane;
@@ -201,6 +205,16 @@ __device__ __forceinline__ void smooth_stats_chunk(const DevFrame& f, uint32_t f
           atomicAdd(reinterpret_cast<unsigned long long*>(grid + k) + t, (unsigned long long)val);
         }
       }
+      if (mode == 2u)                                          // the colour cells: lane 2 j + t carries word t of the j-th
+        for (uint32_t base = 0; base < ncell; base += 32u) {
+          const uint32_t j = base + (lane >> 1), t = lane & 1u;
+          if (j < ncell) {
+            const uint32_t sl = T.lid[j];
+            const uint32_t rg = T.acc[3][sl];
+            const uint64_t val = t == 0 ? (uint64_t)(rg & 0xFFFFu) | ((uint64_t)(rg >> 16) << 32) : (uint64_t)T.acc[4][sl];
+            atomicAdd(reinterpret_cast<unsigned long long*>(cgrid + T.key[sl]) + t, (unsigned long long)val);
+          }
+        }
       return;
     }
   }
@@ -234,6 +248,12 @@ __device__ __forceinline__ void smooth_stats_chunk(const DevFrame& f, uint32_t f
                          : lane == 1 ? (uint64_t)s1 | ((uint64_t)s2 << 32)
                          : lane == 2 ? sp2 : (uint64_t)sp;
       atomicAdd(reinterpret_cast<unsigned long long*>(grid + k) + lane, (unsigned long long)val);
+    }
+    if (mode == 2u) {
+      const uint32_t rg = wave_reduce<false>(in ? c01 : 0u), bb = wave_reduce<false>(in ? c2 : 0u);
+      if (lane < 2u)
+        atomicAdd(reinterpret_cast<unsigned long long*>(cgrid + k) + lane,
+                  (unsigned long long)(lane == 0 ? (uint64_t)(rg & 0xFFFFu) | ((uint64_t)(rg >> 16) << 32) : (uint64_t)bb));
     }
     todo &= ~mask;
   }
@@ -315,27 +335,42 @@ __global__ __launch_bounds__(256) void k_smooth_mark(const DevFrame* __restrict_
   for (uint32_t q = 0; q < m; ++q)
     if (cell_mixed(gload(sg.cells(blockIdx.y) + k[q]))) {
       paint_flags(sg.flags(blockIdx.y), k[q], w, 1);
-      (sg.cells(blockIdx.y) + k[q])->mixed = 1u;             // for the apply kernels: the 64-bit test once per cell, not per point
+      (sg.cells(blockIdx.y) + k[q])->mixed = kSmoothMixed | kSmoothPainted;   // for the apply kernels: the 64-bit test once per cell, not per point
     }
 }
 
-// Restores the all-zero state: every listed cell is un-painted if it was mixed, and zeroed (several waves list the
-// same cell; the first to read it still sees it mixed).
+// Restores the all-zero state: every listed cell is un-painted if flags were painted around it, and zeroed (several
+// waves list the same cell; the first to read it still sees the bit).  both: the colour cell too, and the cells that
+// points were moved INTO (no wave listed those).
+__device__ __forceinline__ void clear_cell(const SmoothGrid& sg, uint32_t frame, uint32_t key, uint32_t w, bool both) {
+  SmoothCell* cell = sg.cells(frame) + key;
+  const SmoothCell seen = gload(cell);
+  if (both) {
+    uint4* cc = reinterpret_cast<uint4*>(sg.color_cells(frame) + key);
+    *cc = make_uint4(0u, 0u, 0u, 0u);
+  }
+  if (!(seen.count | seen.s[0] | seen.s[1] | seen.s[2] | (uint32_t)seen.sp2 | (uint32_t)(seen.sp2 >> 32) | seen.sp | seen.mixed))
+    return;                                                 // another entry of the same cell has cleared it
+  if (seen.mixed & kSmoothPainted) paint_flags(sg.flags(frame), key, w, 0);
+  uint4* c = reinterpret_cast<uint4*>(cell);
+  c[0] = make_uint4(0u, 0u, 0u, 0u); c[1] = make_uint4(0u, 0u, 0u, 0u);
+}
 __global__ __launch_bounds__(256) void k_smooth_clear(const DevFrame* __restrict__ frames, uint32_t first, SmoothGrid sg,
-                                                      uint32_t w) {
+                                                      uint32_t w, bool both) {
   const DevFrame& f = frames[first + blockIdx.y];
   const uint32_t n = min(*gl(f.n_points), f.capacity);
+  if (both) {                                               // (few: grid-stride over the workgroups of the frame)
+    const uint32_t m = min(*gl(sg.moved_count + blockIdx.y), (uint32_t)sg.moved_stride);
+    for (uint32_t e = blockIdx.x * 256u + threadIdx.x; e < m; e += gridDim.x * 256u) {
+      const SmoothMoved mv = sg.moved(blockIdx.y)[e];
+      clear_cell(sg, blockIdx.y, sg.keys(blockIdx.y)[mv.point], w, true);
+      clear_cell(sg, blockIdx.y, mv.old_cell, w, true);        // (a wave whose list overflowed finds its cells through the
+    }                                                          //  key array, where this point's entry has changed)
+  }
   if (blockIdx.x * 1024u >= n) return;
   uint32_t k[4];
   const uint32_t m = listed_cells(sg, blockIdx.y, blockIdx.x * 256u + threadIdx.x, n, k);
-  for (uint32_t q = 0; q < m; ++q) {
-    SmoothCell* cell = sg.cells(blockIdx.y) + k[q];
-    const SmoothCell seen = gload(cell);
-    if (seen.count == 0) continue;                            // another wave's entry of the same cell has cleared it
-    if (seen.mixed) paint_flags(sg.flags(blockIdx.y), k[q], w, 0);
-    uint4* c = reinterpret_cast<uint4*>(cell);
-    c[0] = make_uint4(0u, 0u, 0u, 0u); c[1] = make_uint4(0u, 0u, 0u, 0u);
-  }
+  for (uint32_t q = 0; q < m; ++q) clear_cell(sg, blockIdx.y, k[q], w, both);
 }
 
 namespace {
@@ -353,16 +388,17 @@ __device__ __forceinline__ bool load_hood(const SmoothCell* grid, const int32_t 
     h.inside[d] = !(cx < 0 || cy < 0 || cz < 0 || cx >= (int32_t)w || cy >= (int32_t)w || cz >= (int32_t)w);
     h.c[d] = SmoothCell{};
     if (h.inside[d]) h.c[d] = gload(grid + ((size_t)cz * w + cy) * w + cx);
-    mixed |= h.c[d].mixed != 0;
+    mixed |= (h.c[d].mixed & kSmoothMixed) != 0;
   }
   return mixed;
 }
 }  // namespace
 
 __device__ __forceinline__ void smooth_apply_geometry_point(const DevFrame& f, uint32_t frame, uint32_t i, uint32_t n,
-                                                            SmoothGrid sg, uint32_t w, uint32_t G, uint32_t T) {
+                                                            SmoothGrid sg, uint32_t w, uint32_t G, uint32_t T, bool both) {
   if (i >= n) return;
-  if (!sg.flags(frame)[sg.keys(frame)[i]]) return;        // no mixed cell anywhere near this point (k_smooth_mark)
+  const uint32_t own_key = sg.keys(frame)[i];
+  if (!sg.flags(frame)[own_key]) return;                   // no mixed cell anywhere near this point (k_smooth_mark)
   const vpcc_point3 pt = gload(f.out_xyz + i);
   const uint32_t p[3] = {pt.x, pt.y, pt.z};
   int32_t s[3];
@@ -393,20 +429,72 @@ __device__ __forceinline__ void smooth_apply_geometry_point(const DevFrame& f, u
     const int64_t x = (C[0] + 8) >> 4, y = (C[1] + 8) >> 4, z = (C[2] + 8) >> 4;
     o.x = (uint16_t)(x > 65535 ? 65535 : x); o.y = (uint16_t)(y > 65535 ? 65535 : y); o.z = (uint16_t)(z > 65535 ? 65535 : z);
     gstore(f.out_xyz + i, o);
+    if (both) {
+      // The colour filter's cells are those of the smoothed positions: a point that lands in another cell is noted
+      // (k_smooth_moved_* move its sums) and carries its new cell index from here on.  Few points move at all (one
+      // in a few thousand), so the returning atomic on the frame's counter is no hot spot.
+      const uint32_t new_key = (cell_coord(o.z, G, w) * w + cell_coord(o.y, G, w)) * w + cell_coord(o.x, G, w);
+      if (new_key != own_key) {
+        const uint32_t at = atomicAdd(sg.moved_count + frame, 1u);
+        if (at < sg.moved_stride) sg.moved(frame)[at] = SmoothMoved{i, own_key};
+        sg.keys(frame)[i] = new_key;
+      }
+    }
+  }
+}
+
+// Both filters in one pass, after the geometry filter: (1) every noted point takes its count, colour and patch sums
+// from the cell it left to the cell it is in now (coordinate sums are not needed any more); (2) once all have moved,
+// both cells of every noted point are re-examined: the mixed bit is set or cleared, and flags are painted around a cell
+// that has become mixed (flags around a cell that no longer is stay — they only make a point look at its
+// neighbourhood in vain — and are un-painted with the rest by k_smooth_clear, which the painted bit tells).
+__global__ __launch_bounds__(256) void k_smooth_moved_sums(const DevFrame* __restrict__ frames, uint32_t first, SmoothGrid sg) {
+  const DevFrame& f = frames[first + blockIdx.y];
+  const uint32_t m = min(*gl(sg.moved_count + blockIdx.y), (uint32_t)sg.moved_stride);
+  for (uint32_t e = blockIdx.x * 256u + threadIdx.x; e < m; e += gridDim.x * 256u) {
+    const SmoothMoved mv = sg.moved(blockIdx.y)[e];
+    const uint32_t to = sg.keys(blockIdx.y)[mv.point], patch = gl(f.out_patch)[mv.point];
+    const vpcc_color3 col = gload(f.out_rgb + mv.point);
+    const uint32_t rgb[3] = {col.r, col.g, col.b};
+    SmoothCell* a = sg.cells(blockIdx.y) + mv.old_cell;
+    SmoothCell* b = sg.cells(blockIdx.y) + to;
+    atomicSub(&a->count, 1u); atomicAdd(&b->count, 1u);
+    atomicSub(&a->sp, patch); atomicAdd(&b->sp, patch);
+    const unsigned long long q = (unsigned long long)patch * patch;
+    atomicAdd(reinterpret_cast<unsigned long long*>(&a->sp2), 0ull - q);
+    atomicAdd(reinterpret_cast<unsigned long long*>(&b->sp2), q);
+    for (int c = 0; c < 3; ++c) {
+      atomicSub(&sg.color_cells(blockIdx.y)[mv.old_cell].s[c], rgb[c]);
+      atomicAdd(&sg.color_cells(blockIdx.y)[to].s[c], rgb[c]);
+    }
+  }
+}
+__global__ __launch_bounds__(256) void k_smooth_moved_mark(SmoothGrid sg, uint32_t w) {
+  const uint32_t m = min(*gl(sg.moved_count + blockIdx.y), (uint32_t)sg.moved_stride);
+  for (uint32_t e = blockIdx.x * 256u + threadIdx.x; e < 2u * m; e += gridDim.x * 256u) {
+    const SmoothMoved mv = sg.moved(blockIdx.y)[e >> 1];
+    const uint32_t key = (e & 1u) ? sg.keys(blockIdx.y)[mv.point] : mv.old_cell;
+    SmoothCell* cell = sg.cells(blockIdx.y) + key;
+    const SmoothCell c = gload(cell);
+    const bool mixed = cell_mixed(c);
+    // several noted points may share a cell: all compute the same bits from the same (final) sums
+    if (mixed && !(c.mixed & kSmoothPainted)) paint_flags(sg.flags(blockIdx.y), key, w, 1);
+    const uint32_t bits = (mixed ? kSmoothMixed : 0u) | ((mixed || (c.mixed & kSmoothPainted)) ? kSmoothPainted : 0u);
+    if (bits != c.mixed) cell->mixed = bits;
   }
 }
 
 __global__ __launch_bounds__(256) void k_smooth_apply_geometry(const DevFrame* __restrict__ frames, uint32_t first,
-                                                               SmoothGrid sg, uint32_t w, uint32_t G, uint32_t T) {
+                                                               SmoothGrid sg, uint32_t w, uint32_t G, uint32_t T, bool both) {
   const DevFrame& f = frames[first + blockIdx.y];
   const uint32_t n = min(*gl(f.n_points), f.capacity);
 #pragma unroll 1
   for (uint32_t c = 0; c < kSmoothChunks; ++c)
-    smooth_apply_geometry_point(f, blockIdx.y, (blockIdx.x * kSmoothChunks + c) * 256u + threadIdx.x, n, sg, w, G, T);
+    smooth_apply_geometry_point(f, blockIdx.y, (blockIdx.x * kSmoothChunks + c) * 256u + threadIdx.x, n, sg, w, G, T, both);
 }
 
 __device__ __forceinline__ void smooth_apply_color_point(const DevFrame& f, uint32_t frame, uint32_t i, uint32_t n,
-                                                         SmoothGrid sg, uint32_t w, uint32_t G, uint32_t Ts, uint32_t Td) {
+                                                         SmoothGrid sg, uint32_t w, uint32_t G, uint32_t Ts, uint32_t Td, bool both) {
   if (i >= n) return;
   if (!sg.flags(frame)[sg.keys(frame)[i]]) return;        // no mixed cell anywhere near this point (k_smooth_mark)
   const vpcc_point3 pt = gload(f.out_xyz + i);
@@ -417,6 +505,16 @@ __device__ __forceinline__ void smooth_apply_color_point(const DevFrame& f, uint
   for (int a = 0; a < 3; ++a) axis_setup(p[a], G, w, s[a], wt[a]);
   Hood h;
   if (!load_hood(sg.cells(frame), s, w, h)) return;
+  if (both) {                                               // the colour sums live next to the cells, not in them
+    const SmoothColorCell* cg = sg.color_cells(frame);
+#pragma unroll
+    for (int d = 0; d < 8; ++d)
+      if (h.inside[d] && h.c[d].count) {
+        const int32_t cx = s[0] + (d & 1), cy = s[1] + ((d >> 1) & 1), cz = s[2] + (d >> 2);
+        const SmoothColorCell cc = gload(cg + ((size_t)cz * w + cy) * w + cx);
+        h.c[d].s[0] = cc.s[0]; h.c[d].s[1] = cc.s[1]; h.c[d].s[2] = cc.s[2];
+      }
+  }
   const vpcc_color3 col = gload(f.out_rgb + i);
   const int64_t cl[3] = {col.r, col.g, col.b};
   // the point's own cell is one of the eight: index of (q - s) per axis
@@ -441,7 +539,7 @@ __device__ __forceinline__ void smooth_apply_color_point(const DevFrame& f, uint
     const int64_t W = wt[0][d & 1] * wt[1][(d >> 1) & 1] * wt[2][d >> 2];
     num[0] += W * c.s[0]; num[1] += W * c.s[1]; num[2] += W * c.s[2];
     den += W * c.count;
-    mixed |= c.mixed != 0;
+    mixed |= (c.mixed & kSmoothMixed) != 0;
   }
   if (!mixed || den <= 0) return;
   int64_t m[3], dist = 0;
@@ -459,12 +557,12 @@ __device__ __forceinline__ void smooth_apply_color_point(const DevFrame& f, uint
 }
 
 __global__ __launch_bounds__(256) void k_smooth_apply_color(const DevFrame* __restrict__ frames, uint32_t first,
-                                                            SmoothGrid sg, uint32_t w, uint32_t G, uint32_t Ts, uint32_t Td) {
+                                                            SmoothGrid sg, uint32_t w, uint32_t G, uint32_t Ts, uint32_t Td, bool both) {
   const DevFrame& f = frames[first + blockIdx.y];
   const uint32_t n = min(*gl(f.n_points), f.capacity);
 #pragma unroll 1
   for (uint32_t c = 0; c < kSmoothChunks; ++c)
-    smooth_apply_color_point(f, blockIdx.y, (blockIdx.x * kSmoothChunks + c) * 256u + threadIdx.x, n, sg, w, G, Ts, Td);
+    smooth_apply_color_point(f, blockIdx.y, (blockIdx.x * kSmoothChunks + c) * 256u + threadIdx.x, n, sg, w, G, Ts, Td, both);
 }
 
 
@@ -475,16 +573,23 @@ void launch_smooth_stats(const DevFrame* d_frames, uint32_t first, uint32_t coun
                      (hipStream_t)stream, d_frames, first, sg, w, G, mode);
 }
 void launch_smooth_apply_geometry(const DevFrame* d_frames, uint32_t first, uint32_t count, uint32_t max_points,
-                                  SmoothGrid sg, uint32_t w, uint32_t G, uint32_t T, void* stream) {
+                                  SmoothGrid sg, uint32_t w, uint32_t G, uint32_t T, bool both, void* stream) {
   if (!count || !max_points) return;
   hipLaunchKernelGGL(k_smooth_apply_geometry, dim3((max_points + 256 * kSmoothChunks - 1) / (256 * kSmoothChunks), count), dim3(256),
-                     0, (hipStream_t)stream, d_frames, first, sg, w, G, T);
+                     0, (hipStream_t)stream, d_frames, first, sg, w, G, T, both);
 }
 void launch_smooth_apply_color(const DevFrame* d_frames, uint32_t first, uint32_t count, uint32_t max_points,
-                               SmoothGrid sg, uint32_t w, uint32_t G, uint32_t Ts, uint32_t Td, void* stream) {
+                               SmoothGrid sg, uint32_t w, uint32_t G, uint32_t Ts, uint32_t Td, bool both, void* stream) {
   if (!count || !max_points) return;
   hipLaunchKernelGGL(k_smooth_apply_color, dim3((max_points + 256 * kSmoothChunks - 1) / (256 * kSmoothChunks), count), dim3(256), 0,
-                     (hipStream_t)stream, d_frames, first, sg, w, G, Ts, Td);
+                     (hipStream_t)stream, d_frames, first, sg, w, G, Ts, Td, both);
+}
+void launch_smooth_moved(const DevFrame* d_frames, uint32_t first, uint32_t count, SmoothGrid sg, uint32_t w, uint32_t G,
+                         void* stream) {
+  if (!count) return;
+  (void)G;
+  hipLaunchKernelGGL(k_smooth_moved_sums, dim3(16, count), dim3(256), 0, (hipStream_t)stream, d_frames, first, sg);
+  hipLaunchKernelGGL(k_smooth_moved_mark, dim3(16, count), dim3(256), 0, (hipStream_t)stream, sg, w);
 }
 void launch_smooth_mark(const DevFrame* d_frames, uint32_t first, uint32_t count, uint32_t max_points, SmoothGrid sg,
                         uint32_t w, void* stream) {
@@ -493,10 +598,10 @@ void launch_smooth_mark(const DevFrame* d_frames, uint32_t first, uint32_t count
                      first, sg, w);
 }
 void launch_smooth_clear(const DevFrame* d_frames, uint32_t first, uint32_t count, uint32_t max_points, SmoothGrid sg,
-                         uint32_t w, void* stream) {
+                         uint32_t w, bool both, void* stream) {
   if (!count || !max_points) return;
   hipLaunchKernelGGL(k_smooth_clear, dim3((max_points + 1023) / 1024, count), dim3(256), 0, (hipStream_t)stream, d_frames,
-                     first, sg, w);
+                     first, sg, w, both);
 }
 
 }  // namespace vpcc
