@@ -109,10 +109,11 @@ struct SmoothCell {
 static_assert(sizeof(SmoothCell) == 32, "SmoothCell is 32 B");
 constexpr uint32_t kSmoothMixed = 1u, kSmoothPainted = 2u;
 // R, G, B sums of a cell when ONE statistics pass serves both filters (same grid size): a parallel array.
-struct SmoothColorCell { uint32_t s[3], pad; };
+// What the colour filter needs of a cell, in 16 bytes: the point count with the mixed bit above it, and the sums.
+struct SmoothColorCell { uint32_t count, s[3]; };
+constexpr uint32_t kColorCellMixed = 1u << 31;
 static_assert(sizeof(SmoothColorCell) == 16, "SmoothColorCell is 16 B");
-// A point the geometry filter moved into another cell: (point index, cell it left).
-struct SmoothMoved { uint32_t point, old_cell; };
+
 
 #if defined(__HIPCC__)
 #define VPCC_HD __host__ __device__
@@ -133,12 +134,14 @@ struct SmoothGrid {
   size_t list_stride;         //   points — the distinct cells the wave's points fall into, kSmoothNoCell where unused; or
                               //   kSmoothListOverflow in entry 0: the cells of these 64 points are in the key array instead
   size_t color_offset;        // both filters in one pass: bytes from the slot's start to its w^3 colour cells (else 0)
-  SmoothMoved* moved_base;    //   ... the points the geometry filter moved to another cell, frame slot j at + j * moved_stride,
-  size_t moved_stride;        //   and how many (one counter per frame slot, zeroed by vpcc_gof_smooth)
-  uint32_t* moved_count;
+  uint64_t* moved_base;       //   ... which points the geometry filter moved: one bit per point, a 64-bit word per wave of 64
+  size_t moved_stride;        //   points (frame slot j at + j * moved_stride; zeroed by vpcc_gof_smooth before every pass),
+  uint32_t* oldkey_base;      //   and the cell a moved point LEFT if it changed cell (frame slot j at + j * key_stride; written
+                              //   for those points only)
   VPCC_HD SmoothCell* cells(uint32_t j) const { return reinterpret_cast<SmoothCell*>(base + j * slot_bytes); }
   VPCC_HD SmoothColorCell* color_cells(uint32_t j) const { return reinterpret_cast<SmoothColorCell*>(base + j * slot_bytes + color_offset); }
-  VPCC_HD SmoothMoved* moved(uint32_t j) const { return moved_base + j * moved_stride; }
+  VPCC_HD uint64_t* moved(uint32_t j) const { return moved_base + j * moved_stride; }
+  VPCC_HD uint32_t* old_keys(uint32_t j) const { return oldkey_base + j * key_stride; }
   VPCC_HD unsigned char* flags(uint32_t j) const { return base + j * slot_bytes + flags_offset; }
   VPCC_HD uint32_t* keys(uint32_t j) const { return key_base + j * key_stride; }
   VPCC_HD uint32_t* lists(uint32_t j) const { return list_base + j * list_stride; }
@@ -152,8 +155,8 @@ void launch_smooth_apply_geometry(const DevFrame* d_frames, uint32_t first, uint
                                   SmoothGrid sg, uint32_t w, uint32_t G, uint32_t T, bool both, void* stream);
 void launch_smooth_apply_color(const DevFrame* d_frames, uint32_t first, uint32_t count, uint32_t max_points,
                                SmoothGrid sg, uint32_t w, uint32_t G, uint32_t Ts, uint32_t Td, bool both, void* stream);
-void launch_smooth_moved(const DevFrame* d_frames, uint32_t first, uint32_t count, SmoothGrid sg, uint32_t w, uint32_t G,
-                         void* stream);
+void launch_smooth_moved(const DevFrame* d_frames, uint32_t first, uint32_t count, uint32_t max_points, SmoothGrid sg,
+                         uint32_t w, uint32_t G, void* stream);
 void launch_smooth_mark(const DevFrame* d_frames, uint32_t first, uint32_t count, uint32_t max_points, SmoothGrid sg,
                         uint32_t w, void* stream);
 void launch_smooth_clear(const DevFrame* d_frames, uint32_t first, uint32_t count, uint32_t max_points, SmoothGrid sg,

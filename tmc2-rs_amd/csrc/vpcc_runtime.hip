@@ -105,7 +105,7 @@ struct vpcc_gof {
   size_t smooth_bytes = 0;
   bool smooth_clean = false;           // the scratch is all-zero (the invariant between launches)
   void* smooth_keys = nullptr;         // cell index of every point of every frame (capacity words per frame), then the cell lists
-  void* smooth_moved = nullptr;        // both filters in one pass: points moved to another cell (capacity entries per frame), counters
+  void* smooth_moved = nullptr;        // both filters in one pass: which points moved (a bit each), and the cell each left
 };
 
 namespace {
@@ -1090,12 +1090,12 @@ extern "C" int vpcc_gof_smooth(vpcc_gof* g, uint32_t first, uint32_t count, cons
     sg.key_base = (uint32_t*)g->smooth_keys;
     sg.list_base = sg.key_base + sg.key_stride * g->n_frames;
     if (both) {
-      sg.moved_stride = g->capacity;
+      sg.moved_stride = align_up((g->capacity + 63) / 64, 32);
       if (!g->smooth_moved)
-        HIP_TRY(ctx, hipMalloc(&g->smooth_moved, sizeof(SmoothMoved) * sg.moved_stride * g->n_frames + sizeof(uint32_t) * g->n_frames));
-      sg.moved_base = (SmoothMoved*)g->smooth_moved;
-      sg.moved_count = (uint32_t*)(sg.moved_base + sg.moved_stride * g->n_frames);
-      HIP_TRY(ctx, hipMemsetAsync(sg.moved_count, 0, sizeof(uint32_t) * g->n_frames, s));
+        HIP_TRY(ctx, hipMalloc(&g->smooth_moved, (sizeof(uint64_t) * sg.moved_stride + sizeof(uint32_t) * sg.key_stride) * g->n_frames));
+      sg.moved_base = (uint64_t*)g->smooth_moved;
+      sg.oldkey_base = (uint32_t*)(sg.moved_base + sg.moved_stride * g->n_frames);
+      HIP_TRY(ctx, hipMemsetAsync(sg.moved_base, 0, sizeof(uint64_t) * sg.moved_stride * std::min<size_t>(count, g->n_frames), s));
     }
     const uint32_t chunk = (uint32_t)std::max<size_t>(1, std::min<size_t>(count, (size_t(16) << 30) / sg.slot_bytes));
     const size_t need = sg.slot_bytes * chunk;
@@ -1133,7 +1133,7 @@ extern "C" int vpcc_gof_smooth(vpcc_gof* g, uint32_t first, uint32_t count, cons
       }
       if (both) {
         T.begin("k_smooth_moved");
-        launch_smooth_moved(g->d_frames, c0, c, sg, w, G, s);
+        launch_smooth_moved(g->d_frames, c0, c, max_points, sg, w, G, s);
         T.end();
       }
       if (!geo || both) {

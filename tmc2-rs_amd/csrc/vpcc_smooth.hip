@@ -211,7 +211,8 @@ __device__ __forceinline__ void smooth_stats_chunk(const DevFrame& f, uint32_t f
           if (j < ncell) {
             const uint32_t sl = T.lid[j];
             const uint32_t rg = T.acc[3][sl];
-            const uint64_t val = t == 0 ? (uint64_t)(rg & 0xFFFFu) | ((uint64_t)(rg >> 16) << 32) : (uint64_t)T.acc[4][sl];
+            const uint64_t val = t == 0 ? (uint64_t)(T.acc[2][sl] >> 22) | ((uint64_t)(rg & 0xFFFFu) << 32)        // {count, R}
+                                        : (uint64_t)(rg >> 16) | ((uint64_t)T.acc[4][sl] << 32);                    // {G, B}
             atomicAdd(reinterpret_cast<unsigned long long*>(cgrid + T.key[sl]) + t, (unsigned long long)val);
           }
         }
@@ -253,7 +254,7 @@ __device__ __forceinline__ void smooth_stats_chunk(const DevFrame& f, uint32_t f
       const uint32_t rg = wave_reduce<false>(in ? c01 : 0u), bb = wave_reduce<false>(in ? c2 : 0u);
       if (lane < 2u)
         atomicAdd(reinterpret_cast<unsigned long long*>(cgrid + k) + lane,
-                  (unsigned long long)(lane == 0 ? (uint64_t)(rg & 0xFFFFu) | ((uint64_t)(rg >> 16) << 32) : (uint64_t)bb));
+                  (unsigned long long)(lane == 0 ? (uint64_t)cnt | ((uint64_t)(rg & 0xFFFFu) << 32) : (uint64_t)(rg >> 16) | ((uint64_t)bb << 32)));
     }
     todo &= ~mask;
   }
@@ -336,6 +337,10 @@ __global__ __launch_bounds__(256) void k_smooth_mark(const DevFrame* __restrict_
     if (cell_mixed(gload(sg.cells(blockIdx.y) + k[q]))) {
       paint_flags(sg.flags(blockIdx.y), k[q], w, 1);
       (sg.cells(blockIdx.y) + k[q])->mixed = kSmoothMixed | kSmoothPainted;   // for the apply kernels: the 64-bit test once per cell, not per point
+      if (sg.color_offset) {                                                   // both filters: the colour filter reads the colour cells only
+        SmoothColorCell* cc = sg.color_cells(blockIdx.y) + k[q];
+        cc->count = cc->count | kColorCellMixed;
+      }
     }
 }
 
@@ -345,12 +350,12 @@ __global__ __launch_bounds__(256) void k_smooth_mark(const DevFrame* __restrict_
 __device__ __forceinline__ void clear_cell(const SmoothGrid& sg, uint32_t frame, uint32_t key, uint32_t w, bool both) {
   SmoothCell* cell = sg.cells(frame) + key;
   const SmoothCell seen = gload(cell);
-  if (both) {
+  if (!(seen.count | seen.s[0] | seen.s[1] | seen.s[2] | (uint32_t)seen.sp2 | (uint32_t)(seen.sp2 >> 32) | seen.sp | seen.mixed))
+    return;                                                 // another entry of the same cell has cleared it
+  if (both) {                                               // (a colour cell holds nothing its cell does not: count, sums of those points)
     uint4* cc = reinterpret_cast<uint4*>(sg.color_cells(frame) + key);
     *cc = make_uint4(0u, 0u, 0u, 0u);
   }
-  if (!(seen.count | seen.s[0] | seen.s[1] | seen.s[2] | (uint32_t)seen.sp2 | (uint32_t)(seen.sp2 >> 32) | seen.sp | seen.mixed))
-    return;                                                 // another entry of the same cell has cleared it
   if (seen.mixed & kSmoothPainted) paint_flags(sg.flags(frame), key, w, 0);
   uint4* c = reinterpret_cast<uint4*>(cell);
   c[0] = make_uint4(0u, 0u, 0u, 0u); c[1] = make_uint4(0u, 0u, 0u, 0u);
@@ -359,18 +364,22 @@ __global__ __launch_bounds__(256) void k_smooth_clear(const DevFrame* __restrict
                                                       uint32_t w, bool both) {
   const DevFrame& f = frames[first + blockIdx.y];
   const uint32_t n = min(*gl(f.n_points), f.capacity);
-  if (both) {                                               // (few: grid-stride over the workgroups of the frame)
-    const uint32_t m = min(*gl(sg.moved_count + blockIdx.y), (uint32_t)sg.moved_stride);
-    for (uint32_t e = blockIdx.x * 256u + threadIdx.x; e < m; e += gridDim.x * 256u) {
-      const SmoothMoved mv = sg.moved(blockIdx.y)[e];
-      clear_cell(sg, blockIdx.y, sg.keys(blockIdx.y)[mv.point], w, true);
-      clear_cell(sg, blockIdx.y, mv.old_cell, w, true);        // (a wave whose list overflowed finds its cells through the
-    }                                                          //  key array, where this point's entry has changed)
-  }
   if (blockIdx.x * 1024u >= n) return;
   uint32_t k[4];
   const uint32_t m = listed_cells(sg, blockIdx.y, blockIdx.x * 256u + threadIdx.x, n, k);
   for (uint32_t q = 0; q < m; ++q) clear_cell(sg, blockIdx.y, k[q], w, both);
+  if (both) {
+    // the cells moved points went INTO are in no list, and a wave whose list overflowed finds its cells through the
+    // key array, where a moved point's entry has changed: the first of a wave's sixteen threads sees to its moved points
+    const uint32_t e = blockIdx.x * 256u + threadIdx.x, wave = e / kSmoothListLen;
+    if (e % kSmoothListLen == 0 && wave * 64u < n)
+      for (uint64_t mask = sg.moved(blockIdx.y)[wave]; mask; mask &= mask - 1ull) {
+        const uint32_t i = wave * 64u + (uint32_t)__builtin_ctzll(mask);
+        const uint32_t now = sg.keys(blockIdx.y)[i], was = sg.old_keys(blockIdx.y)[i];
+        clear_cell(sg, blockIdx.y, now, w, true);
+        if (was != now) clear_cell(sg, blockIdx.y, was, w, true);
+      }
+  }
 }
 
 namespace {
@@ -394,11 +403,11 @@ __device__ __forceinline__ bool load_hood(const SmoothCell* grid, const int32_t 
 }
 }  // namespace
 
-__device__ __forceinline__ void smooth_apply_geometry_point(const DevFrame& f, uint32_t frame, uint32_t i, uint32_t n,
-                                                            SmoothGrid sg, uint32_t w, uint32_t G, uint32_t T, bool both) {
-  if (i >= n) return;
-  const uint32_t own_key = sg.keys(frame)[i];
-  if (!sg.flags(frame)[own_key]) return;                   // no mixed cell anywhere near this point (k_smooth_mark)
+// Returns whether the point was moved.
+__device__ __forceinline__ bool smooth_apply_geometry_point(const DevFrame& f, uint32_t frame, uint32_t i, uint32_t n,
+                                                            SmoothGrid sg, uint32_t w, uint32_t G, uint32_t T) {
+  if (i >= n) return false;
+  if (!sg.flags(frame)[sg.keys(frame)[i]]) return false;   // no mixed cell anywhere near this point (k_smooth_mark)
   const vpcc_point3 pt = gload(f.out_xyz + i);
   const uint32_t p[3] = {pt.x, pt.y, pt.z};
   int32_t s[3];
@@ -406,7 +415,7 @@ __device__ __forceinline__ void smooth_apply_geometry_point(const DevFrame& f, u
 #pragma unroll
   for (int a = 0; a < 3; ++a) axis_setup(p[a], G, w, s[a], wt[a]);
   Hood h;
-  if (!load_hood(sg.cells(frame), s, w, h)) return;
+  if (!load_hood(sg.cells(frame), s, w, h)) return false;
   int64_t num[3] = {0, 0, 0}, den = 0;
 #pragma unroll
   for (int d = 0; d < 8; ++d) {
@@ -416,7 +425,7 @@ __device__ __forceinline__ void smooth_apply_geometry_point(const DevFrame& f, u
     num[0] += W * c.s[0]; num[1] += W * c.s[1]; num[2] += W * c.s[2];
     den += W * c.count;
   }
-  if (den <= 0) return;
+  if (den <= 0) return false;
   int64_t C[3], d2 = 0;
 #pragma unroll
   for (int a = 0; a < 3; ++a) {
@@ -429,58 +438,72 @@ __device__ __forceinline__ void smooth_apply_geometry_point(const DevFrame& f, u
     const int64_t x = (C[0] + 8) >> 4, y = (C[1] + 8) >> 4, z = (C[2] + 8) >> 4;
     o.x = (uint16_t)(x > 65535 ? 65535 : x); o.y = (uint16_t)(y > 65535 ? 65535 : y); o.z = (uint16_t)(z > 65535 ? 65535 : z);
     gstore(f.out_xyz + i, o);
-    if (both) {
-      // The colour filter's cells are those of the smoothed positions: a point that lands in another cell is noted
-      // (k_smooth_moved_* move its sums) and carries its new cell index from here on.  Few points move at all (one
-      // in a few thousand), so the returning atomic on the frame's counter is no hot spot.
-      const uint32_t new_key = (cell_coord(o.z, G, w) * w + cell_coord(o.y, G, w)) * w + cell_coord(o.x, G, w);
-      if (new_key != own_key) {
-        const uint32_t at = atomicAdd(sg.moved_count + frame, 1u);
-        if (at < sg.moved_stride) sg.moved(frame)[at] = SmoothMoved{i, own_key};
-        sg.keys(frame)[i] = new_key;
-      }
-    }
+    return true;
   }
+  return false;
 }
 
-// Both filters in one pass, after the geometry filter: (1) every noted point takes its count, colour and patch sums
-// from the cell it left to the cell it is in now (coordinate sums are not needed any more); (2) once all have moved,
-// both cells of every noted point are re-examined: the mixed bit is set or cleared, and flags are painted around a cell
-// that has become mixed (flags around a cell that no longer is stay — they only make a point look at its
-// neighbourhood in vain — and are un-painted with the rest by k_smooth_clear, which the painted bit tells).
-__global__ __launch_bounds__(256) void k_smooth_moved_sums(const DevFrame* __restrict__ frames, uint32_t first, SmoothGrid sg) {
+// Both filters in one pass, after the geometry filter — a thread per wave of 64 points, which walks the wave's moved
+// bits (one point in a few thousand moves): (1) a moved point that is in another cell now takes its count, colour and
+// patch sums from the cell it left to the cell it is in (coordinate sums are not needed any more) and has both cells
+// noted (key array: the new one; old-key array: the one it left); (2) once all have moved, both cells of every such
+// point are re-examined: the mixed bit is set or cleared, and flags are painted around a cell that has become mixed
+// (flags around a cell that no longer is stay — they only make a point look at its neighbourhood in vain — and are
+// un-painted with the rest by k_smooth_clear, which the painted bit tells).
+__global__ __launch_bounds__(256) void k_smooth_moved_sums(const DevFrame* __restrict__ frames, uint32_t first, SmoothGrid sg,
+                                                           uint32_t w, uint32_t G) {
   const DevFrame& f = frames[first + blockIdx.y];
-  const uint32_t m = min(*gl(sg.moved_count + blockIdx.y), (uint32_t)sg.moved_stride);
-  for (uint32_t e = blockIdx.x * 256u + threadIdx.x; e < m; e += gridDim.x * 256u) {
-    const SmoothMoved mv = sg.moved(blockIdx.y)[e];
-    const uint32_t to = sg.keys(blockIdx.y)[mv.point], patch = gl(f.out_patch)[mv.point];
-    const vpcc_color3 col = gload(f.out_rgb + mv.point);
+  const uint32_t n = min(*gl(f.n_points), f.capacity);
+  const uint32_t wave = blockIdx.x * 256u + threadIdx.x;
+  if (wave * 64u >= n) return;
+  for (uint64_t mask = sg.moved(blockIdx.y)[wave]; mask; mask &= mask - 1ull) {
+    const uint32_t i = wave * 64u + (uint32_t)__builtin_ctzll(mask);
+    const vpcc_point3 pt = gload(f.out_xyz + i);
+    const uint32_t from = sg.keys(blockIdx.y)[i];
+    const uint32_t to = (cell_coord(pt.z, G, w) * w + cell_coord(pt.y, G, w)) * w + cell_coord(pt.x, G, w);
+    sg.old_keys(blockIdx.y)[i] = from;
+    if (to == from) continue;                                 // moved inside its cell
+    sg.keys(blockIdx.y)[i] = to;                              // the point's cell from here on
+    const uint32_t patch = gl(f.out_patch)[i];
+    const vpcc_color3 col = gload(f.out_rgb + i);
     const uint32_t rgb[3] = {col.r, col.g, col.b};
-    SmoothCell* a = sg.cells(blockIdx.y) + mv.old_cell;
+    SmoothCell* a = sg.cells(blockIdx.y) + from;
     SmoothCell* b = sg.cells(blockIdx.y) + to;
+    SmoothColorCell* ca = sg.color_cells(blockIdx.y) + from;
+    SmoothColorCell* cb = sg.color_cells(blockIdx.y) + to;
     atomicSub(&a->count, 1u); atomicAdd(&b->count, 1u);
+    atomicSub(&ca->count, 1u); atomicAdd(&cb->count, 1u);       // (the mixed bit above the count is not touched: count >= 1)
     atomicSub(&a->sp, patch); atomicAdd(&b->sp, patch);
     const unsigned long long q = (unsigned long long)patch * patch;
     atomicAdd(reinterpret_cast<unsigned long long*>(&a->sp2), 0ull - q);
     atomicAdd(reinterpret_cast<unsigned long long*>(&b->sp2), q);
     for (int c = 0; c < 3; ++c) {
-      atomicSub(&sg.color_cells(blockIdx.y)[mv.old_cell].s[c], rgb[c]);
-      atomicAdd(&sg.color_cells(blockIdx.y)[to].s[c], rgb[c]);
+      atomicSub(&ca->s[c], rgb[c]);
+      atomicAdd(&cb->s[c], rgb[c]);
     }
   }
 }
-__global__ __launch_bounds__(256) void k_smooth_moved_mark(SmoothGrid sg, uint32_t w) {
-  const uint32_t m = min(*gl(sg.moved_count + blockIdx.y), (uint32_t)sg.moved_stride);
-  for (uint32_t e = blockIdx.x * 256u + threadIdx.x; e < 2u * m; e += gridDim.x * 256u) {
-    const SmoothMoved mv = sg.moved(blockIdx.y)[e >> 1];
-    const uint32_t key = (e & 1u) ? sg.keys(blockIdx.y)[mv.point] : mv.old_cell;
-    SmoothCell* cell = sg.cells(blockIdx.y) + key;
-    const SmoothCell c = gload(cell);
-    const bool mixed = cell_mixed(c);
-    // several noted points may share a cell: all compute the same bits from the same (final) sums
-    if (mixed && !(c.mixed & kSmoothPainted)) paint_flags(sg.flags(blockIdx.y), key, w, 1);
-    const uint32_t bits = (mixed ? kSmoothMixed : 0u) | ((mixed || (c.mixed & kSmoothPainted)) ? kSmoothPainted : 0u);
-    if (bits != c.mixed) cell->mixed = bits;
+__global__ __launch_bounds__(256) void k_smooth_moved_mark(const DevFrame* __restrict__ frames, uint32_t first, SmoothGrid sg,
+                                                           uint32_t w) {
+  const DevFrame& f = frames[first + blockIdx.y];
+  const uint32_t n = min(*gl(f.n_points), f.capacity);
+  const uint32_t wave = blockIdx.x * 256u + threadIdx.x;
+  if (wave * 64u >= n) return;
+  for (uint64_t mask = sg.moved(blockIdx.y)[wave]; mask; mask &= mask - 1ull) {
+    const uint32_t i = wave * 64u + (uint32_t)__builtin_ctzll(mask);
+    const uint32_t now = sg.keys(blockIdx.y)[i], was = sg.old_keys(blockIdx.y)[i];
+    if (now == was) continue;
+    for (int side = 0; side < 2; ++side) {
+      const uint32_t key = side ? now : was;
+      SmoothCell* cell = sg.cells(blockIdx.y) + key;
+      const SmoothCell c = gload(cell);
+      const bool mixed = cell_mixed(c);
+      // several moved points may share a cell: all compute the same bits from the same (final) sums
+      if (mixed && !(c.mixed & kSmoothPainted)) paint_flags(sg.flags(blockIdx.y), key, w, 1);
+      const uint32_t bits = (mixed ? kSmoothMixed : 0u) | ((mixed || (c.mixed & kSmoothPainted)) ? kSmoothPainted : 0u);
+      if (bits != c.mixed) cell->mixed = bits;
+      sg.color_cells(blockIdx.y)[key].count = c.count | (mixed ? kColorCellMixed : 0u);
+    }
   }
 }
 
@@ -490,7 +513,18 @@ __global__ __launch_bounds__(256) void k_smooth_apply_geometry(const DevFrame* _
   const uint32_t n = min(*gl(f.n_points), f.capacity);
 #pragma unroll 1
   for (uint32_t c = 0; c < kSmoothChunks; ++c)
-    smooth_apply_geometry_point(f, blockIdx.y, (blockIdx.x * kSmoothChunks + c) * 256u + threadIdx.x, n, sg, w, G, T, both);
+  {
+    const uint32_t i = (blockIdx.x * kSmoothChunks + c) * 256u + threadIdx.x;
+    const bool moved = smooth_apply_geometry_point(f, blockIdx.y, i, n, sg, w, G, T);
+    // The colour filter's cells are those of the smoothed positions: which points moved is noted, one bit per point
+    // (a word per wave, zeroed beforehand and written by the few waves that moved a point; no counter to fight over —
+    // a list fed by returning atomics on one counter per frame cost this kernel 0.15 ms, a word stored by EVERY wave
+    // 0.09), and k_smooth_moved_* take a moved point's sums to its new cell if it has one.
+    if (both) {
+      const uint64_t mask = __ballot(moved);
+      if (mask != 0 && (threadIdx.x & 63u) == 0) sg.moved(blockIdx.y)[i >> 6] = mask;     // (all-zero before: vpcc_gof_smooth)
+    }
+  }
 }
 
 __device__ __forceinline__ void smooth_apply_color_point(const DevFrame& f, uint32_t frame, uint32_t i, uint32_t n,
@@ -504,16 +538,25 @@ __device__ __forceinline__ void smooth_apply_color_point(const DevFrame& f, uint
 #pragma unroll
   for (int a = 0; a < 3; ++a) axis_setup(p[a], G, w, s[a], wt[a]);
   Hood h;
-  if (!load_hood(sg.cells(frame), s, w, h)) return;
-  if (both) {                                               // the colour sums live next to the cells, not in them
+  if (both) {                                               // both filters in one pass: the 16-byte colour cells say it all
     const SmoothColorCell* cg = sg.color_cells(frame);
+    bool any = false;
 #pragma unroll
-    for (int d = 0; d < 8; ++d)
-      if (h.inside[d] && h.c[d].count) {
-        const int32_t cx = s[0] + (d & 1), cy = s[1] + ((d >> 1) & 1), cz = s[2] + (d >> 2);
+    for (int d = 0; d < 8; ++d) {
+      const int32_t cx = s[0] + (d & 1), cy = s[1] + ((d >> 1) & 1), cz = s[2] + (d >> 2);
+      h.inside[d] = !(cx < 0 || cy < 0 || cz < 0 || cx >= (int32_t)w || cy >= (int32_t)w || cz >= (int32_t)w);
+      h.c[d] = SmoothCell{};
+      if (h.inside[d]) {
         const SmoothColorCell cc = gload(cg + ((size_t)cz * w + cy) * w + cx);
+        h.c[d].count = cc.count & ~kColorCellMixed;
         h.c[d].s[0] = cc.s[0]; h.c[d].s[1] = cc.s[1]; h.c[d].s[2] = cc.s[2];
+        h.c[d].mixed = (cc.count & kColorCellMixed) ? kSmoothMixed : 0u;
       }
+      any |= h.c[d].mixed != 0;
+    }
+    if (!any) return;
+  } else if (!load_hood(sg.cells(frame), s, w, h)) {
+    return;
   }
   const vpcc_color3 col = gload(f.out_rgb + i);
   const int64_t cl[3] = {col.r, col.g, col.b};
@@ -584,12 +627,12 @@ void launch_smooth_apply_color(const DevFrame* d_frames, uint32_t first, uint32_
   hipLaunchKernelGGL(k_smooth_apply_color, dim3((max_points + 256 * kSmoothChunks - 1) / (256 * kSmoothChunks), count), dim3(256), 0,
                      (hipStream_t)stream, d_frames, first, sg, w, G, Ts, Td, both);
 }
-void launch_smooth_moved(const DevFrame* d_frames, uint32_t first, uint32_t count, SmoothGrid sg, uint32_t w, uint32_t G,
-                         void* stream) {
-  if (!count) return;
-  (void)G;
-  hipLaunchKernelGGL(k_smooth_moved_sums, dim3(16, count), dim3(256), 0, (hipStream_t)stream, d_frames, first, sg);
-  hipLaunchKernelGGL(k_smooth_moved_mark, dim3(16, count), dim3(256), 0, (hipStream_t)stream, sg, w);
+void launch_smooth_moved(const DevFrame* d_frames, uint32_t first, uint32_t count, uint32_t max_points, SmoothGrid sg,
+                         uint32_t w, uint32_t G, void* stream) {
+  if (!count || !max_points) return;
+  const dim3 grid(((max_points + 63) / 64 + 255) / 256, count);
+  hipLaunchKernelGGL(k_smooth_moved_sums, grid, dim3(256), 0, (hipStream_t)stream, d_frames, first, sg, w, G);
+  hipLaunchKernelGGL(k_smooth_moved_mark, grid, dim3(256), 0, (hipStream_t)stream, d_frames, first, sg, w);
 }
 void launch_smooth_mark(const DevFrame* d_frames, uint32_t first, uint32_t count, uint32_t max_points, SmoothGrid sg,
                         uint32_t w, void* stream) {
