@@ -403,11 +403,10 @@ __device__ __forceinline__ bool load_hood(const SmoothCell* grid, const int32_t 
 }
 }  // namespace
 
-// Returns whether the point was moved.
-__device__ __forceinline__ bool smooth_apply_geometry_point(const DevFrame& f, uint32_t frame, uint32_t i, uint32_t n,
-                                                            SmoothGrid sg, uint32_t w, uint32_t G, uint32_t T) {
-  if (i >= n) return false;
-  if (!sg.flags(frame)[sg.keys(frame)[i]]) return false;   // no mixed cell anywhere near this point (k_smooth_mark)
+__device__ __forceinline__ void smooth_apply_geometry_point(const DevFrame& f, uint32_t frame, uint32_t i, uint32_t n,
+                                                            SmoothGrid sg, uint32_t w, uint32_t G, uint32_t T, bool both) {
+  if (i >= n) return;
+  if (!sg.flags(frame)[sg.keys(frame)[i]]) return;        // no mixed cell anywhere near this point (k_smooth_mark)
   const vpcc_point3 pt = gload(f.out_xyz + i);
   const uint32_t p[3] = {pt.x, pt.y, pt.z};
   int32_t s[3];
@@ -415,7 +414,7 @@ __device__ __forceinline__ bool smooth_apply_geometry_point(const DevFrame& f, u
 #pragma unroll
   for (int a = 0; a < 3; ++a) axis_setup(p[a], G, w, s[a], wt[a]);
   Hood h;
-  if (!load_hood(sg.cells(frame), s, w, h)) return false;
+  if (!load_hood(sg.cells(frame), s, w, h)) return;
   int64_t num[3] = {0, 0, 0}, den = 0;
 #pragma unroll
   for (int d = 0; d < 8; ++d) {
@@ -425,7 +424,7 @@ __device__ __forceinline__ bool smooth_apply_geometry_point(const DevFrame& f, u
     num[0] += W * c.s[0]; num[1] += W * c.s[1]; num[2] += W * c.s[2];
     den += W * c.count;
   }
-  if (den <= 0) return false;
+  if (den <= 0) return;
   int64_t C[3], d2 = 0;
 #pragma unroll
   for (int a = 0; a < 3; ++a) {
@@ -438,9 +437,13 @@ __device__ __forceinline__ bool smooth_apply_geometry_point(const DevFrame& f, u
     const int64_t x = (C[0] + 8) >> 4, y = (C[1] + 8) >> 4, z = (C[2] + 8) >> 4;
     o.x = (uint16_t)(x > 65535 ? 65535 : x); o.y = (uint16_t)(y > 65535 ? 65535 : y); o.z = (uint16_t)(z > 65535 ? 65535 : z);
     gstore(f.out_xyz + i, o);
-    return true;
+    // The colour filter's cells are those of the smoothed positions: which points moved is noted, one bit per point
+    // (a word per wave of 64 points, all-zero before: vpcc_gof_smooth), and k_smooth_moved_* take a moved point's sums
+    // to its new cell if it has one.  One point in a few thousand moves: a non-returning atomic OR each (a list fed by
+    // returning atomics on one counter per frame cost this kernel 0.15 ms; the wave's ballot stored by its first lane
+    // 0.06-0.09, a reconvergence point in a kernel of early exits).
+    if (both) atomicOr(reinterpret_cast<uint32_t*>(sg.moved(frame) + (i >> 6)) + ((i >> 5) & 1u), 1u << (i & 31u));
   }
-  return false;
 }
 
 // Both filters in one pass, after the geometry filter — a thread per wave of 64 points, which walks the wave's moved
@@ -513,18 +516,7 @@ __global__ __launch_bounds__(256) void k_smooth_apply_geometry(const DevFrame* _
   const uint32_t n = min(*gl(f.n_points), f.capacity);
 #pragma unroll 1
   for (uint32_t c = 0; c < kSmoothChunks; ++c)
-  {
-    const uint32_t i = (blockIdx.x * kSmoothChunks + c) * 256u + threadIdx.x;
-    const bool moved = smooth_apply_geometry_point(f, blockIdx.y, i, n, sg, w, G, T);
-    // The colour filter's cells are those of the smoothed positions: which points moved is noted, one bit per point
-    // (a word per wave, zeroed beforehand and written by the few waves that moved a point; no counter to fight over —
-    // a list fed by returning atomics on one counter per frame cost this kernel 0.15 ms, a word stored by EVERY wave
-    // 0.09), and k_smooth_moved_* take a moved point's sums to its new cell if it has one.
-    if (both) {
-      const uint64_t mask = __ballot(moved);
-      if (mask != 0 && (threadIdx.x & 63u) == 0) sg.moved(blockIdx.y)[i >> 6] = mask;     // (all-zero before: vpcc_gof_smooth)
-    }
-  }
+    smooth_apply_geometry_point(f, blockIdx.y, (blockIdx.x * kSmoothChunks + c) * 256u + threadIdx.x, n, sg, w, G, T, both);
 }
 
 __device__ __forceinline__ void smooth_apply_color_point(const DevFrame& f, uint32_t frame, uint32_t i, uint32_t n,
