@@ -1076,6 +1076,7 @@ extern "C" int vpcc_gof_smooth(vpcc_gof* g, uint32_t first, uint32_t count, cons
     const uint32_t G = geo ? p->grid_size : p->color_grid_size;
     const uint32_t w = ((1u << p->geometry_bitdepth_3d) + G - 1) / G;
     const size_t cells = (size_t)w * w * w;
+    if (cells >= (size_t(1) << 32)) return fail(ctx, VPCC_ERR_UNSUPPORTED, "smoothing grid of 2^32 cells or more (cell indices are 32 bits)");
     // Scratch: per frame slot a dense grid (the cell index of every point has its own allocation).  At most
     // ~16 GiB: a GOF whose grids need more is smoothed in chunks of frames.  The scratch is all-zero
     // between launches (k_smooth_clear restores what a launch touched), so it is cleared only when it is
