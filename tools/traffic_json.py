@@ -11,7 +11,8 @@ def means(sub, kern):
     """Per counter: the mean per dispatch of every kernel whose name contains `kern`, SUMMED over those kernels (one
     kernel for k_recon_tiles; the eight launches of a smoothing step for k_smooth)."""
     acc = collections.defaultdict(lambda: collections.defaultdict(list))
-    for f in glob.glob(os.path.join(root, sub, "**", "*counter_collection.csv"), recursive=True):
+    # (gpurun merges every call's output into the same directory: the newest file is this round's pass)
+    for f in sorted(glob.glob(os.path.join(root, sub, "**", "*counter_collection.csv"), recursive=True), key=os.path.getmtime)[-1:]:
         for r in csv.DictReader(open(f)):
             if kern in r["Kernel_Name"]:
                 acc[r["Counter_Name"]][r["Kernel_Name"]].append(float(r["Counter_Value"]))
@@ -31,12 +32,12 @@ fetch_b, write_b = f.get("FETCH_SIZE", 0) * 1024, w.get("WRITE_SIZE", 0) * 1024
 # calibration: sparse_read reads K of every 4 tiles of each 128-B line; whole lines arrive whatever K is
 cal = []
 per = collections.defaultdict(dict)
-for p in glob.glob(os.path.join(root, "sparse_rd", "**", "*counter_collection.csv"), recursive=True):
+for p in sorted(glob.glob(os.path.join(root, "sparse_rd", "**", "*counter_collection.csv"), recursive=True), key=os.path.getmtime)[-1:]:
     for r in csv.DictReader(open(p)):
         if "k_sparse" in r["Kernel_Name"]:
             per[int(r["Dispatch_Id"])][r["Counter_Name"]] = float(r["Counter_Value"])
 fs = {}
-for p in glob.glob(os.path.join(root, "sparse_FETCH_SIZE", "**", "*counter_collection.csv"), recursive=True):
+for p in sorted(glob.glob(os.path.join(root, "sparse_FETCH_SIZE", "**", "*counter_collection.csv"), recursive=True), key=os.path.getmtime)[-1:]:
     for r in csv.DictReader(open(p)):
         if "k_sparse" in r["Kernel_Name"] and r["Counter_Name"] == "FETCH_SIZE":
             fs[int(r["Dispatch_Id"])] = float(r["Counter_Value"]) * 1024
