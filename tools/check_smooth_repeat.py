@@ -1,3 +1,7 @@
+#!/usr/bin/env python3
+"""Diagnostic: repeated reconstruct + smooth on one gof, alternating between "both filters in one pass" (grid 8 / 8)
+and separate passes (4 / 16), with per-iteration counts of points that differ from the specification — what
+tests/test_smoothing.py::test_repeated_smoothing_launches_leave_the_grid_clean asserts, in numbers."""
 import sys, os
 sys.path.insert(0, "/root/repo/tests"); sys.path.insert(0, "/root/repo/tmc2-rs_amd")
 import numpy as np, cases, oracle_binding as ob
