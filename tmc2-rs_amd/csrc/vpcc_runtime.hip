@@ -321,12 +321,15 @@ int copy_plane(vpcc_ctx* ctx, void* dst, const void* src, size_t elem, uint32_t 
   return VPCC_OK;
 }
 
-// Placement of the two big blocks.  How fast the memory system takes the tile kernel's streams depends on WHERE in
-// VRAM the planes and the output arrays lie, by about 10 % of the kernel's time (profiles/r03/placement.txt); no
-// simpler access pattern predicts it, so the kernel itself is the probe: the first whole-gof launch of a gof whose
-// blocks are new runs on a few candidate output blocks (alive together, so they lie in different places), keeps the
-// fastest, does the same for the planes block (device-to-device copies), and once more for the output block if the
-// planes moved.  VPCC_PLACEMENT_CANDIDATES=1 takes the allocations as they come.
+// Placement of the big blocks (VPCC_GOF_TUNE_PLACEMENT).  VRAM consists of kinds of regions, tens of GB each, and the
+// memory system is fastest when a launch's traffic is spread evenly over them: the same 128-frame launch takes 0.45 ms
+// or 0.52 ms depending on where the gof's planes and output arrays lie (DESIGN.md 4.1 "Placement",
+// profiles/r03/pair_offset.txt, slab_*.txt).  Nothing tells the kinds apart but a measurement, and no simpler access
+// pattern predicts the kernel's time, so the kernel itself is the probe: the first whole-gof launch of a gof whose
+// blocks are new times the launch with each block in turn — the outputs and the planes of part 0, of part 1 — on
+// candidate allocations (alive together, so each lies somewhere else; planes by device-to-device copy, descriptors
+// rebased) and keeps the fastest; a second sweep if the first moved anything and the budget lasts.
+// VPCC_PLACEMENT_CANDIDATES=1 takes the allocations as they come.
 void rebase_frames(vpcc_gof* g, const void* from, size_t bytes, void* to) {
   const char* lo = (const char*)from;
   const ptrdiff_t d = (char*)to - lo;
