@@ -69,6 +69,11 @@ __device__ __forceinline__ vpcc_color3 load_color(const vpcc_color3* base, uint3
 }
 typedef uint16_t u16x2 __attribute__((ext_vector_type(2)));
 // value of lane - kShift within the lane's row of 16 (DPP row_shr); `outside` where there is no such lane
+// value of the lane's partner inside its quad of four lanes (DPP quad_perm)
+template <int kCtrl>
+__device__ __forceinline__ uint32_t qperm(uint32_t v) {
+  return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, kCtrl, 0xF, 0xF, false);
+}
 template <int kShift>
 __device__ __forceinline__ uint32_t row_shr(uint32_t v, uint32_t outside) {
   return (uint32_t)__builtin_amdgcn_update_dpp((int)outside, (int)v, 0x110 + kShift, 0xF, 0xF, false);
@@ -169,11 +174,27 @@ __device__ __forceinline__ void smooth_stats_chunk(const DevFrame& f, uint32_t f
     __builtin_amdgcn_wave_barrier();                         // (LDS operations of one wave execute in order)
     const bool clash = active && (T.key[slot] != key || T.pl[slot] != patch);
     if (__ballot(clash) == 0) {
-      if (active) {
-        if (pack) atomicAdd(&T.acc[0][slot], v01);
-        else { atomicAdd(&T.acc[0][slot], v[0]); atomicAdd(&T.acc[1][slot], v[1]); }
-        atomicAdd(&T.acc[2][slot], v[2] + (1u << 22));         // 64 x 65535 < 2^22: the count above the sum
-        if (mode == 2u) { atomicAdd(&T.acc[3][slot], c01); atomicAdd(&T.acc[4][slot], c2); }   // 64 x 255 < 2^16
+      // Lanes of one slot are served one after the other by the LDS (a CU has ONE; ten lanes per slot and five adds made
+      // it the busiest unit of the kernel), so neighbours with the same cell first add up in registers: lane pairs, then
+      // pairs of pairs (two DPP steps inside every quad of lanes; a third step across quads cost more than it saved);
+      // the lanes that were added to a neighbour stay out.  Statistics for both filters 0.97 -> 0.875 ms.
+      uint32_t a[5] = {pack ? v01 : v[0], pack ? 0u : v[1], v[2] + (1u << 22), c01, c2};   // 64 x 65535 < 2^22: the count above the sum
+      bool live = active;
+      {
+        const bool same = qperm<0xB1>(key) == key;               // lane ^ 1
+#pragma unroll
+        for (int q = 0; q < 5; ++q) { const uint32_t o = qperm<0xB1>(a[q]); if (same && !(lane & 1u)) a[q] += o; }
+        if (same && (lane & 1u)) live = false;
+        const bool same2 = qperm<0x4E>(key) == key;              // lane ^ 2 (lanes 0 and 2 of a quad: never given away above)
+#pragma unroll
+        for (int q = 0; q < 5; ++q) { const uint32_t o = qperm<0x4E>(a[q]); if (same2 && !(lane & 3u)) a[q] += o; }
+        if (same2 && (lane & 3u) == 2u) live = false;
+      }
+      if (live) {
+        atomicAdd(&T.acc[0][slot], a[0]);
+        if (!pack) atomicAdd(&T.acc[1][slot], a[1]);
+        atomicAdd(&T.acc[2][slot], a[2]);
+        if (mode == 2u) { atomicAdd(&T.acc[3][slot], a[3]); atomicAdd(&T.acc[4][slot], a[4]); }   // 64 x 255 < 2^16
       }
       __builtin_amdgcn_wave_barrier();
       const bool elected = head && T.lid[slot] == lane;
