@@ -50,6 +50,15 @@ sys.path.insert(0, os.path.join(REPO, "tmc2-rs_amd"))
 HBM_PEAK_GBPS = 8000.0   # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6300 GB/s is the measured copy rate
 
 
+def stale(traffic, family):
+    """Was the committed traffic figure measured on other kernel sources than the ones this run was built from?  The
+    family's own sources count where the file records them (a smoothing change does not age the tile kernel's figure)."""
+    from tmc2rs import provenance
+    if traffic.get("family_source_sha16"):
+        return traffic["family_source_sha16"] != provenance.kernel_source_sha16(family)
+    return traffic.get("kernel_source_sha16") != provenance.kernel_source_sha16()
+
+
 def measured_traffic(kernel, workload, frames):
     """Memory-side bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes
     (latest profiles/rNN/traffic*.json whose kernel / workload / frame count match), or None."""
@@ -425,7 +434,7 @@ def main():
                     "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBPS, 4),
                     "achieved_is": "algorithmic bytes (SURVEY 8d) / kernel time — not a physical HBM rate; that is frac_traffic",
                     "traffic": tr["hbm_bytes_per_launch"] if tr else None,
-                    "traffic_stale": (tr.get("kernel_source_sha16") != lib_info["kernel_source_sha16"]) if tr else None,
+                    "traffic_stale": stale(tr, "k_recon_tiles") if tr else None,
                     "traffic_measured_on": {"kernel_source_sha16": tr.get("kernel_source_sha16"), "library_sha16": (tr.get("library") or {}).get("sha16")} if tr else None,
                     "algorithmic_bytes_per_launch": dom_bytes, "kernel_ms": round(dom_ms, 4),
                     "kernel_ms_launches_averaged": launches_averaged,
@@ -533,7 +542,7 @@ def main():
                          "frac": round(sb / (sm * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4),
                          "traffic": trs["hbm_bytes_per_launch"] if trs else None,
                          "frac_traffic": round(trs["hbm_bytes_per_launch"] / (sm * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4) if trs else None,
-                         "traffic_stale": (trs.get("kernel_source_sha16") != lib_info["kernel_source_sha16"]) if trs else None,
+                         "traffic_stale": stale(trs, "k_smooth") if trs else None,
                          "verified": spec_check(g2, fr2, [0, nb - 1])})
             out2["equals_spec"] = all(v["equals_spec"] for v in out2["verified"])
         else:
@@ -552,7 +561,7 @@ def main():
                          "frac": round(alg2 / (km * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4),
                          "traffic": tro["hbm_bytes_per_launch"] if tro else None,
                          "frac_traffic": round(tro["hbm_bytes_per_launch"] / (km * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4) if tro else None,
-                         "traffic_stale": (tro.get("kernel_source_sha16") != lib_info["kernel_source_sha16"]) if tro else None,
+                         "traffic_stale": stale(tro, "k_recon_tiles") if tro else None,
                          "entries_checked": 2 * n_distinct, "equals_oracle": bool(eq)})
         out2["placement"] = g2.placement() if tune else "as allocated"
         g2.close()

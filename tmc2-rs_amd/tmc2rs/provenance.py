@@ -10,6 +10,9 @@ from . import _abi
 # every file the tile / smoothing kernels are compiled from
 KERNEL_SOURCES = ("vpcc_tiles.hip", "vpcc_smooth.hip", "vpcc_kernels.hip", "vpcc_device.hpp", "vpcc_devfn.hpp",
                   "vpcc_colour.h")
+# ... and per kernel family (a traffic figure of the tile kernel does not go stale when a smoothing kernel changes)
+FAMILY_SOURCES = {"k_recon_tiles": ("vpcc_tiles.hip", "vpcc_device.hpp", "vpcc_devfn.hpp", "vpcc_colour.h"),
+                  "k_smooth": ("vpcc_smooth.hip", "vpcc_device.hpp", "vpcc_devfn.hpp")}
 
 
 def _sha16(chunks):
@@ -32,9 +35,10 @@ def hipflags():
     return ""
 
 
-def kernel_source_sha16():
+def kernel_source_sha16(family=None):
+    """sha of the kernel sources + HIPFLAGS: of all kernels, or of one family ("k_recon_tiles", "k_smooth")."""
     csrc = os.path.join(_abi.PROJECT_DIR, "csrc")
-    chunks = [open(os.path.join(csrc, n), "rb").read() for n in KERNEL_SOURCES]
+    chunks = [open(os.path.join(csrc, n), "rb").read() for n in (FAMILY_SOURCES[family] if family else KERNEL_SOURCES)]
     chunks.append(hipflags().encode())
     return _sha16(chunks)
 

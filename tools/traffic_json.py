@@ -55,7 +55,7 @@ for i, (K, rs) in enumerate(cfg):
 print(json.dumps({
     "round": rnd, "kernel": kernel, "workload": workload,
     # what was measured: the library the passes loaded and the kernel sources + flags it was built from
-    "library": provenance.library(), "kernel_source_sha16": provenance.kernel_source_sha16(), "hipflags": provenance.hipflags(),
+    "library": provenance.library(), "kernel_source_sha16": provenance.kernel_source_sha16(), "family_source_sha16": provenance.kernel_source_sha16(kernel if kernel in provenance.FAMILY_SOURCES else None), "hipflags": provenance.hipflags(),
     "source": "rocprofv3 --kernel-trace --pmc, separate passes (tools/profile_round.sh); reads = 2 x FETCH_SIZE as "
               "MI355X_MICROARCH.md prescribes for gfx950, cross-checked by the exact request-size counters; writes = WRITE_SIZE",
     "launches_averaged": {"FETCH_SIZE": nf.get("FETCH_SIZE", 0), "WRITE_SIZE": nw.get("WRITE_SIZE", 0), "request_counters": max(nrd.values()) if nrd else 0},
