@@ -426,8 +426,6 @@ __device__ __forceinline__ bool load_hood(const SmoothCell* grid, const int32_t 
 
 __device__ __forceinline__ void smooth_apply_geometry_point(const DevFrame& f, uint32_t frame, uint32_t i, uint32_t n,
                                                             SmoothGrid sg, uint32_t w, uint32_t G, uint32_t T, bool both) {
-  if (i >= n) return;
-  if (!sg.flags(frame)[sg.keys(frame)[i]]) return;        // no mixed cell anywhere near this point (k_smooth_mark)
   const vpcc_point3 pt = gload(f.out_xyz + i);
   const uint32_t p[3] = {pt.x, pt.y, pt.z};
   int32_t s[3];
@@ -535,15 +533,25 @@ __global__ __launch_bounds__(256) void k_smooth_apply_geometry(const DevFrame* _
                                                                SmoothGrid sg, uint32_t w, uint32_t G, uint32_t T, bool both) {
   const DevFrame& f = frames[first + blockIdx.y];
   const uint32_t n = min(*gl(f.n_points), f.capacity);
+  // ONE flag load (through the point's cell index) decides whether a point needs its 2x2x2 cells at all (k_smooth_mark);
+  // the indices and flags of the thread's points are fetched together: two round trips instead of two per point
+  uint32_t key[kSmoothChunks];
+  bool flagged[kSmoothChunks];
+#pragma unroll
+  for (uint32_t c = 0; c < kSmoothChunks; ++c) {
+    const uint32_t i = (blockIdx.x * kSmoothChunks + c) * 256u + threadIdx.x;
+    key[c] = i < n ? sg.keys(blockIdx.y)[i] : 0xFFFFFFFFu;
+  }
+#pragma unroll
+  for (uint32_t c = 0; c < kSmoothChunks; ++c) flagged[c] = key[c] != 0xFFFFFFFFu && sg.flags(blockIdx.y)[key[c]] != 0;
 #pragma unroll 1
   for (uint32_t c = 0; c < kSmoothChunks; ++c)
-    smooth_apply_geometry_point(f, blockIdx.y, (blockIdx.x * kSmoothChunks + c) * 256u + threadIdx.x, n, sg, w, G, T, both);
+    if (flagged[c])
+      smooth_apply_geometry_point(f, blockIdx.y, (blockIdx.x * kSmoothChunks + c) * 256u + threadIdx.x, n, sg, w, G, T, both);
 }
 
 __device__ __forceinline__ void smooth_apply_color_point(const DevFrame& f, uint32_t frame, uint32_t i, uint32_t n,
                                                          SmoothGrid sg, uint32_t w, uint32_t G, uint32_t Ts, uint32_t Td, bool both) {
-  if (i >= n) return;
-  if (!sg.flags(frame)[sg.keys(frame)[i]]) return;        // no mixed cell anywhere near this point (k_smooth_mark)
   const vpcc_point3 pt = gload(f.out_xyz + i);
   const uint32_t p[3] = {pt.x, pt.y, pt.z};
   int32_t s[3];
@@ -616,9 +624,19 @@ __global__ __launch_bounds__(256) void k_smooth_apply_color(const DevFrame* __re
                                                             SmoothGrid sg, uint32_t w, uint32_t G, uint32_t Ts, uint32_t Td, bool both) {
   const DevFrame& f = frames[first + blockIdx.y];
   const uint32_t n = min(*gl(f.n_points), f.capacity);
+  uint32_t key[kSmoothChunks];                              // (as in k_smooth_apply_geometry)
+  bool flagged[kSmoothChunks];
+#pragma unroll
+  for (uint32_t c = 0; c < kSmoothChunks; ++c) {
+    const uint32_t i = (blockIdx.x * kSmoothChunks + c) * 256u + threadIdx.x;
+    key[c] = i < n ? sg.keys(blockIdx.y)[i] : 0xFFFFFFFFu;
+  }
+#pragma unroll
+  for (uint32_t c = 0; c < kSmoothChunks; ++c) flagged[c] = key[c] != 0xFFFFFFFFu && sg.flags(blockIdx.y)[key[c]] != 0;
 #pragma unroll 1
   for (uint32_t c = 0; c < kSmoothChunks; ++c)
-    smooth_apply_color_point(f, blockIdx.y, (blockIdx.x * kSmoothChunks + c) * 256u + threadIdx.x, n, sg, w, G, Ts, Td, both);
+    if (flagged[c])
+      smooth_apply_color_point(f, blockIdx.y, (blockIdx.x * kSmoothChunks + c) * 256u + threadIdx.x, n, sg, w, G, Ts, Td, both);
 }
 
 
