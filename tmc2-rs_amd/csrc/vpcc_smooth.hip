@@ -118,6 +118,7 @@ __device__ __forceinline__ uint32_t wave_reduce(uint32_t v) {
 // kernels were bound by the rate at which workgroups can be launched (1.3-1.7 resident waves per SIMD on average,
 // VALU 23 % busy — tools/pmc_smooth.sh), not by anything they do.
 constexpr uint32_t kSmoothChunks = 4;
+constexpr uint32_t kApplyChunks = 4;    // points per thread of the apply kernels (2: 2.41 ms for the step, 8: 2.25, 16: 3.77; 4: 2.24)
 __device__ __forceinline__ void smooth_stats_chunk(const DevFrame& f, uint32_t frame, uint32_t chunk, uint32_t n,
                                                    SmoothGrid sg, uint32_t w, uint32_t G, uint32_t mode) {
   const uint32_t i = chunk * 256u + threadIdx.x;
@@ -535,19 +536,19 @@ __global__ __launch_bounds__(256) void k_smooth_apply_geometry(const DevFrame* _
   const uint32_t n = min(*gl(f.n_points), f.capacity);
   // ONE flag load (through the point's cell index) decides whether a point needs its 2x2x2 cells at all (k_smooth_mark);
   // the indices and flags of the thread's points are fetched together: two round trips instead of two per point
-  uint32_t key[kSmoothChunks];
-  bool flagged[kSmoothChunks];
+  uint32_t key[kApplyChunks];
+  bool flagged[kApplyChunks];
 #pragma unroll
-  for (uint32_t c = 0; c < kSmoothChunks; ++c) {
-    const uint32_t i = (blockIdx.x * kSmoothChunks + c) * 256u + threadIdx.x;
+  for (uint32_t c = 0; c < kApplyChunks; ++c) {
+    const uint32_t i = (blockIdx.x * kApplyChunks + c) * 256u + threadIdx.x;
     key[c] = i < n ? sg.keys(blockIdx.y)[i] : 0xFFFFFFFFu;
   }
 #pragma unroll
-  for (uint32_t c = 0; c < kSmoothChunks; ++c) flagged[c] = key[c] != 0xFFFFFFFFu && sg.flags(blockIdx.y)[key[c]] != 0;
+  for (uint32_t c = 0; c < kApplyChunks; ++c) flagged[c] = key[c] != 0xFFFFFFFFu && sg.flags(blockIdx.y)[key[c]] != 0;
 #pragma unroll 1
-  for (uint32_t c = 0; c < kSmoothChunks; ++c)
+  for (uint32_t c = 0; c < kApplyChunks; ++c)
     if (flagged[c])
-      smooth_apply_geometry_point(f, blockIdx.y, (blockIdx.x * kSmoothChunks + c) * 256u + threadIdx.x, n, sg, w, G, T, both);
+      smooth_apply_geometry_point(f, blockIdx.y, (blockIdx.x * kApplyChunks + c) * 256u + threadIdx.x, n, sg, w, G, T, both);
 }
 
 __device__ __forceinline__ void smooth_apply_color_point(const DevFrame& f, uint32_t frame, uint32_t i, uint32_t n,
@@ -624,19 +625,19 @@ __global__ __launch_bounds__(256) void k_smooth_apply_color(const DevFrame* __re
                                                             SmoothGrid sg, uint32_t w, uint32_t G, uint32_t Ts, uint32_t Td, bool both) {
   const DevFrame& f = frames[first + blockIdx.y];
   const uint32_t n = min(*gl(f.n_points), f.capacity);
-  uint32_t key[kSmoothChunks];                              // (as in k_smooth_apply_geometry)
-  bool flagged[kSmoothChunks];
+  uint32_t key[kApplyChunks];                              // (as in k_smooth_apply_geometry)
+  bool flagged[kApplyChunks];
 #pragma unroll
-  for (uint32_t c = 0; c < kSmoothChunks; ++c) {
-    const uint32_t i = (blockIdx.x * kSmoothChunks + c) * 256u + threadIdx.x;
+  for (uint32_t c = 0; c < kApplyChunks; ++c) {
+    const uint32_t i = (blockIdx.x * kApplyChunks + c) * 256u + threadIdx.x;
     key[c] = i < n ? sg.keys(blockIdx.y)[i] : 0xFFFFFFFFu;
   }
 #pragma unroll
-  for (uint32_t c = 0; c < kSmoothChunks; ++c) flagged[c] = key[c] != 0xFFFFFFFFu && sg.flags(blockIdx.y)[key[c]] != 0;
+  for (uint32_t c = 0; c < kApplyChunks; ++c) flagged[c] = key[c] != 0xFFFFFFFFu && sg.flags(blockIdx.y)[key[c]] != 0;
 #pragma unroll 1
-  for (uint32_t c = 0; c < kSmoothChunks; ++c)
+  for (uint32_t c = 0; c < kApplyChunks; ++c)
     if (flagged[c])
-      smooth_apply_color_point(f, blockIdx.y, (blockIdx.x * kSmoothChunks + c) * 256u + threadIdx.x, n, sg, w, G, Ts, Td, both);
+      smooth_apply_color_point(f, blockIdx.y, (blockIdx.x * kApplyChunks + c) * 256u + threadIdx.x, n, sg, w, G, Ts, Td, both);
 }
 
 
@@ -649,13 +650,13 @@ void launch_smooth_stats(const DevFrame* d_frames, uint32_t first, uint32_t coun
 void launch_smooth_apply_geometry(const DevFrame* d_frames, uint32_t first, uint32_t count, uint32_t max_points,
                                   SmoothGrid sg, uint32_t w, uint32_t G, uint32_t T, bool both, void* stream) {
   if (!count || !max_points) return;
-  hipLaunchKernelGGL(k_smooth_apply_geometry, dim3((max_points + 256 * kSmoothChunks - 1) / (256 * kSmoothChunks), count), dim3(256),
+  hipLaunchKernelGGL(k_smooth_apply_geometry, dim3((max_points + 256 * kApplyChunks - 1) / (256 * kApplyChunks), count), dim3(256),
                      0, (hipStream_t)stream, d_frames, first, sg, w, G, T, both);
 }
 void launch_smooth_apply_color(const DevFrame* d_frames, uint32_t first, uint32_t count, uint32_t max_points,
                                SmoothGrid sg, uint32_t w, uint32_t G, uint32_t Ts, uint32_t Td, bool both, void* stream) {
   if (!count || !max_points) return;
-  hipLaunchKernelGGL(k_smooth_apply_color, dim3((max_points + 256 * kSmoothChunks - 1) / (256 * kSmoothChunks), count), dim3(256), 0,
+  hipLaunchKernelGGL(k_smooth_apply_color, dim3((max_points + 256 * kApplyChunks - 1) / (256 * kApplyChunks), count), dim3(256), 0,
                      (hipStream_t)stream, d_frames, first, sg, w, G, Ts, Td, both);
 }
 void launch_smooth_moved(const DevFrame* d_frames, uint32_t first, uint32_t count, uint32_t max_points, SmoothGrid sg,
