@@ -179,11 +179,19 @@ void Decoder::worker() {
   // frames are (a fresh Context per GOF, src/lib.rs:120), and a launch over 128 frames costs 12 % less per frame
   // than four launches over 32.
   const size_t G = params_.devices.empty() ? 1 : params_.devices.size();
+  const auto t_worker = std::chrono::steady_clock::now();
+  const bool trace_steps = std::getenv("VPCC_DECODER_TRACE") != nullptr && std::getenv("VPCC_DECODER_TRACE")[0] == '2';
+  auto step = [&](const char* what) {                   // VPCC_DECODER_TRACE=2: the start-up, step by step
+    if (trace_steps)
+      std::fprintf(stderr, "[vpcc decoder] +%.1f ms %s\n",
+                   std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_worker).count(), what);
+  };
   std::vector<std::unique_ptr<Lane>> lanes;
   for (size_t d = 0; d < G; ++d) lanes.push_back(std::make_unique<Lane>(params_.devices.empty() ? 0 : params_.devices[d]));
   auto fail = [&](const std::string& why) { error_ = why; chan_.close_tx(); };
   for (size_t d = 0; d < G; ++d)
     if (lanes[d]->post([](vpcc_ctx* c) { return c ? 0 : 1; }).get()) { fail("vpcc_ctx_create failed: no usable gfx950 device (no CPU fallback)"); return; }
+  step("contexts ready");
   stats_.lanes = (uint32_t)G;
   for (size_t d = 0; d < G && d < 8; ++d) stats_.numa_node[d] = lanes[d]->numa_node();
 
@@ -191,6 +199,7 @@ void Decoder::worker() {
   bool pinned = false;
   if (!file_.empty())
     pinned = lanes[0]->post([&](vpcc_ctx* c) { return vpcc_host_pin(c, file_.data(), file_.size()); }).get() == VPCC_OK;
+  step("input page-locked");
   struct Unpin {
     Lane* l; const void* p; bool on;
     ~Unpin() { if (on) l->post([this](vpcc_ctx* c) { return vpcc_host_unpin(c, p); }).get(); }
@@ -288,14 +297,21 @@ void Decoder::worker() {
     ~Cleanup() { for (auto& f : q) destroy_fn(&f); }
   } cleanup{inflight, destroy};
   size_t launched = 0;
-  for (size_t k = 0; k < units.size(); ++k) {         // while ssvu.get_v3c_unit_count() > 0, src/lib.rs:118
-    while (launched < units.size() && launched <= k + kAhead) {   // their ingest overlaps this unit's work
+  // Units are posted up to kAhead ahead (their ingest overlaps the current unit's work) — but only once the current
+  // unit's point counts are back and its first downloads are posted: a lane serves its queue in order, and with the
+  // look-ahead posted first the first unit's counts and downloads waited behind the planning and allocation of the next
+  // two units (first frame after 190 ms instead of 110, of which 50-130 are the page-locking of the input).
+  auto launch_upto = [&](size_t last) {
+    while (launched < units.size() && launched <= last) {
       inflight.emplace_back();
       for (size_t q = units[launched].first; q < units[launched].second; ++q)
         for (const vpcc_frame_desc& fr : gofs_[q].frames) inflight.back().frames.push_back(&fr);
       launch(&inflight.back());
       ++launched;
     }
+  };
+  for (size_t k = 0; k < units.size(); ++k) {         // while ssvu.get_v3c_unit_count() > 0, src/lib.rs:118
+    launch_upto(k);
     InFlight& cur = inflight.front();
     const size_t n = cur.frames.size();
     double slowest = 0;
@@ -313,6 +329,7 @@ void Decoder::worker() {
     }
     // reference: a panic in the worker -> the consumer sees end-of-stream where this GOF would have started
     if (!first_err.empty()) { fail(first_err); return; }
+    if (k == 0) step("first unit planned, uploads and launch enqueued");
     stats_.launch_seconds += slowest;
     std::vector<std::vector<uint32_t>> counts(G);
     {
@@ -342,6 +359,7 @@ void Decoder::worker() {
       if (bad >= 0) { fail(errs[(size_t)bad]); return; }
       for (size_t d = 0; d < G; ++d) stats_.kernel_seconds += cur.part[d].kernel_seconds;
       t_counts += secs(t0, now());
+      if (k == 0) step("first unit reconstructed (point counts back)");
     }
     // Downloads are posted a window of frames ahead of the hand-over — every lane works through its own
     // frames while earlier ones are delivered in presentation order (src/decoder.rs:188) — but not the whole
@@ -379,6 +397,8 @@ void Decoder::worker() {
     auto settle = [&](size_t from) {                       // downloads in flight write into `sets`
       for (size_t q = from; q < posted; ++q) done[q].wait();
     };
+    post_downloads(window);                                // this unit's first frames before the lanes hear of the next units
+    launch_upto(k + kAhead);
     for (size_t f = 0; f < n; ++f) {
       post_downloads(f + window);
       const auto t0 = now();
@@ -389,6 +409,7 @@ void Decoder::worker() {
       if (!st) {
         sent = chan_.send(std::move(sets[f]));
         t_send += secs(t1, now());
+        if (k == 0 && f == 0) step("first frame handed over");
       }
       if (st || !sent) {                                   // device error, or receiver dropped (src/decoder.rs:311-313)
         settle(f + 1);
