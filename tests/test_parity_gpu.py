@@ -302,6 +302,40 @@ def test_device_resident_planes(ctx):
     g.close()
 
 
+def test_tuned_placement_with_device_planes(ctx):
+    """VPCC_GOF_TUNE_PLACEMENT on a gof whose planes are the caller's device memory: only the output parts can be
+    placed (the planes stay where the caller put them); results as ever."""
+    import torch
+    distinct = [synth.longdress_frame(i) for i in range(3)]
+    refs3 = [ob.reconstruct(f)[1] for f in distinct]
+    dev = torch.device("cuda:0")
+    keepalive, descs = [], []
+
+    def up(a):
+        x = torch.from_numpy(np.ascontiguousarray(a).view(np.uint8).reshape(-1)).to(dev)
+        keepalive.append(x)
+        return x.data_ptr()
+
+    for i in range(12):
+        f = distinct[i % 3]
+        d, keep = _abi.host_frame_desc(f)
+        keepalive.append(keep)
+        d.occupancy.y = up(f["occupancy"])
+        d.occupancy.stride = d.occupancy.width
+        for m in range(2):
+            d.geometry[m].y = up(f["geometry"][m])
+            d.attribute[m].y, d.attribute[m].u, d.attribute[m].v = (up(p) for p in f["attribute"][m])
+        descs.append(d)
+    torch.cuda.synchronize()
+    g = ctx.gof(None, capacity=1_000_000, memory=_abi.VPCC_MEM_DEVICE, descs=descs, flags=_abi.VPCC_GOF_TUNE_PLACEMENT)
+    g.reconstruct()
+    p = g.placement()
+    assert p["tuned"] == 1 and p["candidates"] >= 2, p
+    for i in (0, 7, 8, 11):
+        _check(g.download(i), refs3[i % 3])
+    g.close()
+
+
 TILE_KERNEL_CASES = ["small0", "medium1_randocc", "relative_d1", "overlap", "single_map_extension", "no_attribute",
                      "gray_exact_boundaries", "wide_samples", "precision1_block16", "precision2_block16",
                      "precision8_block16", "precision16_block16", "truncation_degenerate_axes"]
