@@ -221,7 +221,8 @@ void vpcc_gof_destroy(vpcc_gof* gof);
                                            flag the gof keeps its ingested planes and its output arrays in two parts each
                                            (by frame), and the first whole-gof vpcc_gof_reconstruct measures the kernel on
                                            candidate allocations of every part (up to VPCC_PLACEMENT_CANDIDATES, default
-                                           16, per block size; no new ones once VPCC_PLACEMENT_BUDGET_MS, default 800,
+                                           16, per block size; no new ones once VPCC_PLACEMENT_BUDGET_MS, default 800 — not
+                                           counting the time allocations wait for the driver, up to five times that —
                                            have passed), keeps the fastest and frees the rest: 0.2-0.8 s once, 30 GB of
                                            transient allocations (up to 130 GB where VRAM is alike for a long stretch).  The blocks move during that call:
                                            vpcc_gof_device_outputs before it pins them where they are (no measurement).

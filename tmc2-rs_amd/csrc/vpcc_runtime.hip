@@ -392,6 +392,10 @@ int place_blocks(vpcc_gof* g, uint32_t max_groups, hipStream_t s) {
   };
   const auto t0 = std::chrono::steady_clock::now();
   auto spent_ms = [&] { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count(); };
+  // The budget counts the measurement, not the time the driver makes an allocation wait while it wipes memory somebody
+  // freed a moment ago (a hipMalloc of 0.5 GB then takes 100 ms and more instead of one) — up to a hard limit.
+  double stalled_ms = 0;
+  auto over_budget = [&] { const double t = spent_ms(); return t - stalled_ms > budget_ms || t > 5.0 * budget_ms; };
   // Candidate allocations are kept in a pool per block size for the whole measurement and given back at its end
   // (parts of a kind are equally big and share their candidates): VRAM that is freed gets wiped by the driver before
   // it is handed out again, at about 40 GB/s, and whoever allocates next waits for it — a first version that took fresh
@@ -404,11 +408,13 @@ int place_blocks(vpcc_gof* g, uint32_t max_groups, hipStream_t s) {
   (void)hipMemGetInfo(&free_b, &total_b);
   auto grow = [&](Pool& P, size_t n) {                          // up to n more blocks, while budget and memory last
     for (size_t k = 0; k < n; ++k) {
-      if ((!P.blocks.empty() && spent_ms() > budget_ms) || held + P.bytes > free_b / 2) return;
+      if ((!P.blocks.empty() && over_budget()) || held + P.bytes > free_b / 2) return;
       void* p = nullptr;
       const double t_a = spent_ms();
       if (hipMalloc(&p, P.bytes) != hipSuccess) { (void)hipGetLastError(); return; }
-      if (trace && spent_ms() - t_a > 10.0) fprintf(stderr, "[vpcc] placement: hipMalloc of %zu MB took %.0f ms (%zu MB held)\n", P.bytes >> 20, spent_ms() - t_a, held >> 20);
+      const double took = spent_ms() - t_a;
+      if (took > 5.0) stalled_ms += took;
+      if (trace && took > 10.0) fprintf(stderr, "[vpcc] placement: hipMalloc of %zu MB took %.0f ms (%zu MB held)\n", P.bytes >> 20, took, held >> 20);
       P.blocks.push_back(p);
       held += P.bytes;
     }
@@ -442,9 +448,9 @@ int place_blocks(vpcc_gof* g, uint32_t max_groups, hipStream_t s) {
         // 2-GiB and larger round sizes took 100 ms and more; kept until the measurement ends, so that the pools of the
         // blocks that follow start beyond them), then eight more candidates.
         const bool flat = ms[worst] < flat_ratio * ms[best];
-        if (!skip_ahead || !flat || P.skips == 3 || spent_ms() > budget_ms) break;
+        if (!skip_ahead || !flat || P.skips == 3 || over_budget()) break;
         const size_t distance = size_t(16 * (P.skips + 1)) << 30;                  // 16, 32, 48 GB
-        for (size_t skipped = 0; skipped < distance && held + bytes <= free_b / 2 && spent_ms() < budget_ms; skipped += bytes) {
+        for (size_t skipped = 0; skipped < distance && held + bytes <= free_b / 2 && !over_budget(); skipped += bytes) {
           void* sp = nullptr;
           if (hipMalloc(&sp, bytes) != hipSuccess) { (void)hipGetLastError(); break; }
           spacers.push_back(sp);
@@ -494,11 +500,11 @@ int place_blocks(vpcc_gof* g, uint32_t max_groups, hipStream_t s) {
   int st = VPCC_OK;
   bool moved_any = false;
   for (int sweep = 0; sweep < 2 && !st; ++sweep) {
-    if (sweep && (!moved_any || spent_ms() > budget_ms)) break;
+    if (sweep && (!moved_any || over_budget())) break;
     for (int part = 0; part < vpcc_ctx::kParts && !st; ++part)
       for (int kind = 1; kind >= 0 && !st; --kind) {
         vpcc_ctx::Block& B = M.block[2 * part + kind];
-        if (!B.ptr || B.bytes < (size_t(16) << 20) || (sweep && spent_ms() > budget_ms)) continue;
+        if (!B.ptr || B.bytes < (size_t(16) << 20) || (sweep && over_budget())) continue;
         bool moved = false;
         char what[32];
         snprintf(what, sizeof what, "%s %d", names[kind], part);
