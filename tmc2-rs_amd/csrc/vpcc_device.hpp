@@ -90,6 +90,8 @@ struct DevFrame {
   uint32_t capacity;
   uint32_t n_tiles;           // number of tile items (the array is padded to a multiple of 16 readable items)
   uint32_t prec_shift;        // log2(prec) when prec is a power of two (tile kernel)
+  uint32_t tiled;             // geometry and attribute planes are stored block by block (k_tile_planes): block b of a luma
+                              //   plane = 256 consecutive samples (16 rows of 16), of a chroma plane 64 (8 rows of 8); b = by * bw + bx
 };
 
 // One grid cell of the smoothing filters (oracle/vpcc_smoothing_spec.h): all-zero = empty.
@@ -162,6 +164,11 @@ void launch_smooth_mark(const DevFrame* d_frames, uint32_t first, uint32_t count
 void launch_smooth_clear(const DevFrame* d_frames, uint32_t first, uint32_t count, uint32_t max_points, SmoothGrid sg,
                          uint32_t w, bool both, void* stream);
 
+// Re-arranges the geometry and attribute planes of frames [first, first + count) from the raster layout (`raster`: the
+// frames' descriptors with raster pointers and strides) into the block-by-block layout (`tiled`: the same frames with the
+// destination pointers).  Both arrays on the device.
+void launch_tile_planes(const DevFrame* raster, const DevFrame* tiled, uint32_t first, uint32_t count, uint32_t max_blocks,
+                        void* stream);
 // Kernel launchers (vpcc_kernels.hip).  All asynchronous on `stream`.
 void launch_block_owner(const DevFrame* d_frames, uint32_t first, uint32_t count, uint32_t max_vb,
                         void* stream);

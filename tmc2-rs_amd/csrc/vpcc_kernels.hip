@@ -179,6 +179,40 @@ void launch_emit(const DevFrame* d_frames, uint32_t first, uint32_t count, uint3
   if (!count || !max_vb) return;
   hipLaunchKernelGGL(k_emit, dim3(max_vb, count), dim3(256), 0, (hipStream_t)stream, d_frames, first);
 }
+// Raster planes -> block-by-block planes (DevFrame::tiled), a wave per 16x16 block: lane l moves the block's pixels
+// 4 (l & 3) .. + 3 of row l >> 2 of every luma plane (8 bytes) to bytes 8 l .. of the block's 512; lanes 0-15 move the
+// 8x8 chroma block the same way (row l >> 1, samples 4 (l & 1) .. + 3).  Every block of the canvas, once per gof.
+__global__ __launch_bounds__(256) void k_tile_planes(const DevFrame* __restrict__ raster, const DevFrame* __restrict__ tiled,
+                                                     uint32_t first) {
+  const DevFrame& r = raster[first + blockIdx.y];
+  const DevFrame& t = tiled[first + blockIdx.y];
+  const uint32_t blk = blockIdx.x * 4u + (threadIdx.x >> 6), lane = threadIdx.x & 63u;
+  if (blk >= r.bw * r.bh) return;
+  const uint32_t x0 = (blk % r.bw) * 16u, y0 = (blk / r.bw) * 16u;
+  typedef uint32_t v2 __attribute__((ext_vector_type(2)));
+  const uint32_t px = x0 + 4u * (lane & 3u), py = y0 + (lane >> 2);
+  for (uint32_t m = 0; m < r.map_count; ++m) {
+    *(VPCC_GLOBAL v2*)((VPCC_GLOBAL unsigned char*)t.geo[m] + blk * 512u + 8u * lane) =
+        *(const VPCC_GLOBAL v2*)((const VPCC_GLOBAL unsigned char*)r.geo[m] + ((size_t)py * r.geo_stride[m] + px) * 2u);
+    if (r.has_attr) {
+      *(VPCC_GLOBAL v2*)((VPCC_GLOBAL unsigned char*)t.attr_y[m] + blk * 512u + 8u * lane) =
+          *(const VPCC_GLOBAL v2*)((const VPCC_GLOBAL unsigned char*)r.attr_y[m] + ((size_t)py * r.attr_stride[m] + px) * 2u);
+      if (lane < 16u) {
+        const size_t c = ((size_t)(y0 / 2u + (lane >> 1)) * r.attr_cstride[m] + x0 / 2u + 4u * (lane & 1u)) * 2u;
+        *(VPCC_GLOBAL v2*)((VPCC_GLOBAL unsigned char*)t.attr_u[m] + blk * 128u + 8u * lane) =
+            *(const VPCC_GLOBAL v2*)((const VPCC_GLOBAL unsigned char*)r.attr_u[m] + c);
+        *(VPCC_GLOBAL v2*)((VPCC_GLOBAL unsigned char*)t.attr_v[m] + blk * 128u + 8u * lane) =
+            *(const VPCC_GLOBAL v2*)((const VPCC_GLOBAL unsigned char*)r.attr_v[m] + c);
+      }
+    }
+  }
+}
+void launch_tile_planes(const DevFrame* raster, const DevFrame* tiled, uint32_t first, uint32_t count, uint32_t max_blocks,
+                        void* stream) {
+  if (!count || !max_blocks) return;
+  hipLaunchKernelGGL(k_tile_planes, dim3((max_blocks + 3) / 4, count), dim3(256), 0, (hipStream_t)stream, raster, tiled, first);
+}
+
 void launch_upsample_occupancy(const DevFrame* d_frames, uint32_t frame, uint8_t* d_out, uint32_t width,
                                uint32_t height, void* stream) {
   if (!width || !height) return;

@@ -49,6 +49,7 @@ struct vpcc_ctx {
     void release() { for (Block& b : block) { if (b.ptr) (void)hipFree(b.ptr); b = Block{}; } }
   };
   std::vector<Placement> placement_cache;
+  std::vector<Block> temp_cache;        // raster staging blocks of destroyed gofs (tiled planes), a handful
 };
 
 struct KernelTiming {
@@ -75,6 +76,9 @@ struct vpcc_gof {
   void* arena = nullptr;
   size_t arena_bytes = 0;
   vpcc_ctx::Placement mem;             // the planes blocks and the output blocks
+  vpcc_ctx::Block temp[vpcc_ctx::kParts];   // tiled planes: where the raster planes were uploaded to (kept until the gof goes)
+  DevFrame* d_raster = nullptr;        //   ... and the descriptors k_tile_planes read them through
+  std::vector<DevFrame> h_raster;      //   (their host copy: alive as long as an upload may read it)
   bool placed = false;                 // the blocks are final (place_blocks ran, or the caller holds pointers into them)
   DevFrame* d_frames = nullptr;
   uint32_t* d_counts = nullptr;        // n_frames contiguous point counters
@@ -181,6 +185,7 @@ extern "C" void vpcc_ctx_destroy(vpcc_ctx* ctx) {
   (void)hipSetDevice(ctx->device);
   for (auto& a : ctx->arena_cache) (void)hipFree(a.first);
   for (auto& b : ctx->placement_cache) b.release();
+  for (auto& b : ctx->temp_cache) (void)hipFree(b.ptr);
   if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
   if (ctx->copy_stream) (void)hipStreamDestroy(ctx->copy_stream);
   if (ctx->d2h_stream) (void)hipStreamDestroy(ctx->d2h_stream);
@@ -294,6 +299,12 @@ extern "C" void vpcc_gof_destroy(vpcc_gof* gof) {
     if (cache.size() < 4) cache.emplace_back(gof->arena, gof->arena_bytes);
     else (void)hipFree(gof->arena);
   }
+  for (vpcc_ctx::Block& t : gof->temp)
+    if (t.ptr) {
+      if (gof->ctx->temp_cache.size() < 4) gof->ctx->temp_cache.push_back(t);
+      else (void)hipFree(t.ptr);
+    }
+  if (gof->d_raster) (void)hipFree(gof->d_raster);
   if (gof->mem.any()) {
     auto& cache = gof->ctx->placement_cache;                     // at most four sets: the slowest (unmeasured first,
     cache.push_back(gof->mem);                                    // oldest among equals) goes
@@ -690,6 +701,38 @@ int gof_create_impl(vpcc_ctx* ctx, const vpcc_frame_desc* frames, uint32_t n_fra
   HIP_TRY(ctx, hipEventCreateWithFlags(&g->upload_done, hipEventDisableTiming));
   HIP_TRY(ctx, hipEventCreateWithFlags(&g->results_ready, hipEventDisableTiming));
 
+  // Tiled planes.  The tile kernel reads a plane block by block (16 rows of 32 bytes, each a quarter of a 128-byte line
+  // that the neighbouring blocks' waves need as well, moments later or long after): in the raster layout a third of
+  // its reads are lines fetched more than once.  Planes the library ingests itself (VPCC_MEM_HOST) are therefore
+  // re-arranged once, right behind their upload, so that a block's samples are contiguous (k_tile_planes): the
+  // kernel then reads exactly the blocks it needs, 512 contiguous bytes per wave and plane.  Needs the raster copy
+  // as staging (kept with the gof, reused by the context).  VPCC_NO_TILED_PLANES=1 keeps the raster layout.
+  bool tiled = kind == VPCC_MEM_HOST && all_simple && !(gof_flags & VPCC_GOF_FORCE_GENERAL) && !slab && !getenv("VPCC_NO_TILED_PLANES");
+  for (uint32_t i = 0; i < n_frames && tiled; ++i) {
+    const vpcc_frame_desc& F = frames[i];
+    tiled = F.width % 16u == 0 && F.height % 16u == 0;
+    for (uint32_t m = 0; m < F.map_count && tiled; ++m) {
+      tiled = F.geometry[m].width == F.width && F.geometry[m].height == F.height;
+      if (tiled && F.attribute_count)
+        tiled = F.attribute[m].width == F.width && F.attribute[m].height == F.height &&
+                chroma_elems(F.attribute[m]) == (size_t)(F.width / 2u) * (F.height / 2u) && F.attribute[m].cstride == F.width / 2u;
+    }
+  }
+  if (tiled)
+    for (int part = 0; part < vpcc_ctx::kParts; ++part) {
+      const size_t need = g->mem.block[2 * part].bytes;
+      if (!need) continue;
+      auto& cache = ctx->temp_cache;
+      for (size_t k = 0; k < cache.size(); ++k)
+        if (cache[k].bytes >= need && cache[k].bytes <= need + need / 4) { g->temp[part] = cache[k]; cache.erase(cache.begin() + k); break; }
+      if (!g->temp[part].ptr) {
+        HIP_TRY(ctx, hipMalloc(&g->temp[part].ptr, need));
+        g->temp[part].bytes = need;
+      }
+    }
+  std::vector<DevFrame>& h_raster = g->h_raster;
+  h_raster.resize(tiled ? n_frames : 0);
+  auto up = [&](uint32_t i, int sub) { return tiled ? (char*)g->temp[part_of(i)].ptr : kb(i, 0, sub); };   // where the planes are uploaded to
   const auto t_fill = std::chrono::steady_clock::now();
   // 3. fill descriptors and upload (plane ingest on the copy stream)
   hipStream_t s = ctx->copy_stream;
@@ -739,7 +782,7 @@ int gof_create_impl(vpcc_ctx* ctx, const vpcc_frame_desc* frames, uint32_t n_fra
       for (uint32_t m = 0; m < F.map_count; ++m) {
         const vpcc_image_u16& G = F.geometry[m];
         D.geo[m] = (const uint16_t*)(kb(i, 0, 0) + o.geo[m]); D.geo_stride[m] = G.width;
-        st = copy_plane(ctx, kb(i, 0, 0) + o.geo[m], G.y, 2, G.width, G.height, G.stride, s);
+        st = copy_plane(ctx, up(i, 0) + o.geo[m], G.y, 2, G.width, G.height, G.stride, s);
         if (st) return st;
         if (F.attribute_count) {
           const vpcc_image_u16& A = F.attribute[m];
@@ -747,13 +790,13 @@ int gof_create_impl(vpcc_ctx* ctx, const vpcc_frame_desc* frames, uint32_t n_fra
           D.attr_u[m] = (const uint16_t*)(kb(i, 0, 1) + o.au[m]);
           D.attr_v[m] = (const uint16_t*)(kb(i, 0, 1) + o.av[m]);
           D.attr_stride[m] = A.width; D.attr_cstride[m] = A.cstride;
-          st = copy_plane(ctx, kb(i, 0, 1) + o.ay[m], A.y, 2, A.width, A.height, A.stride, s);
+          st = copy_plane(ctx, up(i, 1) + o.ay[m], A.y, 2, A.width, A.height, A.stride, s);
           if (st) return st;
           // chroma keeps its source stride: the reference indexes it as a flat array
           // (v/2)*(width/2)+(u/2), src/decoder.rs:977, which for odd widths runs across rows
           const size_t ce = chroma_elems(A);
-          HIP_TRY(ctx, hipMemcpyAsync(kb(i, 0, 1) + o.au[m], A.u, ce * 2, hipMemcpyHostToDevice, s));
-          HIP_TRY(ctx, hipMemcpyAsync(kb(i, 0, 1) + o.av[m], A.v, ce * 2, hipMemcpyHostToDevice, s));
+          HIP_TRY(ctx, hipMemcpyAsync(up(i, 1) + o.au[m], A.u, ce * 2, hipMemcpyHostToDevice, s));
+          HIP_TRY(ctx, hipMemcpyAsync(up(i, 1) + o.av[m], A.v, ce * 2, hipMemcpyHostToDevice, s));
         }
       }
     }
@@ -769,6 +812,19 @@ int gof_create_impl(vpcc_ctx* ctx, const vpcc_frame_desc* frames, uint32_t n_fra
         D.attr_y[m] = D.attr_u[m] = D.attr_v[m] = D.geo[m];
         D.attr_stride[m] = D.attr_cstride[m] = D.geo_stride[m];
       }
+    if (tiled) {
+      D.tiled = 1u;
+      DevFrame& Rd = h_raster[i];                             // the same frame as k_tile_planes reads it: planes in the staging block
+      Rd = D;
+      Rd.tiled = 0u;
+      const ptrdiff_t d = (char*)g->temp[part_of(i)].ptr - kb(i, 0, 0);
+      for (uint32_t m = 0; m < 2; ++m) {
+        Rd.geo[m] = (const uint16_t*)((const char*)D.geo[m] + d);
+        Rd.attr_y[m] = (const uint16_t*)((const char*)D.attr_y[m] + d);
+        Rd.attr_u[m] = (const uint16_t*)((const char*)D.attr_u[m] + d);
+        Rd.attr_v[m] = (const uint16_t*)((const char*)D.attr_v[m] + d);
+      }
+    }
     if (!P.patches.empty())
       HIP_TRY(ctx, hipMemcpyAsync(base + o.patches, P.patches.data(), sizeof(DevPatch) * P.patches.size(),
                                   hipMemcpyHostToDevice, s));
@@ -784,6 +840,13 @@ int gof_create_impl(vpcc_ctx* ctx, const vpcc_frame_desc* frames, uint32_t n_fra
   for (uint32_t i = 0; i < n_frames && tiles_ok; ++i) tiles_ok = tile_planes_aligned(g->h_frames[i]);
   g->general = !tiles_ok;
   HIP_TRY(ctx, hipMemcpyAsync(g->d_frames, g->h_frames.data(), sizeof(DevFrame) * n_frames, hipMemcpyHostToDevice, s));
+  if (tiled) {
+    uint32_t max_blocks = 0;
+    for (uint32_t i = 0; i < n_frames; ++i) max_blocks = std::max(max_blocks, g->plans[i].bw * g->plans[i].bh);
+    HIP_TRY(ctx, hipMalloc((void**)&g->d_raster, sizeof(DevFrame) * n_frames));
+    HIP_TRY(ctx, hipMemcpyAsync(g->d_raster, h_raster.data(), sizeof(DevFrame) * n_frames, hipMemcpyHostToDevice, s));
+    launch_tile_planes(g->d_raster, g->d_frames, 0, n_frames, max_blocks, s);
+  }
   HIP_TRY(ctx, hipMemsetAsync(g->d_counts, 0, sizeof(uint32_t) * n_frames, s));
   HIP_TRY(ctx, hipMemsetAsync(base + ctrl_begin, 0, g->ctrl_bytes, s));
   HIP_TRY(ctx, hipEventRecord(g->upload_done, s));

@@ -277,7 +277,17 @@ __device__ __forceinline__ void load_origin(const Item& it, uint32_t lane, uint3
   px0 = occ ? it.x0 + 4u * (lane & 3u) : it.x0;
   py0 = occ ? it.y0 + (lane >> 2) : it.y0;
 }
+// Tiled planes (DevFrame::tiled): the samples of a 16x16 block are contiguous — lane l's four pixels are samples
+// 4 l .. 4 l + 3 of the block, a wave reads 512 consecutive bytes of a luma plane and 128 of a chroma plane instead of
+// sixteen 32-byte pieces of sixteen lines (eight 16-byte pieces) that it shares with the neighbouring blocks.
+__device__ __forceinline__ uint32_t tile_block(CFrame& f, const Item& it) { return (it.y0 >> 4) * f.bw + (it.x0 >> 4); }
 __device__ __forceinline__ void load_geometry(CFrame& f, const Item& it, uint32_t lane, Samples& s) {
+  if (f.tiled) {
+    const uint32_t off = tile_block(f, it) * 512u + (s.occ ? 8u * lane : 0u);
+    s.g0 = load4_row(f.geo[0], off);
+    s.g1 = load4_row(f.geo[1], off);
+    return;
+  }
   uint32_t px0, py0;
   load_origin(it, lane, s.occ, px0, py0);
   const uint32_t off = (__umul24(py0, f.geo_stride[0]) + px0) * 2u;                // both layers: one video, one row pitch
@@ -288,6 +298,18 @@ __device__ __forceinline__ void load_geometry(CFrame& f, const Item& it, uint32_
 // Attribute samples; chroma is nearest-neighbour (src/decoder.rs:977): pixels 0,1 of the lane use
 // chroma sample px0/2, pixels 2,3 the next one.
 __device__ __forceinline__ void load_attributes(CFrame& f, const Item& it, uint32_t lane, Samples& s) {
+  if (f.tiled) {
+    const uint32_t blk = tile_block(f, it);
+    const uint32_t y0 = blk * 512u + (s.occ ? 8u * lane : 0u);
+    const uint32_t c0 = blk * 128u + (s.occ ? ((lane >> 3) * 8u + (lane & 3u) * 2u) * 2u : 0u);   // chroma row (lane >> 2) >> 1, samples 2 (lane & 3), +1
+    s.y0 = load4_row(f.attr_y[0], y0);
+    s.u0 = load2(f.attr_u[0], c0);
+    s.v0 = load2(f.attr_v[0], c0);
+    s.y1 = load4_row(f.attr_y[1], y0);
+    s.u1 = load2(f.attr_u[1], c0);
+    s.v1 = load2(f.attr_v[1], c0);
+    return;
+  }
   uint32_t px0, py0;
   load_origin(it, lane, s.occ, px0, py0);
   // both layers come from one video: one row pitch (tile_planes_aligned), one offset per plane kind
