@@ -74,7 +74,7 @@ constexpr uint64_t kGenShift = 34;
 constexpr uint64_t kAggregate = 1ull << kStatusShift;
 constexpr uint64_t kPrefix = 2ull << kStatusShift;
 constexpr uint32_t kSpinLimit = 1u << 22;
-constexpr uint32_t kFramesInFlight = 8;     // frames of one XCD label worked on at a time (launches of more than 8 x this many frames run in rounds)
+constexpr uint32_t kFramesInFlight = 16;    // frames of one XCD label worked on at a time (launches of more than 8 x this many frames run in rounds)
 
 __device__ __forceinline__ uint64_t st_load(const uint64_t* p) {
   return __hip_atomic_load(gl(p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -691,16 +691,16 @@ void k_recon_tiles(const DevFrame* __restrict__ frames, uint32_t first,
   const uint32_t variant = kDiagnostic ? variant_arg : 0u;
   // XCD-aware placement (speed only): ids equal mod 8 share an XCD/L2; a frame stays on one label.
   // The frames of one label are interleaved, so the workgroups of ONE frame start a few slots apart.
-  // Launches of more than 64 frames run in ROUNDS: an XCD works on kFramesInFlight frames of its label at a time
+  // Launches of more than 128 frames run in ROUNDS: an XCD works on kFramesInFlight frames of its label at a time
   // (an equal share of its resident workgroups each); a workgroup whose ticket lies past the end of its frame goes on
   // to the frame kFramesInFlight places further down its label at once — its pipeline carries on across the change:
   // it counts the new frame's group while it emits the last group it holds of the old one.  Nobody waits for a
-  // round to end.  Fewer frames in flight share the XCD's 4 MB L2 better, but more workgroups per frame mean longer
-  // look-back chains and more changes of frame.  Measured on 128-frame launches: on blocks as hipMalloc places them
-  // 4 / 8 / 16 frames in flight took 0.5195 / 0.5155 / 0.5016 ms and read 1 285 / 1 347 / 1 439 MB
-  // (profiles/r03/ab_frames_in_flight.txt); on placed blocks (VPCC_GOF_TUNE_PLACEMENT, where the memory system is
-  // 12 % faster and the bytes weigh more) 0.459 / 0.4531 / 0.4537 ms, S-owlii 1.0705 (8) vs 1.0767 (16) and 265 MB
-  // fewer reads (ab_frames_in_flight_placed.txt): 8.
+  // round to end.  Fewer frames in flight shared the XCD's 4 MB L2 better while planes were read in raster layout
+  // (lines shared between neighbouring blocks), but more workgroups per frame mean longer look-back chains and more
+  // changes of frame.  Measured on 128-frame launches: raster planes as hipMalloc places them 4 / 8 / 16 frames in
+  // flight 0.5195 / 0.5155 / 0.5016 ms; raster planes on placed blocks 0.459 / 0.4531 / 0.4537 (and 91 MB fewer
+  // reads with 8); TILED planes (a block's lines are its own) 0.4052 / 0.3989 / 0.3970, S-owlii 0.9546 (8) vs 0.9417
+  // (16), reads all but equal (profiles/r03/ab_frames_in_flight*.txt, ab_tiled.txt): 16.
   const uint32_t xcd = blockIdx.x & 7u, slot = blockIdx.x >> 3;
   const uint32_t frame_groups = (count + 7u) / 8u;
   const bool rounds = frame_groups > kFramesInFlight;
