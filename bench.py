@@ -432,7 +432,7 @@ def main():
             tr = measured_traffic("k_smooth", args.workload, n_batch)
         roofline = {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 1), "peak": HBM_PEAK_GBPS,
                     "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBPS, 4),
-                    "achieved_is": "algorithmic bytes (SURVEY 8d) / kernel time — not a physical HBM rate; that is frac_traffic",
+                    "achieved_is": "algorithmic bytes (SURVEY 8d: whole planes once + 9 B/point) / kernel time — not a physical HBM rate (the kernel reads only the blocks that hold points: frac can exceed 1); that is frac_traffic",
                     "traffic": tr["hbm_bytes_per_launch"] if tr else None,
                     "traffic_stale": stale(tr, "k_recon_tiles") if tr else None,
                     "traffic_measured_on": {"kernel_source_sha16": tr.get("kernel_source_sha16"), "library_sha16": (tr.get("library") or {}).get("sha16")} if tr else None,
