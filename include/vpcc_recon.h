@@ -198,7 +198,10 @@ int vpcc_reconstruct_frame(vpcc_ctx* ctx, const vpcc_frame_desc* frame, vpcc_mem
  * one batched launch sequence.  With VPCC_MEM_HOST the planes are copied to
  * HBM at creation; with VPCC_MEM_DEVICE they are borrowed and must outlive the
  * gof.  capacity_points is the per-frame output capacity (0 = the safe bound
- * vpcc_frame_capacity_bound()). */
+ * vpcc_frame_capacity_bound()).
+ * Planes copied to HBM are re-arranged block by block behind the copy (16x16 samples contiguous: what the
+ * reconstruction kernel reads at once), which takes a second, staging copy of the planes in device memory for
+ * the life of the gof; borrowed device planes are read where and as they are (slower by about a tenth). */
 int  vpcc_gof_create(vpcc_ctx* ctx, const vpcc_frame_desc* frames, uint32_t n_frames,
                      vpcc_memory_kind planes, uint64_t capacity_points, uint32_t gof_flags,
                      vpcc_gof** out);
