@@ -231,6 +231,12 @@ void vpcc_gof_destroy(vpcc_gof* gof);
                                            vpcc_gof_device_outputs before it pins them where they are (no measurement).
                                            Not for a gof launched once (the streaming Decoder does not set it).   */
 
+#define VPCC_GOF_COPY_PLANES      0x20u /* VPCC_MEM_DEVICE only: the planes are copied (device to device, on the context's
+                                           copy stream; they must be complete when vpcc_gof_create is called and may go
+                                           when it returns) into memory of the gof's own and re-arranged like host
+                                           planes: the reconstruction kernel then runs its fast path, and
+                                           VPCC_GOF_TUNE_PLACEMENT can place them.                                 */
+
 /* What VPCC_GOF_TUNE_PLACEMENT did for this gof (all zero when it did not run). */
 typedef struct vpcc_placement_info {
   uint32_t tuned;            /* 1: the measurement ran for this gof, 2: the gof reuses a measured set of blocks  */

@@ -334,6 +334,19 @@ def test_tuned_placement_with_device_planes(ctx):
     for i in (0, 7, 8, 11):
         _check(g.download(i), refs3[i % 3])
     g.close()
+    # VPCC_GOF_COPY_PLANES: the gof takes a copy of the device planes (re-arranged block by block, like host planes):
+    # the caller's planes may go as soon as the gof exists
+    g = ctx.gof(None, capacity=1_000_000, memory=_abi.VPCC_MEM_DEVICE, descs=descs,
+                flags=_abi.VPCC_GOF_TUNE_PLACEMENT | _abi.VPCC_GOF_COPY_PLANES)
+    for x in keepalive:
+        if isinstance(x, torch.Tensor):
+            x.zero_()
+    torch.cuda.synchronize()
+    g.reconstruct()
+    assert g.placement()["tuned"] == 1
+    for i in (0, 7, 8, 11):
+        _check(g.download(i), refs3[i % 3])
+    g.close()
 
 
 TILE_KERNEL_CASES = ["small0", "medium1_randocc", "relative_d1", "overlap", "single_map_extension", "no_attribute",

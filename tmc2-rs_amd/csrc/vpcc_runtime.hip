@@ -321,14 +321,14 @@ extern "C" void vpcc_gof_destroy(vpcc_gof* gof) {
 
 namespace {
 
-// Copies a (possibly strided) host plane into a tight device plane.
+// Copies a (possibly strided) plane of the caller's — host memory, or device memory (VPCC_GOF_COPY_PLANES) — into a
+// tight device plane.
 int copy_plane(vpcc_ctx* ctx, void* dst, const void* src, size_t elem, uint32_t width, uint32_t height,
-               uint32_t stride, hipStream_t s) {
+               uint32_t stride, hipStream_t s, hipMemcpyKind dir = hipMemcpyHostToDevice) {
   if (stride == width) {
-    HIP_TRY(ctx, hipMemcpyAsync(dst, src, (size_t)width * height * elem, hipMemcpyHostToDevice, s));
+    HIP_TRY(ctx, hipMemcpyAsync(dst, src, (size_t)width * height * elem, dir, s));
   } else {
-    HIP_TRY(ctx, hipMemcpy2DAsync(dst, (size_t)width * elem, src, (size_t)stride * elem, (size_t)width * elem, height,
-                                  hipMemcpyHostToDevice, s));
+    HIP_TRY(ctx, hipMemcpy2DAsync(dst, (size_t)width * elem, src, (size_t)stride * elem, (size_t)width * elem, height, dir, s));
   }
   return VPCC_OK;
 }
@@ -541,6 +541,9 @@ int gof_create_impl(vpcc_ctx* ctx, const vpcc_frame_desc* frames, uint32_t n_fra
   g->ctx = ctx;
   g->n_frames = n_frames;
   g->flags = gof_flags;
+  // the planes are copied into memory of the gof's own: host planes always, device planes on request
+  const bool own_planes = kind == VPCC_MEM_HOST || (gof_flags & VPCC_GOF_COPY_PLANES) != 0;
+  const hipMemcpyKind dir = kind == VPCC_MEM_HOST ? hipMemcpyHostToDevice : hipMemcpyDeviceToDevice;
   g->plans.resize(n_frames);
   g->h_frames.resize(n_frames);
 
@@ -557,7 +560,7 @@ int gof_create_impl(vpcc_ctx* ctx, const vpcc_frame_desc* frames, uint32_t n_fra
     // bottleneck of a run once the kernels take 0.5 % of it.
     const auto t_plan = std::chrono::steady_clock::now();
     const uint32_t team = n_frames >= 16 ? std::min<uint32_t>(8u, std::max(1u, std::thread::hardware_concurrency() / 2u)) : 1u;
-    auto work = [&](uint32_t t) { for (uint32_t i = t; i < n_frames; i += team) plan_frame(frames[i], &g->plans[i], kind == VPCC_MEM_HOST); };
+    auto work = [&](uint32_t t) { for (uint32_t i = t; i < n_frames; i += team) plan_frame(frames[i], &g->plans[i], kind == VPCC_MEM_HOST); };   // (the host can read the occupancy only there)
     std::vector<std::thread> helpers;
     for (uint32_t t = 1; t < team; ++t) helpers.emplace_back(work, t);
     work(0);
@@ -637,7 +640,7 @@ int gof_create_impl(vpcc_ctx* ctx, const vpcc_frame_desc* frames, uint32_t n_fra
     o.xyz = takek(i, 1, 0, sizeof(vpcc_point3) * cap);                    // (output block: positions, colours, partition in
     o.rgb = F.attribute_count ? takek(i, 1, 1, sizeof(vpcc_color3) * cap) : 0;   //  this order — the smoothing kernels' 8-byte loads
     o.pidx = (gof_flags & VPCC_GOF_WANT_PATCH_INDEX) ? takek(i, 1, 0, sizeof(uint16_t) * cap) : 0;   // read a few bytes past an element)
-    if (kind == VPCC_MEM_HOST) {
+    if (own_planes) {
       o.occ = takek(i, 0, 0, (size_t)F.occupancy.width * F.occupancy.height);
       for (uint32_t m = 0; m < F.map_count; ++m) {
         o.geo[m] = takek(i, 0, 0, (size_t)F.geometry[m].width * F.geometry[m].height * 2);
@@ -707,7 +710,7 @@ int gof_create_impl(vpcc_ctx* ctx, const vpcc_frame_desc* frames, uint32_t n_fra
   // re-arranged once, right behind their upload, so that a block's samples are contiguous (k_tile_planes): the
   // kernel then reads exactly the blocks it needs, 512 contiguous bytes per wave and plane.  Needs the raster copy
   // as staging (kept with the gof, reused by the context).  VPCC_NO_TILED_PLANES=1 keeps the raster layout.
-  bool tiled = kind == VPCC_MEM_HOST && all_simple && !(gof_flags & VPCC_GOF_FORCE_GENERAL) && !slab && !getenv("VPCC_NO_TILED_PLANES");
+  bool tiled = own_planes && all_simple && !(gof_flags & VPCC_GOF_FORCE_GENERAL) && !slab && !getenv("VPCC_NO_TILED_PLANES");
   for (uint32_t i = 0; i < n_frames && tiled; ++i) {
     const vpcc_frame_desc& F = frames[i];
     tiled = F.width % 16u == 0 && F.height % 16u == 0;
@@ -765,7 +768,7 @@ int gof_create_impl(vpcc_ctx* ctx, const vpcc_frame_desc* frames, uint32_t n_fra
     D.map_count = F.map_count; D.absolute_d1 = F.absolute_d1 ? 1u : 0u; D.has_attr = F.attribute_count ? 1u : 0u;
     D.capacity = (uint32_t)cap;
     D.occ_w = F.occupancy.width; D.occ_h = F.occupancy.height;
-    if (kind == VPCC_MEM_DEVICE) {
+    if (!own_planes) {
       D.occ = F.occupancy.y; D.occ_stride = F.occupancy.stride;
       for (uint32_t m = 0; m < F.map_count; ++m) {
         D.geo[m] = F.geometry[m].y; D.geo_stride[m] = F.geometry[m].stride;
@@ -777,12 +780,12 @@ int gof_create_impl(vpcc_ctx* ctx, const vpcc_frame_desc* frames, uint32_t n_fra
     } else {
       D.occ = (const uint8_t*)(kb(i, 0, 0) + o.occ); D.occ_stride = F.occupancy.width;
       int st = copy_plane(ctx, kb(i, 0, 0) + o.occ, F.occupancy.y, 1, F.occupancy.width, F.occupancy.height,
-                          F.occupancy.stride, s);
+                          F.occupancy.stride, s, dir);
       if (st) return st;
       for (uint32_t m = 0; m < F.map_count; ++m) {
         const vpcc_image_u16& G = F.geometry[m];
         D.geo[m] = (const uint16_t*)(kb(i, 0, 0) + o.geo[m]); D.geo_stride[m] = G.width;
-        st = copy_plane(ctx, up(i, 0) + o.geo[m], G.y, 2, G.width, G.height, G.stride, s);
+        st = copy_plane(ctx, up(i, 0) + o.geo[m], G.y, 2, G.width, G.height, G.stride, s, dir);
         if (st) return st;
         if (F.attribute_count) {
           const vpcc_image_u16& A = F.attribute[m];
@@ -790,13 +793,13 @@ int gof_create_impl(vpcc_ctx* ctx, const vpcc_frame_desc* frames, uint32_t n_fra
           D.attr_u[m] = (const uint16_t*)(kb(i, 0, 1) + o.au[m]);
           D.attr_v[m] = (const uint16_t*)(kb(i, 0, 1) + o.av[m]);
           D.attr_stride[m] = A.width; D.attr_cstride[m] = A.cstride;
-          st = copy_plane(ctx, up(i, 1) + o.ay[m], A.y, 2, A.width, A.height, A.stride, s);
+          st = copy_plane(ctx, up(i, 1) + o.ay[m], A.y, 2, A.width, A.height, A.stride, s, dir);
           if (st) return st;
           // chroma keeps its source stride: the reference indexes it as a flat array
           // (v/2)*(width/2)+(u/2), src/decoder.rs:977, which for odd widths runs across rows
           const size_t ce = chroma_elems(A);
-          HIP_TRY(ctx, hipMemcpyAsync(up(i, 1) + o.au[m], A.u, ce * 2, hipMemcpyHostToDevice, s));
-          HIP_TRY(ctx, hipMemcpyAsync(up(i, 1) + o.av[m], A.v, ce * 2, hipMemcpyHostToDevice, s));
+          HIP_TRY(ctx, hipMemcpyAsync(up(i, 1) + o.au[m], A.u, ce * 2, dir, s));
+          HIP_TRY(ctx, hipMemcpyAsync(up(i, 1) + o.av[m], A.v, ce * 2, dir, s));
         }
       }
     }

@@ -39,6 +39,7 @@ VPCC_GOF_FORCE_GENERAL = 0x2
 VPCC_GOF_PROFILE = 0x4
 VPCC_GOF_ASYNC_UPLOAD = 0x8
 VPCC_GOF_TUNE_PLACEMENT = 0x10
+VPCC_GOF_COPY_PLANES = 0x20
 
 ORIENT_DEFAULT, ORIENT_SWAP, ORIENT_ROT90, ORIENT_ROT180, ORIENT_ROT270 = 0, 1, 2, 3, 4
 ORIENT_MIRROR, ORIENT_MROT90, ORIENT_MROT180, ORIENT_MROT270 = 5, 6, 7, 8
