@@ -102,8 +102,10 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-gpu-state", action="store_true", help="skip the rocm-smi reading of clocks and power under load")
     ap.add_argument("--no-other-configs", action="store_true", help="skip the S-owlii and smoothing legs (`other_configs`)")
-    ap.add_argument("--no-tune-placement", action="store_true",
-                    help="create the resident batches without VPCC_GOF_TUNE_PLACEMENT (blocks stay where hipMalloc put them)")
+    ap.add_argument("--pool-gib", type=int, default=32,
+                    help="vpcc_ctx_reserve: the context's pool (two homes in the two kinds of VRAM regions), as the streaming "
+                         "Decoder's lanes take it (VPCC_DECODER_POOL_GIB, default 32).  0: every gof block is a hipMalloc of its own")
+    ap.add_argument("--no-tune-placement", action="store_true", help=argparse.SUPPRESS)   # accepted for old tool scripts
     ap.add_argument("--diag", action="store_true",
                     help="allow the diagnostic library (VPCC_DIAG_LIB=1, tools/ only): its timings are not the product's")
     ap.add_argument("--no-compare", action="store_true",
@@ -183,11 +185,9 @@ def main():
     cap = 1_000_000 if args.workload == "longdress" else 2_400_000
 
     ctx = recon.Context(local_rank)
+    # the allocation policy of the product: the Decoder's lanes reserve the same pool (decoder.cpp), at no cost per gof
+    pool_info = ctx.reserve(args.pool_gib) if args.pool_gib >= 2 else None
     flags = (_abi.VPCC_GOF_FORCE_GENERAL if args.general else 0) | _abi.VPCC_GOF_PROFILE
-    # the timed batches are resident and launched thousands of times: what VPCC_GOF_TUNE_PLACEMENT is for (the
-    # measurement runs inside the first launch, in the warm-up; `config.placement` reports what it found and cost)
-    tune = 0 if args.no_tune_placement else _abi.VPCC_GOF_TUNE_PLACEMENT
-    flags |= tune
     if args.smooth:
         flags |= _abi.VPCC_GOF_WANT_PATCH_INDEX
     bitdepth = 10 if args.workload == "longdress" else 11
@@ -509,7 +509,7 @@ def main():
         mk = synth.longdress_frame if workload == "longdress" else synth.owlii_frame
         fr2 = frames[:n_distinct] if workload == args.workload else [mk(i) for i in range(n_distinct)]
         cap2 = 1_000_000 if workload == "longdress" else 2_400_000
-        fl = _abi.VPCC_GOF_PROFILE | tune | (_abi.VPCC_GOF_WANT_PATCH_INDEX if smooth else 0)
+        fl = _abi.VPCC_GOF_PROFILE | (_abi.VPCC_GOF_WANT_PATCH_INDEX if smooth else 0)
         g2 = ctx.gof(fr2 * cycles_, capacity=cap2, flags=fl)
         g2.profile_interval(4)
         nb = n_distinct * cycles_
@@ -563,11 +563,10 @@ def main():
                          "frac_traffic": round(tro["hbm_bytes_per_launch"] / (km * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4) if tro else None,
                          "traffic_stale": stale(tro, "k_recon_tiles") if tro else None,
                          "entries_checked": 2 * n_distinct, "equals_oracle": bool(eq)})
-        out2["placement"] = g2.placement() if tune else "as allocated"
         g2.close()
         return out2
 
-    placement_info = [g_.placement() for g_ in gofs] if tune else "as allocated"
+    pool_after = ctx.pool_info() if pool_info else None          # (with the timed batches alive)
     other = None
     if rank == 0 and world == 1 and not args.no_other_configs and not args.smooth and not args.general and args.workload == "longdress":
         for g_ in gofs:                                          # their 5 GB are not needed any more
@@ -640,8 +639,8 @@ def main():
                                    f"over {max(args.cycles, 1)} such GOFs ({n_batch} frames, every copy in device buffers of its own)",
                        "frames_per_step_per_gpu": n_batch, "points_per_step_per_gpu": points_per_step,
                        "distinct_frames": args.frames, "gofs_per_launch": max(args.cycles, 1),
-                       "batches_in_rotation": len(gofs),
-                       "placement": placement_info,
+                       "batches_in_rotation": max(args.gofs, 1),
+                       "pool": pool_after if pool_after else "none: every block of a gof is a hipMalloc of its own",
                        "kernel_path": "general" if args.general else "default",
                        "smoothing": smooth_kw if args.smooth else None,
                        "parallelism": f"frame-sharded x{world}, no collective on the data path"},

@@ -34,7 +34,7 @@
 extern "C" {
 #endif
 
-#define VPCC_ABI_VERSION 3   /* 2: vpcc_ctx_bind_thread, vpcc_decoder_stats, vpcc_gof_profile_interval / _kernel_time_means; portable page-locking */
+#define VPCC_ABI_VERSION 4   /* 4: vpcc_ctx_reserve / vpcc_ctx_pool_info replace VPCC_GOF_TUNE_PLACEMENT / vpcc_gof_placement; planes stay raster.  3,  2: vpcc_ctx_bind_thread, vpcc_decoder_stats, vpcc_gof_profile_interval / _kernel_time_means; portable page-locking */
 
 /* ------------------------------------------------------------------ status */
 typedef enum vpcc_status {
@@ -153,6 +153,36 @@ void* vpcc_ctx_stream(const vpcc_ctx* ctx);
  * platform reports none — nothing was changed); VPCC_ERR_DEVICE when the affinity call fails. */
 int  vpcc_ctx_bind_thread(vpcc_ctx* ctx, int* node_out);
 
+/* Two homes.  VRAM consists of KINDS of regions — 32 GB of physical address space each, alternating — and the memory
+ * system serves a launch whose traffic stays inside one kind about a tenth slower than one that spreads it evenly over
+ * two: the same 128-frame reconstruction takes 0.45 or 0.52 ms depending on where hipMalloc happened to put the gof's
+ * planes and outputs.  Nothing but a measurement tells the kinds apart (virtual addresses do not).
+ * vpcc_ctx_reserve makes ONE allocation of `bytes` (rounded up to whole GiB), classifies its GiB granules once — the
+ * reconstruction kernel's output pattern, positions in granule 0, colours in granule j, is slow (3.7 TB/s against 5.3)
+ * exactly when j is of granule 0's kind; under a millisecond per granule — and from then on every gof of the context
+ * keeps its big blocks (ingested planes, output arrays) there: eight frames (one per XCD) in the home of one kind, the
+ * next eight in the other, so that any launch moves the same bytes in both.  No cost per gof, nothing moves, nothing is
+ * measured again; blocks go back to the pool when their gof is destroyed.  A gof that does not fit takes the other home,
+ * then plain allocations.  When the allocation turns out to lie in one kind only (on some GPUs the first 60 GB of VRAM
+ * are alike), a second one of half its size is looked for further away — behind 16-GiB spacers that are freed again,
+ * up to four times, while a third of the device's memory stays free — and kept as the other home: the pool then holds
+ * 1.5 x `bytes`.  30-50 ms for 32 GiB.  Call it once, before the context's first gof.  VPCC_ERR_STATE: the context has
+ * a pool; VPCC_ERR_DEVICE: no memory for it (the context works as before). */
+typedef struct vpcc_pool_info {
+  uint64_t bytes;              /* size of the pool (0: none)                                                    */
+  uint32_t granules;           /* GiB granules classified                                                       */
+  uint32_t kinds;              /* 2: two kinds found; 1: every pairing ran alike — the homes are one            */
+  uint64_t bytes_of_kind[2];   /* [0]: granule 0's kind                                                         */
+  uint64_t in_use[2];          /* bytes handed out, by kind                                                     */
+  float    probe_gbps_same;    /* the probe's rate in the slowest / fastest pairing, GB/s                       */
+  float    probe_gbps_other;
+  float    ms_spent;           /* allocation + classification, wall clock                                       */
+  uint32_t other_home;         /* blocks that had to go to the other home                                       */
+  uint32_t fallbacks;          /* blocks that did not fit the pool at all (allocations of their own)            */
+} vpcc_pool_info;
+int  vpcc_ctx_reserve(vpcc_ctx* ctx, uint64_t bytes, vpcc_pool_info* out /* may be NULL */);
+int  vpcc_ctx_pool_info(vpcc_ctx* ctx, vpcc_pool_info* out);
+
 /* Plane ingest (stand-in for LibavcodecDecoder::decode, src/decoder.rs:1089-1156, whose Vec<u8> planes
  * are the H2D source): page-locks a host range so that uploads from it are true asynchronous DMA. */
 int  vpcc_host_pin(vpcc_ctx* ctx, const void* ptr, size_t bytes);
@@ -199,9 +229,8 @@ int vpcc_reconstruct_frame(vpcc_ctx* ctx, const vpcc_frame_desc* frame, vpcc_mem
  * HBM at creation; with VPCC_MEM_DEVICE they are borrowed and must outlive the
  * gof.  capacity_points is the per-frame output capacity (0 = the safe bound
  * vpcc_frame_capacity_bound()).
- * Planes copied to HBM are re-arranged block by block behind the copy (16x16 samples contiguous: what the
- * reconstruction kernel reads at once), which takes a second, staging copy of the planes in device memory for
- * the life of the gof; borrowed device planes are read where and as they are (slower by about a tenth). */
+ * Planes stay in the raster layout a video decoder hands over, whoever owns them: the reconstruction kernel
+ * stages the tiles it needs in LDS itself (LDS-DMA), nothing is re-arranged in HBM. */
 int  vpcc_gof_create(vpcc_ctx* ctx, const vpcc_frame_desc* frames, uint32_t n_frames,
                      vpcc_memory_kind planes, uint64_t capacity_points, uint32_t gof_flags,
                      vpcc_gof** out);
@@ -216,36 +245,10 @@ void vpcc_gof_destroy(vpcc_gof* gof);
                                            (vpcc_host_pin) and stay valid until the first vpcc_gof_sync /
                                            vpcc_gof_point_counts / vpcc_gof_download of this gof.          */
 
-#define VPCC_GOF_TUNE_PLACEMENT   0x10u /* for a gof that will be launched many times (a resident batch).  VRAM consists
-                                           of kinds of regions (tens of GB each), and the memory system is fastest when
-                                           a launch's traffic is spread evenly over them: the same launch takes 0.45 ms
-                                           or 0.52 ms depending on where the gof's big arrays lie (DESIGN.md 4.1,
-                                           "Placement").  Nothing tells the kinds apart but a measurement.  With this
-                                           flag the gof keeps its ingested planes and its output arrays in two parts each
-                                           (by frame), and the first whole-gof vpcc_gof_reconstruct measures the kernel on
-                                           candidate allocations of every part (up to VPCC_PLACEMENT_CANDIDATES, default
-                                           16, per block size; no new ones once VPCC_PLACEMENT_BUDGET_MS, default 800 — not
-                                           counting the time allocations wait for the driver, up to five times that —
-                                           have passed), keeps the fastest and frees the rest: 0.2-0.8 s once, 30 GB of
-                                           transient allocations (up to 130 GB where VRAM is alike for a long stretch).  The blocks move during that call:
-                                           vpcc_gof_device_outputs before it pins them where they are (no measurement).
-                                           Not for a gof launched once (the streaming Decoder does not set it).   */
-
 #define VPCC_GOF_COPY_PLANES      0x20u /* VPCC_MEM_DEVICE only: the planes are copied (device to device, on the context's
                                            copy stream; they must be complete when vpcc_gof_create is called and may go
-                                           when it returns) into memory of the gof's own and re-arranged like host
-                                           planes: the reconstruction kernel then runs its fast path, and
-                                           VPCC_GOF_TUNE_PLACEMENT can place them.                                 */
-
-/* What VPCC_GOF_TUNE_PLACEMENT did for this gof (all zero when it did not run). */
-typedef struct vpcc_placement_info {
-  uint32_t tuned;            /* 1: the measurement ran for this gof, 2: the gof reuses a measured set of blocks  */
-  uint32_t candidates;       /* placements measured                                                            */
-  float    ms_as_allocated;  /* per launch with the blocks as hipMalloc returned them                          */
-  float    ms_kept;          /* per launch with the blocks kept                                                */
-  float    ms_spent;         /* wall clock of the measurement (inside the first whole-gof reconstruct)         */
-} vpcc_placement_info;
-int vpcc_gof_placement(vpcc_gof* gof, vpcc_placement_info* out);
+                                           when it returns) into memory of the gof's own — with a reserved pool
+                                           (vpcc_ctx_reserve) into its two homes, like ingested host planes.          */
 
 /* Enqueues the reconstruction of frames [first, first+count) on `hip_stream`
  * (a hipStream_t passed as void*; NULL = the context's own stream).  Returns
@@ -322,9 +325,10 @@ typedef struct vpcc_smoothing_params {
  * frames) — plus 5 bytes per point of capacity and frame for the cell indices and the cell lists.  It is zeroed once,
  * when allocated.  When both filters are asked for with the same grid size, one pass over the points serves both
  * (49 bytes per cell, 4.2 more bytes per point); grids of 2^32 cells and more are not supported.
- * Bounds the all-sum cells rely on (not checked): fewer than 2^22 points of a frame in one cell and
- * count x coordinate, count x patch index below 2^32 (the spec's sums are u32 and wrap there too; a wrapped sum of
- * patch indices could make a mixed cell look pure). */
+ * Bound of the all-sum cells, CHECKED on the device: at most 65 537 points of a frame in one grid cell (65 537 x 65 535
+ * < 2^32: no 32-bit sum of coordinates, colours or patch indices can overflow; the specification's u32 sums would wrap
+ * where the kernels' packed 64-bit adds would carry).  A frame that exceeds it — hundreds of points per position —
+ * makes the gof's next vpcc_gof_point_counts / _download / _frame_status return VPCC_ERR_UNSUPPORTED (sticky). */
 int vpcc_gof_smooth(vpcc_gof* gof, uint32_t first, uint32_t count, const vpcc_smoothing_params* params,
                     void* hip_stream);
 

@@ -210,49 +210,65 @@ def test_ticket_counters_survive_skipped_launches(ctx):
     g.close()
 
 
-def test_tuned_placement_moves_blocks_not_results(ctx):
-    """VPCC_GOF_TUNE_PLACEMENT: the first whole-gof launch measures the kernel on candidate allocations of the planes
-    blocks and the output blocks (two parts each, by frame) and keeps the fastest set; the results are those of an untuned gof and of the oracle,
-    partial launches before it do not trigger it, and a later gof of the same shape reuses the measured pair."""
+def test_pool_homes_hold_the_blocks_not_the_results():
+    """vpcc_ctx_reserve: the context classifies the granules of ONE allocation by kind of VRAM region and every gof keeps
+    its planes and outputs there, eight frames in one home, the next eight in the other.  Results are those of a gof
+    without a pool and of the oracle; blocks return to the pool when their gof goes; a gof that does not fit falls back."""
+    c = recon.Context(0)
+    info = c.reserve(36)                                          # a context of its own: the pool lives as long as it does
+    assert info["GiB"] in (36, 54) and info["granules"] == info["GiB"] and info["kinds"] in (1, 2), info   # (54: the second home lay further away)
+    assert sum(info["GiB_of_kind"]) == info["GiB"] and info["in_use_MB"] == [0, 0]
+    assert info["probe_GBps_same_kind"] > 500, info
     distinct = [synth.longdress_frame(i) for i in range(5)]
     refs5 = [ob.reconstruct(f)[1] for f in distinct]
     n = 20                                                        # frames 0-7 and 16-19: part 0, frames 8-15: part 1
     frames = [distinct[i % 5] for i in range(n)]
     refs = [refs5[i % 5] for i in range(n)]
-    flags = _abi.VPCC_GOF_WANT_PATCH_INDEX | _abi.VPCC_GOF_TUNE_PLACEMENT
-    g = ctx.gof(frames, capacity=1_000_000, flags=flags)
+    g = c.gof(frames, capacity=1_000_000, flags=_abi.VPCC_GOF_WANT_PATCH_INDEX)
+    used = c.pool_info()
+    assert sum(used["in_use_MB"]) > 300 and used["blocks_outside_pool"] == 0, used
+    if used["kinds"] == 2 and min(used["GiB_of_kind"]) >= 2:
+        assert min(used["in_use_MB"]) > 100, used               # both homes hold a part
     g.reconstruct(first=6, count=5)
-    assert g.placement()["tuned"] == 0
     for i in range(6, 11):
         _check(g.download(i, want_patch_index=True), refs[i])
     g.reconstruct()
-    p = g.placement()
-    assert p["tuned"] == 1 and p["candidates"] >= 4 and 0 < p["ms_kept"] <= 1.05 * p["ms_as_allocated"], p
     for i in range(n):
         _check(g.download(i, want_patch_index=True), refs[i])
-    g.reconstruct(first=7, count=3)
-    g.reconstruct()
-    for i in (0, 7, 8, 15, 16, 19):
-        _check(g.download(i, want_patch_index=True), refs[i])
-    g.smooth(10, grid_size=8, threshold=4)                      # the filters follow the blocks
+    g.smooth(10, grid_size=8, threshold=4)
     g.sync()
+    g2 = c.gof(frames[:9], capacity=1_000_000)                      # a second gof beside it
+    g2.reconstruct()
+    for i in (0, 8):
+        _check(g2.download(i), refs[i])
     g.close()
-    g = ctx.gof(frames, capacity=1_000_000, flags=flags)           # the pair kept by the context
+    g2.close()
+    assert c.pool_info()["in_use_MB"] == [0, 0]
+    with pytest.raises(recon.VpccError):
+        c.reserve(4)                                              # one pool per context
+    c.close()
+
+
+def test_pool_too_small_falls_back():
+    c = recon.Context(0)
+    c.reserve(2)
+    frames = [synth.longdress_frame(i % 3) for i in range(128)]     # 2.3 GB of planes + 3.6 GB of outputs: more than the pool
+    g = c.gof(frames, capacity=3_000_000)                           # holds even with a second slab (2 + 2 GiB)
+    assert c.pool_info()["blocks_outside_pool"] >= 1
     g.reconstruct()
-    assert g.placement()["tuned"] == 2
-    for i in (0, 9, 19):
-        _check(g.download(i, want_patch_index=True), refs[i])
+    for i in (0, 64, 127):
+        _check(g.download(i), ob.reconstruct(frames[i])[1])
     g.close()
+    c.close()
 
 
-def test_device_outputs_pin_the_blocks(ctx):
-    """Pointers handed out by vpcc_gof_device_outputs stay valid: asking for them before the first launch switches the
-    placement measurement off for that gof."""
+def test_device_outputs_stay_valid(ctx):
+    """Pointers handed out by vpcc_gof_device_outputs stay valid across launches (nothing ever moves a gof's blocks)."""
     frames = [synth.longdress_frame(i) for i in range(4)]
-    g = ctx.gof(frames, capacity=1_000_000, flags=_abi.VPCC_GOF_TUNE_PLACEMENT)
+    g = ctx.gof(frames, capacity=1_000_000)
     before = [g.device_outputs(i) for i in range(4)]
     g.reconstruct()
-    assert g.placement()["tuned"] == 0
+    g.reconstruct()
     assert [g.device_outputs(i) for i in range(4)] == before
     _check(g.download(3), ob.reconstruct(frames[3])[1])
     g.close()
@@ -302,10 +318,12 @@ def test_device_resident_planes(ctx):
     g.close()
 
 
-def test_tuned_placement_with_device_planes(ctx):
-    """VPCC_GOF_TUNE_PLACEMENT on a gof whose planes are the caller's device memory: only the output parts can be
-    placed (the planes stay where the caller put them); results as ever."""
+def test_copied_device_planes():
+    """VPCC_GOF_COPY_PLANES: the gof takes a copy of the caller's device planes (into the pool's homes when the context
+    has one): the caller's planes may go as soon as the gof exists."""
     import torch
+    c = recon.Context(0)
+    c.reserve(4)
     distinct = [synth.longdress_frame(i) for i in range(3)]
     refs3 = [ob.reconstruct(f)[1] for f in distinct]
     dev = torch.device("cuda:0")
@@ -327,56 +345,21 @@ def test_tuned_placement_with_device_planes(ctx):
             d.attribute[m].y, d.attribute[m].u, d.attribute[m].v = (up(p) for p in f["attribute"][m])
         descs.append(d)
     torch.cuda.synchronize()
-    g = ctx.gof(None, capacity=1_000_000, memory=_abi.VPCC_MEM_DEVICE, descs=descs, flags=_abi.VPCC_GOF_TUNE_PLACEMENT)
+    g = c.gof(None, capacity=1_000_000, memory=_abi.VPCC_MEM_DEVICE, descs=descs)      # borrowed planes
     g.reconstruct()
-    p = g.placement()
-    assert p["tuned"] == 1 and p["candidates"] >= 2, p
     for i in (0, 7, 8, 11):
         _check(g.download(i), refs3[i % 3])
     g.close()
-    # VPCC_GOF_COPY_PLANES: the gof takes a copy of the device planes (re-arranged block by block, like host planes):
-    # the caller's planes may go as soon as the gof exists
-    g = ctx.gof(None, capacity=1_000_000, memory=_abi.VPCC_MEM_DEVICE, descs=descs,
-                flags=_abi.VPCC_GOF_TUNE_PLACEMENT | _abi.VPCC_GOF_COPY_PLANES)
+    g = c.gof(None, capacity=1_000_000, memory=_abi.VPCC_MEM_DEVICE, descs=descs, flags=_abi.VPCC_GOF_COPY_PLANES)
     for x in keepalive:
         if isinstance(x, torch.Tensor):
             x.zero_()
     torch.cuda.synchronize()
     g.reconstruct()
-    assert g.placement()["tuned"] == 1
     for i in (0, 7, 8, 11):
         _check(g.download(i), refs3[i % 3])
     g.close()
-
-
-TILE_KERNEL_CASES = ["small0", "medium1_randocc", "relative_d1", "overlap", "single_map_extension", "no_attribute",
-                     "gray_exact_boundaries", "wide_samples", "precision1_block16", "precision2_block16",
-                     "precision8_block16", "precision16_block16", "truncation_degenerate_axes"]
-GENERAL_SEQUENCE_CASES = ["exotic_orientations", "block8_ragged", "block32_multichunk"]
-
-
-@pytest.mark.parametrize("name", TILE_KERNEL_CASES + GENERAL_SEQUENCE_CASES)
-def test_which_kernel_path_ran(ctx, name):
-    """The parity cases above must exercise the kernel they are meant for: the single-pass tile kernel for
-    block size 16 with Default/Swap patches, the general sequence for everything else — and both must match
-    the oracle when the general sequence is forced."""
-    f = cases.PARITY_CASES[name]()
-    st, ref = ob.reconstruct(f)
-    g = ctx.gof([f], flags=_abi.VPCC_GOF_PROFILE | _abi.VPCC_GOF_WANT_PATCH_INDEX)
-    g.reconstruct()
-    names = [k for k, _ in g.kernel_times()]
-    if name in TILE_KERNEL_CASES:
-        assert names == ["k_recon_tiles"], names
-    else:
-        assert "k_emit" in names and "k_recon_tiles" not in names, names
-    _check(g.download(0, want_patch_index=True), ref, colour=f.get("attribute_count", 1) > 0)
-    g.close()
-    g = ctx.gof([f], flags=_abi.VPCC_GOF_FORCE_GENERAL | _abi.VPCC_GOF_WANT_PATCH_INDEX)
-    g.reconstruct()
-    _check(g.download(0, want_patch_index=True), ref, colour=f.get("attribute_count", 1) > 0)
-    g.close()
-
-
+    c.close()
 def test_random_sweep_against_oracle(ctx):
     """Seeded sweep over canvas sizes, precisions, occupancy value styles, patch statistics and map counts;
     every frame runs through the single-pass kernel (block size 16) in ONE batch and must equal the oracle."""

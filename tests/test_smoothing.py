@@ -104,6 +104,84 @@ def test_hip_smoothing_matches_spec(frames, params):
 
 
 @pytest.mark.gpu
+def test_smoothing_in_chunks_of_frames(monkeypatch):
+    """A gof whose grids exceed the scratch limit (16 GiB; 11-bit content with grid 8 needs 0.8 GB per frame) is smoothed
+    in chunks of frames that reuse the same scratch slots.  With both filters in one pass the moved-point bits of a slot
+    must not survive into the next chunk: a big frame in which half of all points move, then smaller ones in its slot."""
+    from tmc2rs import recon
+    rng = np.random.RandomState(11)
+    fr = [cases.overlapping_3d_frame(0, base=synth.longdress_frame(1)), cases.overlapping_3d_frame(1), cases.overlapping_3d_frame(2),
+          cases.overlapping_3d_frame(0, base=synth.longdress_frame(2)), cases.overlapping_3d_frame(3)]
+    for f in fr:
+        d0 = rng.randint(0, 800, size=f["geometry"][0].shape).astype(np.uint16)
+        f["geometry"] = [d0, (d0 + rng.randint(0, 64, size=d0.shape)).astype(np.uint16)]
+    params = dict(grid_size=8, threshold=1, color_grid_size=8, color_threshold_smoothing=5, color_threshold_difference=200)
+    ctx = recon.Context(0)
+    for limit_mb, frames_per_chunk in ((250, 2), (120, 1)):           # a slot is 98 MB (grid 8, 10 bits, both filters)
+        monkeypatch.setenv("VPCC_SMOOTH_SCRATCH_LIMIT_MB", str(limit_mb))
+        g = ctx.gof(fr, flags=_abi.VPCC_GOF_WANT_PATCH_INDEX)
+        g.reconstruct()
+        before = [g.download(i, want_patch_index=True) for i in range(len(fr))]
+        assert before[0]["n"] > 2 * before[1]["n"]
+        g.smooth(10, **params)
+        for i, b in enumerate(before):
+            after = g.download(i)
+            exp_xyz = ob.spec_smooth_geometry(b["xyz"], b["patch_index"], 10, 8, 1)
+            exp_rgb = ob.spec_smooth_color(exp_xyz, b["rgb"], b["patch_index"], 10, 8, 5, 200)
+            assert np.any(exp_xyz != b["xyz"])
+            assert np.array_equal(after["xyz"], exp_xyz), (frames_per_chunk, i)
+            assert np.array_equal(after["rgb"], exp_rgb), (frames_per_chunk, i)
+        g.close()
+    ctx.close()
+
+
+def _collapsed_frame(n_blocks):
+    """Every patch is one fully occupied block whose 512 points (lod 0: all pixels share the tangent and bitangent
+    coordinate; two depths) fall into ONE grid cell."""
+    f = synth.make_frame(320, 256, 4, 16, seed=5, max_side=2, cover_target=0.5)
+    bw = 320 // 16
+    p = np.zeros(n_blocks, dtype=_abi.PATCH_DTYPE)
+    p["u0"] = np.arange(n_blocks) % bw
+    p["v0"] = np.arange(n_blocks) // bw
+    p["size_u0"] = p["size_v0"] = 1
+    p["u1"], p["v1"], p["d1"] = 101, 102, 96
+    p["lod_x"] = p["lod_y"] = 0
+    p["normal_axis"], p["tangent_axis"], p["bitangent_axis"] = 0, 2, 1
+    f["patches"] = p
+    f["occupancy"] = np.ones_like(f["occupancy"])
+    f["geometry"] = [np.full_like(f["geometry"][0], 8), np.full_like(f["geometry"][1], 12)]    # depths 2 and 3
+    return f
+
+
+@pytest.mark.gpu
+def test_smoothing_cell_bound_is_checked():
+    """The cells' 32-bit sums hold 65 537 points of 16-bit values: at the bound the result is the specification's, beyond
+    it the gof reports VPCC_ERR_UNSUPPORTED instead of a silently different output."""
+    from tmc2rs import recon
+    ctx = recon.Context(0)
+    params = dict(grid_size=8, threshold=0, color_grid_size=8, color_threshold_smoothing=0, color_threshold_difference=765)
+    g = ctx.gof([_collapsed_frame(128), cases.overlapping_3d_frame(0)], flags=_abi.VPCC_GOF_WANT_PATCH_INDEX)   # 128 x 512 = 65 536 points in one cell
+    g.reconstruct()
+    b = g.download(0, want_patch_index=True)
+    assert b["n"] == 65536 and len(np.unique(b["xyz"] // 8, axis=0)) == 1
+    g.smooth(10, **params)
+    after = g.download(0)
+    exp_xyz = ob.spec_smooth_geometry(b["xyz"], b["patch_index"], 10, 8, 0)
+    assert np.array_equal(after["xyz"], exp_xyz)
+    assert np.array_equal(after["rgb"], ob.spec_smooth_color(exp_xyz, b["rgb"], b["patch_index"], 10, 8, 0, 765))
+    g.close()
+    g = ctx.gof([_collapsed_frame(200)], flags=_abi.VPCC_GOF_WANT_PATCH_INDEX)                                    # 102 400 points in one cell
+    g.reconstruct()
+    assert g.download(0)["n"] == 102400
+    g.smooth(10, **params)
+    with pytest.raises(recon.VpccError) as e:
+        g.download(0)
+    assert e.value.status == _abi.VPCC_ERR_UNSUPPORTED and "one grid cell" in str(e.value)
+    g.close()
+    ctx.close()
+
+
+@pytest.mark.gpu
 def test_smoothing_needs_patch_index():
     from tmc2rs import recon
     ctx = recon.Context(0)

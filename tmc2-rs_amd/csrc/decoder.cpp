@@ -192,6 +192,33 @@ void Decoder::worker() {
   for (size_t d = 0; d < G; ++d)
     if (lanes[d]->post([](vpcc_ctx* c) { return c ? 0 : 1; }).get()) { fail("vpcc_ctx_create failed: no usable gfx950 device (no CPU fallback)"); return; }
   step("contexts ready");
+  // Two homes (vpcc_ctx_reserve): every lane's context gets its pool — on a thread of its own beside the lane, so that
+  // neither the first frame nor the uploads wait for the allocation and its classification (30-50 ms; more when the
+  // driver is still wiping memory an earlier process gave back).  Gofs created before it is ready allocate as before;
+  // all later ones keep their planes and outputs in it, spread over both kinds of VRAM regions.  Streams of a single
+  // unit do not bother; VPCC_DECODER_POOL_GIB=0 switches it off.
+  struct Reservers {
+    std::vector<std::thread> t;
+    ~Reservers() { for (auto& x : t) if (x.joinable()) x.join(); }      // before the lanes (and their contexts) go
+  } reservers;
+  {
+    const char* e = std::getenv("VPCC_DECODER_POOL_GIB");
+    const uint64_t gib = e ? (uint64_t)std::strtoull(e, nullptr, 10) : 32u;
+    const bool tr = std::getenv("VPCC_DECODER_TRACE") != nullptr;
+    if (gib >= 2 && gofs_.size() > 1)
+      for (size_t d = 0; d < G; ++d) {
+        vpcc_ctx* c = nullptr;
+        lanes[d]->post([&c](vpcc_ctx* x) { c = x; return 0; }).get();
+        reservers.t.emplace_back([c, gib, tr] {
+          vpcc_pool_info pi{};
+          const int st = vpcc_ctx_reserve(c, gib << 30, &pi);        // no memory for it: the gofs allocate as before
+          if (tr)
+            std::fprintf(stderr, "[vpcc decoder] pool of %llu GiB: %s, %u kind(s), %llu + %llu GiB, %.1f ms\n", (unsigned long long)gib,
+                         st ? vpcc_status_string(st) : "reserved", pi.kinds, (unsigned long long)(pi.bytes_of_kind[0] >> 30),
+                         (unsigned long long)(pi.bytes_of_kind[1] >> 30), pi.ms_spent);
+        });
+      }
+  }
   stats_.lanes = (uint32_t)G;
   for (size_t d = 0; d < G && d < 8; ++d) stats_.numa_node[d] = lanes[d]->numa_node();
 

@@ -90,8 +90,6 @@ struct DevFrame {
   uint32_t capacity;
   uint32_t n_tiles;           // number of tile items (the array is padded to a multiple of 16 readable items)
   uint32_t prec_shift;        // log2(prec) when prec is a power of two (tile kernel)
-  uint32_t tiled;             // geometry and attribute planes are stored block by block (k_tile_planes): block b of a luma
-                              //   plane = 256 consecutive samples (16 rows of 16), of a chroma plane 64 (8 rows of 8); b = by * bw + bx
 };
 
 // One grid cell of the smoothing filters (oracle/vpcc_smoothing_spec.h): all-zero = empty.
@@ -110,6 +108,10 @@ struct SmoothCell {
 };
 static_assert(sizeof(SmoothCell) == 32, "SmoothCell is 32 B");
 constexpr uint32_t kSmoothMixed = 1u, kSmoothPainted = 2u;
+// 65 537 x 65 535 < 2^32: up to this many points in a cell no sum of 16-bit values (coordinates, patch indices) leaves its 32 bits
+constexpr uint32_t kSmoothCellMaxPoints = 65537u;
+// DevFrame::error_flag bits
+constexpr uint32_t kErrorSpinLimit = 1u, kErrorSmoothCellOverflow = 2u;
 // R, G, B sums of a cell when ONE statistics pass serves both filters (same grid size): a parallel array.
 // What the colour filter needs of a cell, in 16 bytes: the point count with the mixed bit above it, and the sums.
 struct SmoothColorCell { uint32_t count, s[3]; };
@@ -164,11 +166,6 @@ void launch_smooth_mark(const DevFrame* d_frames, uint32_t first, uint32_t count
 void launch_smooth_clear(const DevFrame* d_frames, uint32_t first, uint32_t count, uint32_t max_points, SmoothGrid sg,
                          uint32_t w, bool both, void* stream);
 
-// Re-arranges the geometry and attribute planes of frames [first, first + count) from the raster layout (`raster`: the
-// frames' descriptors with raster pointers and strides) into the block-by-block layout (`tiled`: the same frames with the
-// destination pointers).  Both arrays on the device.
-void launch_tile_planes(const DevFrame* raster, const DevFrame* tiled, uint32_t first, uint32_t count, uint32_t max_blocks,
-                        void* stream);
 // Kernel launchers (vpcc_kernels.hip).  All asynchronous on `stream`.
 void launch_block_owner(const DevFrame* d_frames, uint32_t first, uint32_t count, uint32_t max_vb,
                         void* stream);
@@ -191,6 +188,8 @@ void plan_tile_launch(const uint32_t* tiles, uint32_t count, uint32_t resident_p
 void launch_tiles(const DevFrame* d_frames, uint32_t first, uint32_t count, uint32_t max_groups, uint32_t gen,
                   const TileLaunchMap& map, uint32_t resident_per_xcd,
                   void* stream);
+// vpcc_ctx_reserve's probe: the tile kernel's output pattern between two arrays (positions: items * 1824 B, colours: items * 912 B)
+void launch_probe_outputs(unsigned char* xyz, unsigned char* rgb, uint32_t items, void* stream);
 void launch_upsample_occupancy(const DevFrame* d_frames, uint32_t frame, uint8_t* d_out, uint32_t width,
                                uint32_t height, void* stream);
 

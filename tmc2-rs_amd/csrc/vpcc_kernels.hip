@@ -179,38 +179,32 @@ void launch_emit(const DevFrame* d_frames, uint32_t first, uint32_t count, uint3
   if (!count || !max_vb) return;
   hipLaunchKernelGGL(k_emit, dim3(max_vb, count), dim3(256), 0, (hipStream_t)stream, d_frames, first);
 }
-// Raster planes -> block-by-block planes (DevFrame::tiled), a wave per 16x16 block: lane l moves the block's pixels
-// 4 (l & 3) .. + 3 of row l >> 2 of every luma plane (8 bytes) to bytes 8 l .. of the block's 512; lanes 0-15 move the
-// 8x8 chroma block the same way (row l >> 1, samples 4 (l & 1) .. + 3).  Every block of the canvas, once per gof.
-__global__ __launch_bounds__(256) void k_tile_planes(const DevFrame* __restrict__ raster, const DevFrame* __restrict__ tiled,
-                                                     uint32_t first) {
-  const DevFrame& r = raster[first + blockIdx.y];
-  const DevFrame& t = tiled[first + blockIdx.y];
-  const uint32_t blk = blockIdx.x * 4u + (threadIdx.x >> 6), lane = threadIdx.x & 63u;
-  if (blk >= r.bw * r.bh) return;
-  const uint32_t x0 = (blk % r.bw) * 16u, y0 = (blk / r.bw) * 16u;
-  typedef uint32_t v2 __attribute__((ext_vector_type(2)));
-  const uint32_t px = x0 + 4u * (lane & 3u), py = y0 + (lane >> 2);
-  for (uint32_t m = 0; m < r.map_count; ++m) {
-    *(VPCC_GLOBAL v2*)((VPCC_GLOBAL unsigned char*)t.geo[m] + blk * 512u + 8u * lane) =
-        *(const VPCC_GLOBAL v2*)((const VPCC_GLOBAL unsigned char*)r.geo[m] + ((size_t)py * r.geo_stride[m] + px) * 2u);
-    if (r.has_attr) {
-      *(VPCC_GLOBAL v2*)((VPCC_GLOBAL unsigned char*)t.attr_y[m] + blk * 512u + 8u * lane) =
-          *(const VPCC_GLOBAL v2*)((const VPCC_GLOBAL unsigned char*)r.attr_y[m] + ((size_t)py * r.attr_stride[m] + px) * 2u);
-      if (lane < 16u) {
-        const size_t c = ((size_t)(y0 / 2u + (lane >> 1)) * r.attr_cstride[m] + x0 / 2u + 4u * (lane & 1u)) * 2u;
-        *(VPCC_GLOBAL v2*)((VPCC_GLOBAL unsigned char*)t.attr_u[m] + blk * 128u + 8u * lane) =
-            *(const VPCC_GLOBAL v2*)((const VPCC_GLOBAL unsigned char*)r.attr_u[m] + c);
-        *(VPCC_GLOBAL v2*)((VPCC_GLOBAL unsigned char*)t.attr_v[m] + blk * 128u + 8u * lane) =
-            *(const VPCC_GLOBAL v2*)((const VPCC_GLOBAL unsigned char*)r.attr_v[m] + c);
+// The reconstruction kernel's output pattern, alone: 4 096 waves, each writing runs of 304 points — 1 824 B of positions into
+// `xyz`, 912 B of colours into `rgb` — with the kernel's store instructions (12 B per lane non-temporal, colours from the
+// even lanes, runs of neighbouring waves adjacent).  Its rate tells whether the two arrays lie in one kind of VRAM region
+// or in two (vpcc_ctx_reserve); the bytes it writes mean nothing.
+__global__ __launch_bounds__(256) void k_probe_outputs(unsigned char* __restrict__ xyz, unsigned char* __restrict__ rgb, uint32_t items) {
+  typedef uint32_t u32x3 __attribute__((ext_vector_type(3)));
+  const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63u;
+  const uint32_t groups = (items + 15u) / 16u;
+  for (uint32_t g = blockIdx.x; g < groups; g += gridDim.x)
+    for (uint32_t t = 0; t < 4; ++t) {
+      const uint32_t i = g * 16u + t * 4u + wave;
+      if (i >= items) continue;
+      VPCC_GLOBAL unsigned char* px = (VPCC_GLOBAL unsigned char*)xyz + (size_t)i * 1824u;
+      VPCC_GLOBAL unsigned char* pc = (VPCC_GLOBAL unsigned char*)rgb + (size_t)i * 912u;
+      const int shift = (int)(((size_t)i * 304u) & 127u);
+      for (int kk = 2 * (int)lane; kk < 304 + shift; kk += 128) {
+        const int k = kk - shift;
+        if (k < 0 || k + 1 >= 304) continue;
+        const u32x3 v = {(uint32_t)k, lane, i};
+        __builtin_nontemporal_store(v, (VPCC_GLOBAL u32x3*)(px + k * 6));
+        if (!(lane & 1u) && k + 3 < 304) __builtin_nontemporal_store(v, (VPCC_GLOBAL u32x3*)(pc + k * 3));
       }
     }
-  }
 }
-void launch_tile_planes(const DevFrame* raster, const DevFrame* tiled, uint32_t first, uint32_t count, uint32_t max_blocks,
-                        void* stream) {
-  if (!count || !max_blocks) return;
-  hipLaunchKernelGGL(k_tile_planes, dim3((max_blocks + 3) / 4, count), dim3(256), 0, (hipStream_t)stream, raster, tiled, first);
+void launch_probe_outputs(unsigned char* xyz, unsigned char* rgb, uint32_t items, void* stream) {
+  hipLaunchKernelGGL(k_probe_outputs, dim3(1024), dim3(256), 0, (hipStream_t)stream, xyz, rgb, items);
 }
 
 void launch_upsample_occupancy(const DevFrame* d_frames, uint32_t frame, uint8_t* d_out, uint32_t width,

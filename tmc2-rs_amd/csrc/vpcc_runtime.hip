@@ -12,6 +12,7 @@
 #include <algorithm>
 #include <cctype>
 #include <chrono>
+#include <mutex>
 #include <cstdio>
 #include <cstring>
 #include <string>
@@ -35,21 +36,28 @@ struct vpcc_ctx {
   // Arenas of destroyed GOFs are kept for the next GOF of the same shape: hipMalloc/hipFree cost
   // milliseconds and hipFree synchronises the whole device, which would stall a GOF pipeline.
   std::vector<std::pair<void*, size_t>> arena_cache;
-  // The big blocks of a gof — the video planes it ingested and its output arrays, each in kParts parts by frame —
-  // are allocations of their own, chosen by measurement (place_blocks below); the sets of destroyed gofs are kept with
-  // their score.
+  // The big blocks of a gof — the video planes it ingested and its output arrays — are kept in kParts parts by frame
+  // (eight frames, one per XCD label, to part 0, the next eight to part 1, ...), and with a reserved pool
+  // (vpcc_ctx_reserve) part p lies in home p: VRAM consists of KINDS of regions, 32 GB each, and a launch whose
+  // traffic stays inside one kind is served 10 % slower than one that spreads it evenly over two (DESIGN.md 4.1,
+  // "Two homes").  Which kind a piece of memory belongs to only a measurement tells: the pool is ONE allocation whose
+  // GiB granules are classified once, when it is reserved, by timing the reconstruction kernel's output pattern
+  // between granule 0 and each of them.
   static constexpr int kParts = 2;
-  struct Block { void* ptr = nullptr; size_t bytes = 0; };
-  struct Placement {
-    Block block[2 * kParts];                             // [2 * part]: ingested planes (VPCC_MEM_HOST gofs only),
-                                                         // [2 * part + 1]: positions, colours, partition
-    float score = 0.f;                                   // 1 / ms of the launch that chose the set (0 = never measured)
-    vpcc_placement_info info{};
-    bool any() const { for (const Block& b : block) if (b.ptr) return true; return false; }
-    void release() { for (Block& b : block) { if (b.ptr) (void)hipFree(b.ptr); b = Block{}; } }
-  };
-  std::vector<Placement> placement_cache;
-  std::vector<Block> temp_cache;        // raster staging blocks of destroyed gofs (tiled planes), a handful
+  struct Block { void* ptr = nullptr; size_t bytes = 0; bool pooled = false; uint32_t run = 0; };
+  struct Pool {
+    static constexpr size_t kGranule = size_t(1) << 30;
+    std::vector<void*> slabs;                            // the allocations (one; two when the first lay in one kind only)
+    struct Run { char* ptr; size_t bytes; int kind; };   // maximal stretches of granules of one kind inside a slab
+    std::vector<Run> runs;
+    struct Extent { char* ptr; size_t bytes; uint32_t run; };
+    std::vector<Extent> free_[2];                        // by kind, sorted by address, coalesced within a run
+    vpcc_pool_info info{};
+    bool reserved() const { return !slabs.empty(); }
+  } pool;
+  std::mutex pool_mutex;                                 // gofs of one context may be destroyed from another thread
+  bool pool_pending = false;                             // a vpcc_ctx_reserve is under way
+  std::vector<Block> block_cache;                        // big blocks of destroyed gofs that are allocations of their own
 };
 
 struct KernelTiming {
@@ -75,11 +83,7 @@ struct vpcc_gof {
   std::vector<DevFrame> h_frames;      // host mirror of d_frames
   void* arena = nullptr;
   size_t arena_bytes = 0;
-  vpcc_ctx::Placement mem;             // the planes blocks and the output blocks
-  vpcc_ctx::Block temp[vpcc_ctx::kParts];   // tiled planes: where the raster planes were uploaded to (kept until the gof goes)
-  DevFrame* d_raster = nullptr;        //   ... and the descriptors k_tile_planes read them through
-  std::vector<DevFrame> h_raster;      //   (their host copy: alive as long as an upload may read it)
-  bool placed = false;                 // the blocks are final (place_blocks ran, or the caller holds pointers into them)
+  vpcc_ctx::Block block[2 * vpcc_ctx::kParts];   // [2 * part]: ingested planes (gofs that own their planes), [2 * part + 1]: positions, colours, partition
   DevFrame* d_frames = nullptr;
   uint32_t* d_counts = nullptr;        // n_frames contiguous point counters
   uint32_t* d_b2p = nullptr;           // all frames' block_to_patch, contiguous
@@ -184,8 +188,8 @@ extern "C" void vpcc_ctx_destroy(vpcc_ctx* ctx) {
   if (!ctx) return;
   (void)hipSetDevice(ctx->device);
   for (auto& a : ctx->arena_cache) (void)hipFree(a.first);
-  for (auto& b : ctx->placement_cache) b.release();
-  for (auto& b : ctx->temp_cache) (void)hipFree(b.ptr);
+  for (void* q : ctx->pool.slabs) (void)hipFree(q);
+  for (auto& b : ctx->block_cache) (void)hipFree(b.ptr);
   if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
   if (ctx->copy_stream) (void)hipStreamDestroy(ctx->copy_stream);
   if (ctx->d2h_stream) (void)hipStreamDestroy(ctx->d2h_stream);
@@ -276,6 +280,215 @@ extern "C" uint64_t vpcc_frame_capacity_bound(const vpcc_frame_desc* frame) {
   return (uint64_t)frame->map_count * frame->width * frame->height;
 }
 
+// ------------------------------------------------------------ pool ("two homes")
+namespace {
+
+// Blocks of destroyed gofs that did not come from the pool are kept for the next gof of the same size: hipMalloc /
+// hipFree cost milliseconds and hipFree synchronises the whole device, which would stall a GOF pipeline.
+constexpr size_t kBlockCacheEntries = 8;
+
+void pool_insert_free(vpcc_ctx::Pool& P, uint32_t run, char* ptr, size_t bytes) {
+  auto& F = P.free_[P.runs[run].kind];
+  size_t k = 0;
+  while (k < F.size() && F[k].ptr < ptr) ++k;
+  F.insert(F.begin() + k, vpcc_ctx::Pool::Extent{ptr, bytes, run});
+  if (k + 1 < F.size() && F[k + 1].run == run && F[k].ptr + F[k].bytes == F[k + 1].ptr) { F[k].bytes += F[k + 1].bytes; F.erase(F.begin() + k + 1); }
+  if (k > 0 && F[k - 1].run == run && F[k - 1].ptr + F[k - 1].bytes == F[k].ptr) { F[k - 1].bytes += F[k].bytes; F.erase(F.begin() + k); }
+}
+
+bool pool_take(vpcc_ctx::Pool& P, int kind, size_t bytes, vpcc_ctx::Block* out) {
+  auto& F = P.free_[kind];
+  for (size_t k = 0; k < F.size(); ++k)
+    if (F[k].bytes >= bytes) {
+      *out = vpcc_ctx::Block{F[k].ptr, bytes, true, F[k].run};
+      F[k].ptr += bytes;
+      F[k].bytes -= bytes;
+      if (!F[k].bytes) F.erase(F.begin() + k);
+      P.info.in_use[kind] += bytes;
+      return true;
+    }
+  return false;
+}
+
+// A block of `bytes` for part `part` of a gof: from the pool's home `part` (then from the other home), else an
+// allocation of its own (from the context's cache of such blocks when one fits).
+int acquire_block(vpcc_ctx* ctx, int part, size_t bytes, vpcc_ctx::Block* out) {
+  bytes = (bytes + (size_t(2) << 20) - 1) & ~((size_t(2) << 20) - 1);
+  std::lock_guard<std::mutex> lock(ctx->pool_mutex);
+  if (ctx->pool.reserved()) {
+    const int want = ctx->pool.info.kinds > 1 ? part % 2 : 0;
+    for (int t = 0; t < 2; ++t)
+      if (pool_take(ctx->pool, (want + t) % 2, bytes, out)) {
+        if (t) ctx->pool.info.other_home++;
+        return VPCC_OK;
+      }
+    ctx->pool.info.fallbacks++;
+  }
+  auto& cache = ctx->block_cache;
+  for (size_t k = 0; k < cache.size(); ++k)
+    if (cache[k].bytes >= bytes && cache[k].bytes <= bytes + bytes / 4) {
+      *out = cache[k];
+      cache.erase(cache.begin() + k);
+      return VPCC_OK;
+    }
+  void* p = nullptr;
+  if (hipMalloc(&p, bytes) != hipSuccess) {
+    (void)hipGetLastError();
+    for (auto& b : cache) (void)hipFree(b.ptr);          // make room and try once more
+    cache.clear();
+    if (hipMalloc(&p, bytes) != hipSuccess) { ctx->last_error = "hipMalloc of a gof block failed"; return VPCC_ERR_DEVICE; }
+  }
+  *out = vpcc_ctx::Block{p, bytes, false, 0};
+  return VPCC_OK;
+}
+
+void release_block(vpcc_ctx* ctx, vpcc_ctx::Block& B) {      // all work on the block is complete
+  if (!B.ptr) return;
+  std::lock_guard<std::mutex> lock(ctx->pool_mutex);
+  if (B.pooled) {
+    ctx->pool.info.in_use[ctx->pool.runs[B.run].kind] -= B.bytes;
+    pool_insert_free(ctx->pool, B.run, (char*)B.ptr, B.bytes);
+  } else if (ctx->block_cache.size() < kBlockCacheEntries) {
+    ctx->block_cache.push_back(B);
+  } else {
+    (void)hipFree(B.ptr);
+  }
+  B = vpcc_ctx::Block{};
+}
+
+}  // namespace
+
+extern "C" int vpcc_ctx_reserve(vpcc_ctx* ctx, uint64_t bytes, vpcc_pool_info* out) {
+  // May run on a thread of its own beside the context's worker (the streaming Decoder does that): it works on a
+  // stream and a Pool of its own, touches nothing of the context but its device id until the finished pool is handed
+  // over under the pool mutex, and reports through its status only (not vpcc_last_error).
+  if (!ctx) return VPCC_ERR_INVALID_ARG;
+  {
+    std::lock_guard<std::mutex> lock(ctx->pool_mutex);
+    if (ctx->pool.reserved() || ctx->pool_pending) return VPCC_ERR_STATE;
+    ctx->pool_pending = true;
+  }
+  struct Pending { vpcc_ctx* c; ~Pending() { std::lock_guard<std::mutex> lock(c->pool_mutex); c->pool_pending = false; } } pending{ctx};
+  constexpr size_t G = vpcc_ctx::Pool::kGranule;
+  const size_t n = (size_t)((bytes + G - 1) / G);
+  if (n < 2) return VPCC_ERR_INVALID_ARG;
+  if (hipSetDevice(ctx->device) != hipSuccess) return VPCC_ERR_DEVICE;
+  const auto t0 = std::chrono::steady_clock::now();
+  const bool trace = getenv("VPCC_RUNTIME_TRACE") != nullptr;
+  vpcc_ctx::Pool P;
+  void* base = nullptr;
+  if (hipMalloc(&base, n * G) != hipSuccess) {
+    (void)hipGetLastError();
+    return VPCC_ERR_DEVICE;
+  }
+  hipStream_t s = nullptr;
+  if (hipStreamCreateWithFlags(&s, hipStreamNonBlocking) != hipSuccess) { (void)hipFree(base); return VPCC_ERR_DEVICE; }
+  // Classification: the reconstruction kernel's OUTPUT pattern (thousands of waves, each writing its own run of
+  // positions into one array and of colours into another) runs at 3.7 TB/s when both arrays lie in one kind of region
+  // and at 5.3 TB/s when they lie in two (profiles/r03/pair_offset.txt, profiles/r04/pool.txt).  Positions in the
+  // pool's granule 0, colours in granule j, for every j: the slow pairings are granule 0's kind.
+  hipEvent_t a = nullptr, b = nullptr;
+  if (hipEventCreate(&a) != hipSuccess || hipEventCreate(&b) != hipSuccess) { (void)hipFree(base); (void)hipStreamDestroy(s); return VPCC_ERR_DEVICE; }
+  constexpr uint32_t kItems = 333000;                     // 607 MB of positions + 304 MB of colours: one 128-frame launch
+  unsigned char* const ref = (unsigned char*)base;
+  auto probe = [&](unsigned char* other) -> float {        // GB/s
+    launch_probe_outputs(ref, other, kItems, s);
+    (void)hipEventRecord(a, s);
+    for (int r = 0; r < 2; ++r) launch_probe_outputs(ref, other, kItems, s);
+    (void)hipEventRecord(b, s);
+    if (hipEventSynchronize(b) != hipSuccess) return 0.f;
+    float ms = 0.f;
+    (void)hipEventElapsedTime(&ms, a, b);
+    return ms > 0.f ? (float)((double)kItems * 2736.0 * 2.0 / (ms * 1e-3) / 1e9) : 0.f;
+  };
+  std::vector<float> rate(n, 0.f);
+  for (size_t j = 1; j < n; ++j) rate[j] = probe(ref + j * G);
+  std::vector<float> sorted(rate.begin() + 1, rate.end());
+  std::sort(sorted.begin(), sorted.end());
+  const float lo = sorted.front(), hi = sorted.back(), med = sorted[sorted.size() / 2];
+  // two levels in this slab: split between them; one level: it is granule 0's own (a pairing with another kind is faster)
+  const float threshold = hi > 1.15f * lo ? 0.5f * (lo + hi) : 1.15f * med;
+  auto classify = [&](std::vector<uint8_t>& kind, const std::vector<float>& r, size_t first) {
+    for (size_t j = first; j < kind.size(); ++j) kind[j] = r[j] > threshold ? 1 : 0;
+    for (size_t j = std::max<size_t>(first, 1); j + 1 < kind.size(); ++j)      // a lone granule between two of the other kind: a mis-measurement
+      if (kind[j - 1] == kind[j + 1] && kind[j] != kind[j - 1]) kind[j] = kind[j - 1];
+  };
+  auto add_slab = [&](void* slab, const std::vector<uint8_t>& kind) {
+    P.slabs.push_back(slab);
+    for (size_t j = 0; j < kind.size();) {                    // runs of one kind -> free extents
+      size_t e = j;
+      while (e < kind.size() && kind[e] == kind[j]) ++e;
+      P.runs.push_back(vpcc_ctx::Pool::Run{(char*)slab + j * G, (e - j) * G, (int)kind[j]});
+      pool_insert_free(P, (uint32_t)P.runs.size() - 1, (char*)slab + j * G, (e - j) * G);
+      P.info.bytes_of_kind[kind[j]] += (e - j) * G;
+      j = e;
+    }
+    P.info.bytes += kind.size() * G;
+    P.info.granules += (uint32_t)kind.size();
+  };
+  auto kinds_string = [](const std::vector<uint8_t>& kind) { std::string t; for (uint8_t k : kind) t += k ? 'b' : 'a'; return t; };
+  P.info = vpcc_pool_info{};
+  std::vector<uint8_t> kind0(n, 0);
+  classify(kind0, rate, 1);
+  add_slab(base, kind0);
+  P.info.probe_gbps_same = lo;
+  P.info.probe_gbps_other = hi;
+  if (trace) fprintf(stderr, "[vpcc] pool: %zu GiB classified: %s (probe %.0f .. %.0f GB/s)\n", n, kinds_string(kind0).c_str(), lo, hi);
+  // A slab that lies in ONE kind (on some GPUs the first 60 GB of VRAM are alike), or all but a quarter of it: look further
+  // away for more of the other — a spacer of 16 GiB nobody uses, then a candidate of half the pool's size, up to four times, while
+  // at least a third of the device's memory stays free.  Spacers and rejected candidates are freed at the end (memory
+  // given back is wiped by the driver before it is handed out again, and whoever allocates next waits for that).
+  const int small = P.info.bytes_of_kind[1] < P.info.bytes_of_kind[0] ? 1 : 0;       // the kind the slab has less of
+  if (P.info.bytes_of_kind[small] * 4 < n * G) {
+    std::vector<void*> spare;
+    const size_t m = std::max<size_t>(2, n / 2);
+    for (int attempt = 0; attempt < 4; ++attempt) {
+      size_t free_b = 0, total_b = 0;
+      if (hipMemGetInfo(&free_b, &total_b) != hipSuccess || free_b < total_b / 3 + (16 + m) * G) break;
+      void* spacer = nullptr;
+      void* cand = nullptr;
+      if (hipMalloc(&spacer, 16 * G) != hipSuccess) { (void)hipGetLastError(); break; }
+      spare.push_back(spacer);
+      if (hipMalloc(&cand, m * G) != hipSuccess) { (void)hipGetLastError(); break; }
+      std::vector<float> r(m, 0.f);
+      for (size_t j = 0; j < m; ++j) r[j] = probe((unsigned char*)cand + j * G);
+      std::vector<uint8_t> kind(m, 0);
+      classify(kind, r, 0);
+      size_t other = 0;
+      for (uint8_t k : kind) other += k == small ? 1 : 0;
+      if (trace) fprintf(stderr, "[vpcc] pool: candidate %d behind a 16-GiB spacer: %s\n", attempt, kinds_string(kind).c_str());
+      if (other * 2 >= m) {
+        add_slab(cand, kind);
+        for (float x : r) P.info.probe_gbps_other = std::max(P.info.probe_gbps_other, x);
+        break;
+      }
+      spare.push_back(cand);
+    }
+    for (void* q : spare) (void)hipFree(q);
+  }
+  (void)hipEventDestroy(a);
+  (void)hipEventDestroy(b);
+  (void)hipStreamDestroy(s);
+  P.info.kinds = P.info.bytes_of_kind[1] ? 2u : 1u;
+  P.info.ms_spent = (float)std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+  if (trace)
+    fprintf(stderr, "[vpcc] pool reserved in %.1f ms: %llu GiB of granule 0's kind, %llu GiB of the other\n", P.info.ms_spent,
+            (unsigned long long)(P.info.bytes_of_kind[0] >> 30), (unsigned long long)(P.info.bytes_of_kind[1] >> 30));
+  if (out) *out = P.info;
+  {
+    std::lock_guard<std::mutex> lock(ctx->pool_mutex);
+    ctx->pool = std::move(P);
+  }
+  return VPCC_OK;
+}
+
+extern "C" int vpcc_ctx_pool_info(vpcc_ctx* ctx, vpcc_pool_info* out) {
+  if (!ctx || !out) return VPCC_ERR_INVALID_ARG;
+  std::lock_guard<std::mutex> lock(ctx->pool_mutex);
+  *out = ctx->pool.info;
+  return VPCC_OK;
+}
+
 // --------------------------------------------------------------------- gof
 extern "C" void vpcc_gof_destroy(vpcc_gof* gof) {
   if (!gof) return;
@@ -299,22 +512,7 @@ extern "C" void vpcc_gof_destroy(vpcc_gof* gof) {
     if (cache.size() < 4) cache.emplace_back(gof->arena, gof->arena_bytes);
     else (void)hipFree(gof->arena);
   }
-  for (vpcc_ctx::Block& t : gof->temp)
-    if (t.ptr) {
-      if (gof->ctx->temp_cache.size() < 4) gof->ctx->temp_cache.push_back(t);
-      else (void)hipFree(t.ptr);
-    }
-  if (gof->d_raster) (void)hipFree(gof->d_raster);
-  if (gof->mem.any()) {
-    auto& cache = gof->ctx->placement_cache;                     // at most four sets: the slowest (unmeasured first,
-    cache.push_back(gof->mem);                                    // oldest among equals) goes
-    if (cache.size() > 4) {
-      size_t worst = 0;
-      for (size_t k = 1; k < cache.size(); ++k) if (cache[k].score < cache[worst].score) worst = k;
-      cache[worst].release();
-      cache.erase(cache.begin() + worst);
-    }
-  }
+  for (vpcc_ctx::Block& B : gof->block) release_block(gof->ctx, B);
   if (gof->h_counts) (void)hipHostFree(gof->h_counts);
   delete gof;
 }
@@ -330,209 +528,6 @@ int copy_plane(vpcc_ctx* ctx, void* dst, const void* src, size_t elem, uint32_t 
   } else {
     HIP_TRY(ctx, hipMemcpy2DAsync(dst, (size_t)width * elem, src, (size_t)stride * elem, (size_t)width * elem, height, dir, s));
   }
-  return VPCC_OK;
-}
-
-// Placement of the big blocks (VPCC_GOF_TUNE_PLACEMENT).  VRAM consists of kinds of regions, tens of GB each, and the
-// memory system is fastest when a launch's traffic is spread evenly over them: the same 128-frame launch takes 0.45 ms
-// or 0.52 ms depending on where the gof's planes and output arrays lie (DESIGN.md 4.1 "Placement",
-// profiles/r03/pair_offset.txt, slab_*.txt).  Nothing tells the kinds apart but a measurement, and no simpler access
-// pattern predicts the kernel's time, so the kernel itself is the probe: the first whole-gof launch of a gof whose
-// blocks are new times the launch with each block in turn — the outputs and the planes of part 0, of part 1 — on
-// candidate allocations (alive together, so each lies somewhere else; planes by device-to-device copy, descriptors
-// rebased) and keeps the fastest; a second sweep if the first moved anything and the budget lasts.
-// VPCC_PLACEMENT_CANDIDATES=1 takes the allocations as they come.
-void rebase_frames(vpcc_gof* g, const void* from, size_t bytes, void* to) {
-  const char* lo = (const char*)from;
-  const ptrdiff_t d = (char*)to - lo;
-  auto mv = [&](auto& p) {
-    const char* c = (const char*)p;
-    if (c && c >= lo && c < lo + bytes) p = (std::remove_reference_t<decltype(p)>)(c + d);
-  };
-  for (DevFrame& D : g->h_frames) {
-    mv(D.occ);
-    for (int m = 0; m < 2; ++m) { mv(D.geo[m]); mv(D.attr_y[m]); mv(D.attr_u[m]); mv(D.attr_v[m]); }
-    mv(D.out_xyz); mv(D.out_rgb); mv(D.out_patch);
-  }
-}
-
-int place_blocks(vpcc_gof* g, uint32_t max_groups, hipStream_t s) {
-  vpcc_ctx* ctx = g->ctx;
-  g->placed = true;
-  static const int wanted = [] {
-    const char* e = getenv("VPCC_PLACEMENT_CANDIDATES");
-    const int v = e ? atoi(e) : 16;
-    return v < 1 ? 1 : v > 32 ? 32 : v;
-  }();
-  static const float flat_ratio = [] {                // (diagnostic: 9 makes every round look flat)
-    const char* e = getenv("VPCC_PLACEMENT_FLAT");
-    return e ? (float)atof(e) : 1.04f;
-  }();
-  static const double budget_ms = [] {                 // no new candidate once the measurement has taken this long
-    const char* e = getenv("VPCC_PLACEMENT_BUDGET_MS");
-    return e ? atof(e) : 800.0;
-  }();
-  vpcc_ctx::Placement& M = g->mem;
-  if (M.score > 0.f) { M.info.tuned = 2; return VPCC_OK; }                     // a set measured by an earlier gof
-  size_t total_bytes = 0;
-  for (const vpcc_ctx::Block& B : M.block) total_bytes += B.bytes;
-  if (wanted <= 1 || total_bytes < (size_t(64) << 20)) return VPCC_OK;          // too small to matter
-  const bool trace = getenv("VPCC_RUNTIME_TRACE") != nullptr;
-  const uint32_t nf = g->n_frames;
-  hipEvent_t a, b;
-  HIP_TRY(ctx, hipEventCreate(&a));
-  HIP_TRY(ctx, hipEventCreate(&b));
-  auto launch = [&] {
-    g->generation = (g->generation % 0x3FFFFFFFu) + 1u;
-    launch_tiles(g->d_frames, 0, nf, max_groups, g->generation, g->tile_map, ctx->resident_tile_wgs_per_xcd, s);
-  };
-  // ms per launch with the descriptors as they stand in h_frames (first launch untimed: first touch of a new block)
-  auto measure = [&](float* ms) -> int {
-    HIP_TRY(ctx, hipMemcpyAsync(g->d_frames, g->h_frames.data(), sizeof(DevFrame) * nf, hipMemcpyHostToDevice, s));
-    launch();
-    *ms = 1e30f;
-    for (int rep = 0; rep < 2; ++rep) {
-      (void)hipEventRecord(a, s);
-      launch();
-      (void)hipEventRecord(b, s);
-      HIP_TRY(ctx, hipEventSynchronize(b));
-      float t = 0.f;
-      if (hipEventElapsedTime(&t, a, b) == hipSuccess && t > 0.f) *ms = std::min(*ms, t);
-    }
-    return VPCC_OK;
-  };
-  const auto t0 = std::chrono::steady_clock::now();
-  auto spent_ms = [&] { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count(); };
-  // The budget counts the measurement, not the time the driver makes an allocation wait while it wipes memory somebody
-  // freed a moment ago (a hipMalloc of 0.5 GB then takes 100 ms and more instead of one) — up to a hard limit.
-  double stalled_ms = 0;
-  auto over_budget = [&] { const double t = spent_ms(); return t - stalled_ms > budget_ms || t > 5.0 * budget_ms; };
-  // Candidate allocations are kept in a pool per block size for the whole measurement and given back at its end
-  // (parts of a kind are equally big and share their candidates): VRAM that is freed gets wiped by the driver before
-  // it is handed out again, at about 40 GB/s, and whoever allocates next waits for it — a first version that took fresh
-  // candidates for every round freed 140 GB and made a later 0.5-GB hipMalloc take 3.6 s.
-  struct Pool { size_t bytes; std::vector<void*> blocks; int skips = 0; };
-  std::vector<Pool> pools;
-  std::vector<void*> spacers;
-  size_t held = 0;
-  size_t free_b = 0, total_b = 0;
-  (void)hipMemGetInfo(&free_b, &total_b);
-  auto grow = [&](Pool& P, size_t n) {                          // up to n more blocks, while budget and memory last
-    for (size_t k = 0; k < n; ++k) {
-      if ((!P.blocks.empty() && over_budget()) || held + P.bytes > free_b / 2) return;
-      void* p = nullptr;
-      const double t_a = spent_ms();
-      if (hipMalloc(&p, P.bytes) != hipSuccess) { (void)hipGetLastError(); return; }
-      const double took = spent_ms() - t_a;
-      if (took > 5.0) stalled_ms += took;
-      if (trace && took > 10.0) fprintf(stderr, "[vpcc] placement: hipMalloc of %zu MB took %.0f ms (%zu MB held)\n", P.bytes >> 20, took, held >> 20);
-      P.blocks.push_back(p);
-      held += P.bytes;
-    }
-  };
-  // One round over a block: its current allocation against the pool's (the pool is filled up to wanted - 1 first);
-  // the loser goes (back) into the pool.
-  auto round = [&](void** block, size_t bytes, bool copy, bool skip_ahead, const char* what, float* best_ms, bool* moved) -> int {
-    size_t pi = 0;
-    while (pi < pools.size() && pools[pi].bytes != bytes) ++pi;
-    if (pi == pools.size()) pools.push_back(Pool{bytes, {}});
-    Pool& P = pools[pi];
-    if (P.blocks.size() + 1 < (size_t)wanted) grow(P, (size_t)wanted - 1 - P.blocks.size());
-    std::vector<float> ms;
-    size_t best = 0, worst = 0;
-    void* cur = *block;                                            // where the descriptors point
-    // on an error the descriptors go back to the block's own allocation (the candidates are freed at the end)
-    auto bail = [&](int status) {
-      rebase_frames(g, cur, bytes, *block);
-      (void)hipMemcpyAsync(g->d_frames, g->h_frames.data(), sizeof(DevFrame) * nf, hipMemcpyHostToDevice, s);
-      (void)hipStreamSynchronize(s);
-      return status;
-    };
-    auto hip_failed = [&](hipError_t e, const char* what_failed) {
-      return bail(fail(ctx, VPCC_ERR_DEVICE, std::string(what_failed) + ": " + hipGetErrorString(e)));
-    };
-    for (size_t c = 0;; ++c) {
-      if (c == P.blocks.size() + 1) {
-        // Every candidate within 4 % of the others: a stretch of memory that is all alike (on some GPUs of the pool the
-        // first 60 GB are, and slow).  Look further away, three times at most per block size: 16, 32, 48 GB of
-        // allocations nobody uses (of the block's own size: hipMalloc hands those out in about a millisecond each, while
-        // 2-GiB and larger round sizes took 100 ms and more; kept until the measurement ends, so that the pools of the
-        // blocks that follow start beyond them), then eight more candidates.
-        const bool flat = ms[worst] < flat_ratio * ms[best];
-        if (!skip_ahead || !flat || P.skips == 3 || over_budget()) break;
-        const size_t distance = size_t(16 * (P.skips + 1)) << 30;                  // 16, 32, 48 GB
-        for (size_t skipped = 0; skipped < distance && held + bytes <= free_b / 2 && !over_budget(); skipped += bytes) {
-          void* sp = nullptr;
-          if (hipMalloc(&sp, bytes) != hipSuccess) { (void)hipGetLastError(); break; }
-          spacers.push_back(sp);
-          held += bytes;
-        }
-        ++P.skips;
-        const size_t before = P.blocks.size();
-        grow(P, 8);
-        if (P.blocks.size() == before) break;
-      }
-      void* to = c ? P.blocks[c - 1] : *block;
-      if (c && copy) {
-        const hipError_t e = hipMemcpyAsync(to, *block, bytes, hipMemcpyDeviceToDevice, s);
-        if (e != hipSuccess) return hip_failed(e, "placement: copy of the planes");
-      }
-      rebase_frames(g, cur, bytes, to);
-      cur = to;
-      ms.push_back(0.f);
-      const int st = measure(&ms[c]);
-      if (st) return bail(st);
-      if (ms[c] < ms[best]) best = c;
-      if (ms[c] > ms[worst]) worst = c;
-    }
-    void* keep = best ? P.blocks[best - 1] : *block;
-    rebase_frames(g, cur, bytes, keep);
-    cur = keep;
-    hipError_t e = hipMemcpyAsync(g->d_frames, g->h_frames.data(), sizeof(DevFrame) * nf, hipMemcpyHostToDevice, s);
-    if (e == hipSuccess) e = hipStreamSynchronize(s);
-    if (e != hipSuccess) return hip_failed(e, "placement: descriptor upload");
-    if (best) { P.blocks[best - 1] = *block; *block = keep; }      // the old place becomes a candidate
-    *best_ms = ms[best];
-    if (M.info.candidates == 0) M.info.ms_as_allocated = ms[0];
-    M.info.candidates += (uint32_t)ms.size();
-    *moved = best != 0;
-    if (trace) {
-      std::string all;
-      for (float t : ms) { char buf[32]; snprintf(buf, sizeof buf, " %.3f", t); all += buf; }
-      fprintf(stderr, "[vpcc] placement, %s (%zu MB; %u frames in the launch): ms per launch by candidate%s -> kept %zu (%.0f ms so far)\n",
-              what, bytes >> 20, nf, all.c_str(), best, spent_ms());
-    }
-    return VPCC_OK;
-  };
-  // Coordinate descent over the blocks: the output and the planes of part 0, of part 1, ...; then once more over
-  // all of them (without looking further away) if the first sweep moved anything and the budget lasts.
-  static const char* const names[2] = {"planes", "output"};
-  float ms = 0.f;
-  int st = VPCC_OK;
-  bool moved_any = false;
-  for (int sweep = 0; sweep < 2 && !st; ++sweep) {
-    if (sweep && (!moved_any || over_budget())) break;
-    for (int part = 0; part < vpcc_ctx::kParts && !st; ++part)
-      for (int kind = 1; kind >= 0 && !st; --kind) {
-        vpcc_ctx::Block& B = M.block[2 * part + kind];
-        if (!B.ptr || B.bytes < (size_t(16) << 20) || (sweep && over_budget())) continue;
-        bool moved = false;
-        char what[32];
-        snprintf(what, sizeof what, "%s %d", names[kind], part);
-        st = round(&B.ptr, B.bytes, kind == 0, sweep == 0 && part == 0, what, &ms, &moved);   // (later rounds are flat when all is well)
-        moved_any = moved_any || moved;
-      }
-  }
-  for (Pool& P : pools) for (void* q : P.blocks) (void)hipFree(q);
-  for (void* q : spacers) (void)hipFree(q);
-  (void)hipEventDestroy(a);
-  (void)hipEventDestroy(b);
-  if (st) return st;
-  M.score = 1.f / ms;
-  M.info.tuned = 1;
-  M.info.ms_kept = ms;
-  M.info.ms_spent = (float)spent_ms();
-  if (trace) fprintf(stderr, "[vpcc] placement took %.1f ms\n", M.info.ms_spent);
   return VPCC_OK;
 }
 
@@ -610,24 +605,13 @@ int gof_create_impl(vpcc_ctx* ctx, const vpcc_frame_desc* frames, uint32_t n_fra
   }
   g->b2p_words = (L.total - b2p_begin) / sizeof(uint32_t);
   L.total = align_up(L.total, 256);
-  // The big blocks' own layouts: [2 * part] planes, [2 * part + 1] outputs.  A gof that tunes its placement splits both
-  // in kParts parts by frame — eight frames (one per XCD) to part 0, the next eight to part 1, and so on — so that
-  // the parts can lie in different places: the memory system is fastest when a launch's traffic is spread evenly over
-  // the kinds of regions VRAM consists of (DESIGN.md §4.1 "Placement").
+  // The big blocks' own layouts: [2 * part] planes, [2 * part + 1] outputs, in kParts parts by frame — eight frames (one
+  // per XCD label) to part 0, the next eight to part 1, and so on: every launch range moves the same bytes in both parts,
+  // and with a reserved pool (vpcc_ctx_reserve) the parts lie in the two kinds of VRAM regions (DESIGN.md 4.1 "Two homes").
   ArenaLayout LB[2 * vpcc_ctx::kParts];
-  const bool split = (gof_flags & VPCC_GOF_TUNE_PLACEMENT) != 0;
-  auto part_of = [&](uint32_t i) { return split ? (int)((i >> 3) % vpcc_ctx::kParts) : 0; };
-  // Diagnostic layout (tools/exp_slab.py, exp_slab2.py): VPCC_DIAG_SLAB="geo,attr,xyz,rgb" puts the four kinds of
-  // arrays at these offsets (GB) of ONE allocation of VPCC_DIAG_SLAB_GB GB.
-  ArenaLayout LX[4];
-  double slab_off[4] = {0, 0, 0, 0};
-  const char* slab_env = getenv("VPCC_DIAG_SLAB");
-  const bool slab = !split && slab_env && sscanf(slab_env, "%lf,%lf,%lf,%lf", &slab_off[0], &slab_off[1], &slab_off[2], &slab_off[3]) == 4;
-  auto slab_at = [&](int k) { return (size_t)(slab_off[k] * (double)(size_t(1) << 30)) & ~size_t(4095); };
-  // kind 0 planes / 1 outputs; sub 0 geometry + occupancy or positions + partition / 1 attributes or colours
-  auto takek = [&](uint32_t i, int kind, int sub, size_t bytes) {
-    return slab ? LX[2 * kind + sub].take(bytes) : LB[2 * part_of(i) + kind].take(bytes);
-  };
+  auto part_of = [&](uint32_t i) { return (int)((i >> 3) % vpcc_ctx::kParts); };
+  // kind 0 planes / 1 outputs
+  auto takek = [&](uint32_t i, int kind, int, size_t bytes) { return LB[2 * part_of(i) + kind].take(bytes); };
   for (uint32_t i = 0; i < n_frames; ++i) {
     const vpcc_frame_desc& F = frames[i];
     const FramePlan& P = g->plans[i];
@@ -664,36 +648,13 @@ int gof_create_impl(vpcc_ctx* ctx, const vpcc_frame_desc* frames, uint32_t n_fra
   }
   const auto t_alloc = std::chrono::steady_clock::now();
   if (!g->arena) HIP_TRY(ctx, hipMalloc(&g->arena, g->arena_bytes));
-  {
-    size_t need[2 * vpcc_ctx::kParts];
-    for (int k = 0; k < 2 * vpcc_ctx::kParts; ++k) need[k] = LB[k].total ? LB[k].total + 256 : 0;
-    if (slab) {                                                   // everything in "outputs, part 0"
-      for (int k = 0; k < 4; ++k) need[1] = std::max(need[1], slab_at(k) + LX[k].total + 4096);
-      if (getenv("VPCC_DIAG_SLAB_GB")) need[1] = std::max(need[1], (size_t)atoi(getenv("VPCC_DIAG_SLAB_GB")) << 30);
+  for (int j = 0; j < 2 * vpcc_ctx::kParts; ++j)
+    if (LB[j].total) {
+      const int st = acquire_block(ctx, j / 2, LB[j].total + 256, &g->block[j]);
+      if (st) return st;
     }
-    auto fits = [](size_t have, size_t want) { return want ? have >= want && have <= want + want / 4 : have == 0; };
-    auto& cache = ctx->placement_cache;
-    size_t pick = cache.size();
-    for (size_t k = 0; k < cache.size(); ++k) {                   // a kept set that fits, the fastest first
-      bool ok = true;
-      for (int j = 0; j < 2 * vpcc_ctx::kParts; ++j) ok = ok && fits(cache[k].block[j].bytes, need[j]);
-      if (ok && (pick == cache.size() || cache[k].score > cache[pick].score)) pick = k;
-    }
-    if (pick < cache.size()) {
-      g->mem = cache[pick];
-      cache.erase(cache.begin() + pick);
-    } else {
-      for (int j = 0; j < 2 * vpcc_ctx::kParts; ++j)
-        if (need[j]) {
-          HIP_TRY(ctx, hipMalloc(&g->mem.block[j].ptr, need[j]));
-          g->mem.block[j].bytes = need[j];
-        }
-    }
-  }
   char* base = (char*)g->arena;
-  auto kb = [&](uint32_t i, int kind, int sub) {
-    return slab ? (char*)g->mem.block[1].ptr + slab_at(2 * kind + sub) : (char*)g->mem.block[2 * part_of(i) + kind].ptr;
-  };
+  auto kb = [&](uint32_t i, int kind, int) { return (char*)g->block[2 * part_of(i) + kind].ptr; };
   g->d_frames = (DevFrame*)(base + off_frames);
   g->d_counts = (uint32_t*)(base + off_counts);
   g->d_b2p = (uint32_t*)(base + b2p_begin);
@@ -704,38 +665,6 @@ int gof_create_impl(vpcc_ctx* ctx, const vpcc_frame_desc* frames, uint32_t n_fra
   HIP_TRY(ctx, hipEventCreateWithFlags(&g->upload_done, hipEventDisableTiming));
   HIP_TRY(ctx, hipEventCreateWithFlags(&g->results_ready, hipEventDisableTiming));
 
-  // Tiled planes.  The tile kernel reads a plane block by block (16 rows of 32 bytes, each a quarter of a 128-byte line
-  // that the neighbouring blocks' waves need as well, moments later or long after): in the raster layout a third of
-  // its reads are lines fetched more than once.  Planes the library ingests itself (VPCC_MEM_HOST) are therefore
-  // re-arranged once, right behind their upload, so that a block's samples are contiguous (k_tile_planes): the
-  // kernel then reads exactly the blocks it needs, 512 contiguous bytes per wave and plane.  Needs the raster copy
-  // as staging (kept with the gof, reused by the context).  VPCC_NO_TILED_PLANES=1 keeps the raster layout.
-  bool tiled = own_planes && all_simple && !(gof_flags & VPCC_GOF_FORCE_GENERAL) && !slab && !getenv("VPCC_NO_TILED_PLANES");
-  for (uint32_t i = 0; i < n_frames && tiled; ++i) {
-    const vpcc_frame_desc& F = frames[i];
-    tiled = F.width % 16u == 0 && F.height % 16u == 0;
-    for (uint32_t m = 0; m < F.map_count && tiled; ++m) {
-      tiled = F.geometry[m].width == F.width && F.geometry[m].height == F.height;
-      if (tiled && F.attribute_count)
-        tiled = F.attribute[m].width == F.width && F.attribute[m].height == F.height &&
-                chroma_elems(F.attribute[m]) == (size_t)(F.width / 2u) * (F.height / 2u) && F.attribute[m].cstride == F.width / 2u;
-    }
-  }
-  if (tiled)
-    for (int part = 0; part < vpcc_ctx::kParts; ++part) {
-      const size_t need = g->mem.block[2 * part].bytes;
-      if (!need) continue;
-      auto& cache = ctx->temp_cache;
-      for (size_t k = 0; k < cache.size(); ++k)
-        if (cache[k].bytes >= need && cache[k].bytes <= need + need / 4) { g->temp[part] = cache[k]; cache.erase(cache.begin() + k); break; }
-      if (!g->temp[part].ptr) {
-        HIP_TRY(ctx, hipMalloc(&g->temp[part].ptr, need));
-        g->temp[part].bytes = need;
-      }
-    }
-  std::vector<DevFrame>& h_raster = g->h_raster;
-  h_raster.resize(tiled ? n_frames : 0);
-  auto up = [&](uint32_t i, int sub) { return tiled ? (char*)g->temp[part_of(i)].ptr : kb(i, 0, sub); };   // where the planes are uploaded to
   const auto t_fill = std::chrono::steady_clock::now();
   // 3. fill descriptors and upload (plane ingest on the copy stream)
   hipStream_t s = ctx->copy_stream;
@@ -785,7 +714,7 @@ int gof_create_impl(vpcc_ctx* ctx, const vpcc_frame_desc* frames, uint32_t n_fra
       for (uint32_t m = 0; m < F.map_count; ++m) {
         const vpcc_image_u16& G = F.geometry[m];
         D.geo[m] = (const uint16_t*)(kb(i, 0, 0) + o.geo[m]); D.geo_stride[m] = G.width;
-        st = copy_plane(ctx, up(i, 0) + o.geo[m], G.y, 2, G.width, G.height, G.stride, s, dir);
+        st = copy_plane(ctx, kb(i, 0, 0) + o.geo[m], G.y, 2, G.width, G.height, G.stride, s, dir);
         if (st) return st;
         if (F.attribute_count) {
           const vpcc_image_u16& A = F.attribute[m];
@@ -793,13 +722,13 @@ int gof_create_impl(vpcc_ctx* ctx, const vpcc_frame_desc* frames, uint32_t n_fra
           D.attr_u[m] = (const uint16_t*)(kb(i, 0, 1) + o.au[m]);
           D.attr_v[m] = (const uint16_t*)(kb(i, 0, 1) + o.av[m]);
           D.attr_stride[m] = A.width; D.attr_cstride[m] = A.cstride;
-          st = copy_plane(ctx, up(i, 1) + o.ay[m], A.y, 2, A.width, A.height, A.stride, s, dir);
+          st = copy_plane(ctx, kb(i, 0, 1) + o.ay[m], A.y, 2, A.width, A.height, A.stride, s, dir);
           if (st) return st;
           // chroma keeps its source stride: the reference indexes it as a flat array
           // (v/2)*(width/2)+(u/2), src/decoder.rs:977, which for odd widths runs across rows
           const size_t ce = chroma_elems(A);
-          HIP_TRY(ctx, hipMemcpyAsync(up(i, 1) + o.au[m], A.u, ce * 2, dir, s));
-          HIP_TRY(ctx, hipMemcpyAsync(up(i, 1) + o.av[m], A.v, ce * 2, dir, s));
+          HIP_TRY(ctx, hipMemcpyAsync(kb(i, 0, 1) + o.au[m], A.u, ce * 2, dir, s));
+          HIP_TRY(ctx, hipMemcpyAsync(kb(i, 0, 1) + o.av[m], A.v, ce * 2, dir, s));
         }
       }
     }
@@ -815,19 +744,6 @@ int gof_create_impl(vpcc_ctx* ctx, const vpcc_frame_desc* frames, uint32_t n_fra
         D.attr_y[m] = D.attr_u[m] = D.attr_v[m] = D.geo[m];
         D.attr_stride[m] = D.attr_cstride[m] = D.geo_stride[m];
       }
-    if (tiled) {
-      D.tiled = 1u;
-      DevFrame& Rd = h_raster[i];                             // the same frame as k_tile_planes reads it: planes in the staging block
-      Rd = D;
-      Rd.tiled = 0u;
-      const ptrdiff_t d = (char*)g->temp[part_of(i)].ptr - kb(i, 0, 0);
-      for (uint32_t m = 0; m < 2; ++m) {
-        Rd.geo[m] = (const uint16_t*)((const char*)D.geo[m] + d);
-        Rd.attr_y[m] = (const uint16_t*)((const char*)D.attr_y[m] + d);
-        Rd.attr_u[m] = (const uint16_t*)((const char*)D.attr_u[m] + d);
-        Rd.attr_v[m] = (const uint16_t*)((const char*)D.attr_v[m] + d);
-      }
-    }
     if (!P.patches.empty())
       HIP_TRY(ctx, hipMemcpyAsync(base + o.patches, P.patches.data(), sizeof(DevPatch) * P.patches.size(),
                                   hipMemcpyHostToDevice, s));
@@ -843,13 +759,6 @@ int gof_create_impl(vpcc_ctx* ctx, const vpcc_frame_desc* frames, uint32_t n_fra
   for (uint32_t i = 0; i < n_frames && tiles_ok; ++i) tiles_ok = tile_planes_aligned(g->h_frames[i]);
   g->general = !tiles_ok;
   HIP_TRY(ctx, hipMemcpyAsync(g->d_frames, g->h_frames.data(), sizeof(DevFrame) * n_frames, hipMemcpyHostToDevice, s));
-  if (tiled) {
-    uint32_t max_blocks = 0;
-    for (uint32_t i = 0; i < n_frames; ++i) max_blocks = std::max(max_blocks, g->plans[i].bw * g->plans[i].bh);
-    HIP_TRY(ctx, hipMalloc((void**)&g->d_raster, sizeof(DevFrame) * n_frames));
-    HIP_TRY(ctx, hipMemcpyAsync(g->d_raster, h_raster.data(), sizeof(DevFrame) * n_frames, hipMemcpyHostToDevice, s));
-    launch_tile_planes(g->d_raster, g->d_frames, 0, n_frames, max_blocks, s);
-  }
   HIP_TRY(ctx, hipMemsetAsync(g->d_counts, 0, sizeof(uint32_t) * n_frames, s));
   HIP_TRY(ctx, hipMemsetAsync(base + ctrl_begin, 0, g->ctrl_bytes, s));
   HIP_TRY(ctx, hipEventRecord(g->upload_done, s));
@@ -858,6 +767,10 @@ int gof_create_impl(vpcc_ctx* ctx, const vpcc_frame_desc* frames, uint32_t n_fra
     fprintf(stderr, "[vpcc] gof of %u frames: allocations %.1f ms, descriptors + %s of the planes %.1f ms\n", n_frames,
             std::chrono::duration<double, std::milli>(t_fill - t_alloc).count(), kind == VPCC_MEM_HOST ? "upload enqueue" : "binding",
             std::chrono::duration<double, std::milli>(t_end - t_fill).count());
+    for (int k = 0; k < 2 * vpcc_ctx::kParts; ++k)
+      if (g->block[k].ptr)
+        fprintf(stderr, "[vpcc]   %s block of part %d: %p + %.2f GB%s\n", (k & 1) ? "output" : "planes", k / 2, g->block[k].ptr,
+                g->block[k].bytes / 1073741824.0, g->block[k].pooled ? " (pool)" : "");
   }
   // descriptor staging (plans, h_frames) lives in the gof; the caller's planes must outlive the copies,
   // so creation is synchronous unless the caller asked for overlapping ingest
@@ -952,10 +865,6 @@ extern "C" int vpcc_gof_reconstruct(vpcc_gof* g, uint32_t first, uint32_t count,
       plan_tile_launch(tiles.data(), count, ctx->resident_tile_wgs_per_xcd, 3, g->tile_map);
       g->tile_map_first = first; g->tile_map_count = count; g->tile_map_valid = true;
     }
-    if (!g->placed && (g->flags & VPCC_GOF_TUNE_PLACEMENT) && first == 0 && count == g->n_frames) {
-      const int st = place_blocks(g, max_groups, s);
-      if (st) return st;
-    }
     g->generation = (g->generation % 0x3FFFFFFFu) + 1u;
     T.begin("k_recon_tiles");
     launch_tiles(g->d_frames, first, count, max_groups, g->generation, g->tile_map, ctx->resident_tile_wgs_per_xcd, s);
@@ -1011,8 +920,12 @@ int fetch_counts(vpcc_gof* g) {
                                  hipMemcpyDeviceToHost, s));
   HIP_TRY(g->ctx, hipStreamSynchronize(s));
   for (uint32_t i = 0; i < g->n_frames; ++i)
-    if (g->h_counts[g->n_frames + i])
+    if (g->h_counts[g->n_frames + i] & kErrorSpinLimit)
       return fail(g->ctx, VPCC_ERR_DEVICE, "look-back spin limit reached in frame " + std::to_string(i));
+  for (uint32_t i = 0; i < g->n_frames; ++i)
+    if (g->h_counts[g->n_frames + i] & kErrorSmoothCellOverflow)
+      return fail(g->ctx, VPCC_ERR_UNSUPPORTED, "smoothing: more than 65 537 points of frame " + std::to_string(i) +
+                  " in one grid cell (the cells' 32-bit sums may have overflowed; the frame's smoothed output is not the specification's)");
   g->counts_valid = true;
   return VPCC_OK;
 }
@@ -1031,7 +944,6 @@ extern "C" int vpcc_gof_device_outputs(vpcc_gof* g, uint32_t frame, void** d_xyz
                                        void** d_count) {
   if (!g || frame >= g->n_frames) return VPCC_ERR_INVALID_ARG;
   const DevFrame& D = g->h_frames[frame];
-  g->placed = true;                     // the caller holds these pointers from now on
   if (d_xyz) *d_xyz = D.out_xyz;
   if (d_rgb) *d_rgb = D.out_rgb;
   if (d_patch_index) *d_patch_index = D.out_patch;
@@ -1070,12 +982,6 @@ extern "C" int vpcc_gof_download(vpcc_gof* g, uint32_t frame, vpcc_point3* xyz_o
     }
     HIP_TRY(ctx, hipStreamSynchronize(s));
   }
-  return VPCC_OK;
-}
-
-extern "C" int vpcc_gof_placement(vpcc_gof* g, vpcc_placement_info* out) {
-  if (!g || !out) return VPCC_ERR_INVALID_ARG;
-  *out = g->placed ? g->mem.info : vpcc_placement_info{};
   return VPCC_OK;
 }
 
@@ -1154,6 +1060,7 @@ extern "C" int vpcc_gof_smooth(vpcc_gof* g, uint32_t first, uint32_t count, cons
   hipStream_t s = hip_stream ? (hipStream_t)hip_stream : ctx->stream;
   if (g->last_stream != s) HIP_TRY(ctx, hipStreamWaitEvent(s, g->results_ready, 0));   // behind the reconstruction
   g->last_stream = s;
+  g->counts_valid = false;                                     // (the filters may raise a frame's error flag)
   Timer T(g, s, false);
   // No host synchronisation: the kernels read every frame's point count from device memory; the launches are
   // sized for the capacity and surplus workgroups leave at once.
@@ -1196,9 +1103,11 @@ extern "C" int vpcc_gof_smooth(vpcc_gof* g, uint32_t first, uint32_t count, cons
         HIP_TRY(ctx, hipMalloc(&g->smooth_moved, (sizeof(uint64_t) * sg.moved_stride + sizeof(uint32_t) * sg.key_stride) * g->n_frames));
       sg.moved_base = (uint64_t*)g->smooth_moved;
       sg.oldkey_base = (uint32_t*)(sg.moved_base + sg.moved_stride * g->n_frames);
-      HIP_TRY(ctx, hipMemsetAsync(sg.moved_base, 0, sizeof(uint64_t) * sg.moved_stride * std::min<size_t>(count, g->n_frames), s));
     }
-    const uint32_t chunk = (uint32_t)std::max<size_t>(1, std::min<size_t>(count, (size_t(16) << 30) / sg.slot_bytes));
+    // (VPCC_SMOOTH_SCRATCH_LIMIT_MB: the limit in MB, for tests that want several chunks out of a small gof)
+    const char* limit_env = getenv("VPCC_SMOOTH_SCRATCH_LIMIT_MB");
+    const size_t scratch_limit = limit_env ? std::max<size_t>(1, (size_t)atoll(limit_env)) << 20 : size_t(16) << 30;
+    const uint32_t chunk = (uint32_t)std::max<size_t>(1, std::min<size_t>(count, scratch_limit / sg.slot_bytes));
     const size_t need = sg.slot_bytes * chunk;
     if (g->smooth_bytes < need) {
       if (g->smooth_grid) HIP_TRY(ctx, hipFree(g->smooth_grid));
@@ -1221,6 +1130,9 @@ extern "C" int vpcc_gof_smooth(vpcc_gof* g, uint32_t first, uint32_t count, cons
     for (uint32_t c0 = first; c0 < first + count; c0 += chunk) {
       const uint32_t c = std::min(chunk, first + count - c0);
       g->smooth_clean = false;                              // until the clearing kernel of this chunk is enqueued
+      // the moved-point bits are indexed by frame SLOT, and every chunk uses slots 0 .. c-1 again: zeroed per chunk (a bit
+      // left by the previous chunk's frame would send k_smooth_moved_sums to a point this frame may not even have)
+      if (both) HIP_TRY(ctx, hipMemsetAsync(sg.moved_base, 0, sizeof(uint64_t) * sg.moved_stride * c, s));
       T.begin(kNames[0][tag]);
       launch_smooth_stats(g->d_frames, c0, c, max_points, sg, w, G, both ? 2u : geo ? 0u : 1u, s);
       T.end();

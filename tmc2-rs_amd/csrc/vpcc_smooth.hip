@@ -372,8 +372,12 @@ __global__ __launch_bounds__(256) void k_smooth_mark(const DevFrame* __restrict_
   if (blockIdx.x * 1024u >= n) return;                      // 256 entries = 16 waves = 1 024 points per workgroup
   uint32_t k[4];
   const uint32_t m = listed_cells(sg, blockIdx.y, blockIdx.x * 256u + threadIdx.x, n, k);
-  for (uint32_t q = 0; q < m; ++q)
-    if (cell_mixed(gload(sg.cells(blockIdx.y) + k[q]))) {
+  for (uint32_t q = 0; q < m; ++q) {
+    const SmoothCell c = gload(sg.cells(blockIdx.y) + k[q]);
+    // The cells' sums are 32 bits wide, two to a 64-bit atomic add: beyond this many points in ONE cell a sum of 16-bit
+    // values could carry into its neighbour (the specification's u32 sums would wrap instead) — reported, not smoothed over.
+    if (c.count > kSmoothCellMaxPoints) atomicOr(f.error_flag, kErrorSmoothCellOverflow);
+    if (cell_mixed(c)) {
       paint_flags(sg.flags(blockIdx.y), k[q], w, 1);
       (sg.cells(blockIdx.y) + k[q])->mixed = kSmoothMixed | kSmoothPainted;   // for the apply kernels: the 64-bit test once per cell, not per point
       if (sg.color_offset) {                                                   // both filters: the colour filter reads the colour cells only
@@ -381,6 +385,7 @@ __global__ __launch_bounds__(256) void k_smooth_mark(const DevFrame* __restrict_
         cc->count = cc->count | kColorCellMixed;
       }
     }
+  }
 }
 
 // Restores the all-zero state: every listed cell is un-painted if flags were painted around it, and zeroed (several

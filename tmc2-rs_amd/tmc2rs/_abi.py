@@ -38,7 +38,6 @@ VPCC_GOF_WANT_PATCH_INDEX = 0x1
 VPCC_GOF_FORCE_GENERAL = 0x2
 VPCC_GOF_PROFILE = 0x4
 VPCC_GOF_ASYNC_UPLOAD = 0x8
-VPCC_GOF_TUNE_PLACEMENT = 0x10
 VPCC_GOF_COPY_PLANES = 0x20
 
 ORIENT_DEFAULT, ORIENT_SWAP, ORIENT_ROT90, ORIENT_ROT180, ORIENT_ROT270 = 0, 1, 2, 3, 4
@@ -164,9 +163,11 @@ def host_frame_desc(frame):
 _lib = None
 
 
-class PlacementInfo(C.Structure):         # vpcc_placement_info
-    _fields_ = [("tuned", C.c_uint32), ("candidates", C.c_uint32), ("ms_as_allocated", C.c_float),
-                ("ms_kept", C.c_float), ("ms_spent", C.c_float)]
+class PoolInfo(C.Structure):              # vpcc_pool_info
+    _fields_ = [("bytes", C.c_uint64), ("granules", C.c_uint32), ("kinds", C.c_uint32),
+                ("bytes_of_kind", C.c_uint64 * 2), ("in_use", C.c_uint64 * 2),
+                ("probe_gbps_same", C.c_float), ("probe_gbps_other", C.c_float), ("ms_spent", C.c_float),
+                ("other_home", C.c_uint32), ("fallbacks", C.c_uint32)]
 
 
 class DecoderStats(C.Structure):          # vpcc_decoder_stats_t
@@ -227,7 +228,8 @@ def load_library():
     lib.vpcc_gof_frame_status.argtypes = [vp, u32]
     lib.vpcc_gof_kernel_times.argtypes = [vp, C.POINTER(C.c_char_p), C.POINTER(C.c_float), C.c_int]
     lib.vpcc_gof_profile_interval.argtypes = [vp, u32]
-    lib.vpcc_gof_placement.argtypes = [vp, C.POINTER(PlacementInfo)]
+    lib.vpcc_ctx_reserve.argtypes = [vp, C.c_uint64, C.POINTER(PoolInfo)]
+    lib.vpcc_ctx_pool_info.argtypes = [vp, C.POINTER(PoolInfo)]
     lib.vpcc_gof_kernel_time_means.argtypes = [vp, u32, C.POINTER(C.c_char_p), C.POINTER(C.c_float),
                                                C.POINTER(u32), C.c_int]
     lib.vpcc_gof_algorithmic_bytes.argtypes = [vp, u32, C.POINTER(u64)]

@@ -58,6 +58,26 @@ class Context:
         """The compute stream's hipStream_t as an integer (e.g. for torch.cuda.ExternalStream)."""
         return self.lib.vpcc_ctx_stream(self.h)
 
+    @staticmethod
+    def _pool_dict(p):
+        return {"GiB": p.bytes >> 30, "granules": int(p.granules), "kinds": int(p.kinds),
+                "GiB_of_kind": [int(p.bytes_of_kind[0] >> 30), int(p.bytes_of_kind[1] >> 30)],
+                "in_use_MB": [int(p.in_use[0] >> 20), int(p.in_use[1] >> 20)],
+                "probe_GBps_same_kind": round(p.probe_gbps_same, 0), "probe_GBps_two_kinds": round(p.probe_gbps_other, 0),
+                "ms_spent": round(p.ms_spent, 1), "blocks_in_other_home": int(p.other_home), "blocks_outside_pool": int(p.fallbacks)}
+
+    def reserve(self, gib):
+        """vpcc_ctx_reserve: one allocation of `gib` GiB, classified by kind of VRAM region; every later gof of this
+        context keeps its big blocks in its two homes."""
+        p = _abi.PoolInfo()
+        self._check(self.lib.vpcc_ctx_reserve(self.h, int(gib) << 30, C.byref(p)), "vpcc_ctx_reserve")
+        return self._pool_dict(p)
+
+    def pool_info(self):
+        p = _abi.PoolInfo()
+        self._check(self.lib.vpcc_ctx_pool_info(self.h, C.byref(p)), "vpcc_ctx_pool_info")
+        return self._pool_dict(p)
+
     def _check(self, st, where):
         if st:
             raise VpccError(st, where, self.lib.vpcc_last_error(self.h).decode())
@@ -146,13 +166,6 @@ class Gof:
 
     def sync(self):
         self.ctx._check(self.lib.vpcc_gof_sync(self.h), "vpcc_gof_sync")
-
-    def placement(self):
-        """vpcc_gof_placement: what VPCC_GOF_TUNE_PLACEMENT measured for this gof (zeros when it did not run)."""
-        p = _abi.PlacementInfo()
-        self.ctx._check(self.lib.vpcc_gof_placement(self.h, C.byref(p)), "vpcc_gof_placement")
-        return {"tuned": int(p.tuned), "candidates": int(p.candidates), "ms_as_allocated": round(p.ms_as_allocated, 4),
-                "ms_kept": round(p.ms_kept, 4), "ms_spent": round(p.ms_spent, 1)}
 
     def point_counts(self):
         out = np.zeros(self.n_frames, dtype=np.uint32)
