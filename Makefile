@@ -2,6 +2,9 @@
 #   make            -> product library  tmc2-rs_amd/libvpcc_recon.so (hipcc, gfx950)
 #                      + test oracle     oracle/libvpcc_oracle.so     (gcc, plain C)
 #   make product / make oracle / make clean        (objects under build/, `make -j` works)
+#   make lds-dma    -> tmc2-rs_amd/libvpcc_recon_ldsdma.so: the library with the EXPERIMENTAL tile kernel of round 4
+#                      (tools/experiments/vpcc_tiles_lds_dma.hip: attribute tiles staged in LDS by LDS-DMA; correct, 13 % fewer
+#                      plane reads, 7 % slower — DESIGN.md 4.1.2).  Loaded only by tools/ab_prebuilt.sh.
 #   make diag       -> tmc2-rs_amd/libvpcc_recon_diag.so: the same objects, with the tile kernel compiled
 #                      -DVPCC_DIAGNOSTIC (run-time ablation switches and in-kernel stamps).  Loaded only when
 #                      a tools/ script sets VPCC_DIAG_LIB=1; tests, bench.py and the product never use it.
@@ -25,6 +28,8 @@ HIP_SRC    := $(wildcard $(CSRC)/*.hip)
 CPP_SRC    := $(wildcard $(CSRC)/*.cpp)
 PRODUCT_OBJ := $(patsubst $(CSRC)/%.hip,$(OBJ)/%.hip.o,$(HIP_SRC)) $(patsubst $(CSRC)/%.cpp,$(OBJ)/%.cpp.o,$(CPP_SRC))
 DIAG_OBJ   := $(filter-out $(OBJ)/vpcc_tiles.hip.o,$(PRODUCT_OBJ)) $(OBJ)/vpcc_tiles.diag.o
+LDSDMA_SO  := $(PROJ)/libvpcc_recon_ldsdma.so
+LDSDMA_OBJ := $(filter-out $(OBJ)/vpcc_tiles.hip.o $(OBJ)/vpcc_host.cpp.o,$(PRODUCT_OBJ)) $(OBJ)/vpcc_tiles.ldsdma.o $(OBJ)/vpcc_host.ldsdma.o
 PRODUCT_HDR := $(wildcard $(CSRC)/*.hpp) $(wildcard $(CSRC)/*.h) include/vpcc_recon.h
 
 ORACLE_SO  := oracle/libvpcc_oracle.so
@@ -34,6 +39,7 @@ ORACLE_HDR := oracle/vpcc_oracle.h oracle/vpcc_smoothing_spec.h include/vpcc_rec
 all: product oracle
 product: $(PRODUCT_SO)
 diag: $(DIAG_SO)
+lds-dma: $(LDSDMA_SO)
 oracle: $(ORACLE_SO)
 
 $(OBJ):
@@ -52,6 +58,13 @@ $(OBJ)/%.cpp.o: $(CSRC)/%.cpp $(PRODUCT_HDR) $(FLAGS_STAMP)
 $(OBJ)/vpcc_tiles.diag.o: $(CSRC)/vpcc_tiles.hip $(PRODUCT_HDR) $(FLAGS_STAMP)
 	$(HIPCC) $(HIPFLAGS) -DVPCC_DIAGNOSTIC -c -o $@ $<
 
+$(OBJ)/vpcc_tiles.ldsdma.o: tools/experiments/vpcc_tiles_lds_dma.hip $(PRODUCT_HDR) $(FLAGS_STAMP)
+	$(HIPCC) $(HIPFLAGS) -c -o $@ $<
+$(OBJ)/vpcc_host.ldsdma.o: $(CSRC)/vpcc_host.cpp $(PRODUCT_HDR) $(FLAGS_STAMP)
+	$(HIPCC) $(HIPFLAGS) -DVPCC_LDS_STAGED_ATTRIBUTES -c -o $@ $<
+$(LDSDMA_SO): $(LDSDMA_OBJ)
+	$(HIPCC) --offload-arch=$(ARCH) -shared -fPIC -o $@ $(LDSDMA_OBJ) -lpthread
+
 $(PRODUCT_SO): $(PRODUCT_OBJ)
 	$(HIPCC) --offload-arch=$(ARCH) -shared -fPIC -o $@ $(PRODUCT_OBJ) -lpthread
 $(DIAG_SO): $(DIAG_OBJ)
@@ -62,6 +75,6 @@ $(ORACLE_SO): $(ORACLE_SRC) $(ORACLE_HDR)
 	$(CC) -O2 -std=c99 -fPIC -shared -ffp-contract=off -Wall -Wextra -o $@ $(ORACLE_SRC) -lm
 
 clean:
-	rm -rf $(PRODUCT_SO) $(DIAG_SO) $(ORACLE_SO) build/obj
+	rm -rf $(PRODUCT_SO) $(DIAG_SO) $(LDSDMA_SO) $(ORACLE_SO) build/obj
 
-.PHONY: all product diag oracle clean
+.PHONY: all product diag lds-dma oracle clean

@@ -222,9 +222,15 @@ bool tile_planes_aligned(const DevFrame& d) {
     if (!al(d.geo[m], 8) || d.geo_stride[m] % 4 || d.geo_stride[m] >= (1u << 24)) return false;
     if (d.has_attr && (d.attr_stride[m] >= (1u << 24) || d.attr_cstride[m] >= (1u << 24))) return false;
     if (d.has_attr) {
-      // attribute tiles reach LDS by 16-byte LDS-DMA pieces: half a luma row / a whole chroma row of a block
+#ifdef VPCC_LDS_STAGED_ATTRIBUTES
+      // (tools/experiments/vpcc_tiles_lds_dma.hip) attribute tiles reach LDS by 16-byte LDS-DMA pieces: half a luma row /
+      // a whole chroma row of a block
       if (!al(d.attr_y[m], 16) || d.attr_stride[m] % 8) return false;
       if (!al(d.attr_u[m], 16) || !al(d.attr_v[m], 16) || d.attr_cstride[m] % 8) return false;
+#else
+      if (!al(d.attr_y[m], 8) || d.attr_stride[m] % 4) return false;
+      if (!al(d.attr_u[m], 4) || !al(d.attr_v[m], 4) || d.attr_cstride[m] % 2) return false;
+#endif
     }
   }
   return true;

@@ -215,10 +215,8 @@ __device__ __forceinline__ Item load_item(const TileItem* p) {
   return it;
 }
 
-struct Samples {       // one item's samples of the lane's 4 pixels
+struct Samples {       // one item's geometry samples of the lane's 4 pixels (the attribute samples go to LDS: AttrTiles)
   Px4 g0, g1;          // geometry D0 / D1
-  Px4 y0, y1;          // attribute luma, layer 0 / 1
-  uint32_t u0, v0, u1, v1;   // chroma: sample for pixels 0,1 in the low half, for pixels 2,3 in the high half
   uint32_t occ;        // bit j: pixel j occupied
 };
 
@@ -288,22 +286,6 @@ __device__ __forceinline__ void load_geometry(CFrame& f, const Item& it, uint32_
   s.g1 = load4_row(f.geo[1], off);                                             // single map: an alias of layer 0
 }
 
-// Attribute samples; chroma is nearest-neighbour (src/decoder.rs:977): pixels 0,1 of the lane use
-// chroma sample px0/2, pixels 2,3 the next one.
-__device__ __forceinline__ void load_attributes(CFrame& f, const Item& it, uint32_t lane, Samples& s) {
-  uint32_t px0, py0;
-  load_origin(it, lane, s.occ, px0, py0);
-  // both layers come from one video: one row pitch (tile_planes_aligned), one offset per plane kind
-  const uint32_t c0 = (__umul24(py0 >> 1, f.attr_cstride[0]) + (px0 >> 1)) * 2u;
-  const uint32_t y0 = (__umul24(py0, f.attr_stride[0]) + px0) * 2u;
-  s.y0 = load4_row(f.attr_y[0], y0);   // absent planes alias present ones
-  s.u0 = load2(f.attr_u[0], c0);
-  s.v0 = load2(f.attr_v[0], c0);
-  s.y1 = load4_row(f.attr_y[1], y0);
-  s.u1 = load2(f.attr_u[1], c0);
-  s.v1 = load2(f.attr_v[1], c0);
-}
-
 // Which D1 points duplicate their D0 point (src/codec.rs:422-427), one bit per pixel of the lane.
 //   absolute D1: the two points differ only in the normal coordinate (src/decoder.rs:881-888),
 //     depth + d1 (mode 0) or max(d1, depth) - depth = d1 - min(depth, d1) (mode 1): equal exactly when
@@ -346,6 +328,8 @@ struct PointConsts {
   int32_t nsign;           // scalar: -1 in mode 1, +1 in mode 0
   uint32_t lod_x, lod_y;   // scalar
   uint32_t sel_xy, sel_z;  // scalar byte-permute selectors
+  uint32_t su, sv;         // scalar: bit positions of the patch-local offsets du, dv in a record (Default: du = column, dv = row
+                           //   of the pixel in its canvas block; Swap: u runs down the canvas column, du = row, dv = column)
   uint32_t v_d1, v_tb, v_bb;   // vector copies of the addends
 };
 __device__ __forceinline__ PointConsts point_consts(const Item& it) {
@@ -354,14 +338,15 @@ __device__ __forceinline__ PointConsts point_consts(const Item& it) {
   c.nsign = (it.flags & kTileMode1) ? -1 : 1;
   c.lod_x = it.lod_x; c.lod_y = it.lod_y;
   c.sel_xy = it.sel_xy; c.sel_z = it.sel_z;
+  c.su = (it.flags & kTileSwap) ? 20u : 16u; c.sv = (it.flags & kTileSwap) ? 16u : 20u;
   c.v_d1 = it.d1; c.v_tb = it.tb; c.v_bb = it.bb;
   c.nmin = __builtin_amdgcn_readfirstlane(c.nmin);            // opaque: one v_min_u32, not min + select on the mode
   asm volatile("" : "+v"(c.v_d1), "+v"(c.v_tb), "+v"(c.v_bb));
   return c;
 }
-// rx = depth | du << 16 | dv << 20 | ... (the low three bytes of a point record)
+// rx = depth | column << 16 | row << 20 | ... (the low three bytes of a point record)
 __device__ __forceinline__ uint2 pack_point(const PointConsts& c, uint32_t rx) {
-  const uint32_t depth = rx & 0xFFFFu, du = __builtin_amdgcn_ubfe(rx, 16u, 4u), dv = __builtin_amdgcn_ubfe(rx, 20u, 4u);
+  const uint32_t depth = rx & 0xFFFFu, du = __builtin_amdgcn_ubfe(rx, c.su, 4u), dv = __builtin_amdgcn_ubfe(rx, c.sv, 4u);
   // normal coordinate: mode 0: depth + d1; mode 1: max(d1, depth) - depth = d1 - min(depth, d1)
   const uint32_t m = __builtin_elementwise_min(depth, c.nmin);               // depth < 2^14
   const uint32_t n = (uint32_t)__mul24((int32_t)m, c.nsign) + c.v_d1;
@@ -379,17 +364,110 @@ __device__ __forceinline__ uint2 relative_point(uint32_t na, bool mode1, uint2 p
   return make_uint2(c[0] | (c[1] << 16), c[2]);
 }
 
-// ---- convert_yuv10_to_rgb8 (src/codec.rs:661-687) for the lane's 4 pixels of one layer ------------
-// vpcc_colour.h: f64 FMAs on a 2^-20 grid whose low dword is the fixed-point result — no division, no
-// floor, no float compare.  Pixels 0,1 and 2,3 share a chroma sample (src/decoder.rs:977), so the
-// chroma part of each channel is evaluated once per pair.  When a fraction pattern could hide an exact
-// integer (2.4e-5 of all triplets; checked on the whole 10-bit cube by tests/colour_exhaustive.c) or a
-// sample exceeds 10 bits, the lane evaluates the reference formula itself.
+// ---- attribute tiles in LDS ---------------------------------------------------------------------------------------
+// The attribute samples of an item never pass through registers: the 16x16 luma tile of both layers and the 8x8
+// chroma tiles of U and V of both layers (1 536 B) are copied from the raster planes straight into LDS by LDS-DMA
+// (global_load_lds_dwordx4: a per-lane source address, 16 B per lane, destination = wave-uniform base + 16 * lane),
+// for ALL sixteen items of a group in one burst, a whole step before the group is emitted: the four (luma) / eight
+// (chroma) horizontally neighbouring blocks that share a 128-byte line ask for it while it is in flight or L2-hot,
+// whatever their position in the group — with register loads one item ahead of emission (rounds 1-3) a line shared by
+// two consecutive quads of items was fetched twice, 5.7 us apart (900 MB read for 512 MB of attribute samples).
+// A wave stages the tiles of its own four items; nobody else reads them, so no barrier is involved: the DMA is issued
+// behind the last store loop of a step, the count phase of the next step issues and consumes ordinary loads behind it,
+// and the vector-memory counter retires in order — once those loads have arrived the tiles have landed.
+// Layout per wave (6 KB), per pair of items 2k, 2k + 1 (3 KB): [luma 2k | chroma 2k | chroma 2k+1 | luma 2k+1] with a luma
+// tile [layer][row 0..15][16 samples] (1 KB) and the chroma tiles [U0, V0, U1, V1][row 0..7][8 samples] (512 B): the two
+// chroma tiles of a pair are one DMA instruction, and the tiles of ONE item are contiguous (its records overflow into them).
+constexpr uint32_t kAttrLumaBytes = 1024u, kAttrChromaBytes = 512u;
+constexpr uint32_t kAttrItemBytes = kAttrLumaBytes + kAttrChromaBytes;
+constexpr uint32_t kAttrWaveBytes = kTileItemsPerWave * kAttrItemBytes;
+__host__ __device__ constexpr uint32_t attr_luma_off(uint32_t i) { return 2u * kAttrItemBytes * (i >> 1) + ((i & 1u) ? 2048u : 0u); }
+__host__ __device__ constexpr uint32_t attr_chroma_off(uint32_t i) { return 2u * kAttrItemBytes * (i >> 1) + 1024u + 512u * (i & 1u); }
+__host__ __device__ constexpr uint32_t attr_item_off(uint32_t i) { return kAttrItemBytes * i; }   // first byte of item i's tiles
+typedef __attribute__((address_space(3))) unsigned char LdsByte;
+typedef uint32_t Rec __attribute__((ext_vector_type(2)));          // a point record (below); a plain vector type: usable through LDS pointers
+typedef __attribute__((address_space(3))) Rec LdsRec;
+
+// One LDS-DMA instruction: 16 bytes per active lane from `src` to LDS byte address `lds_base` + 16 * lane.  M0 (the
+// destination base) is compiler-reserved: saved and restored inside the statement.  The compiler does not count this
+// load (cdna_hip_programming.md, inline asm: "no VGPR destination: register-safe"); see above for what orders it.
+__device__ __forceinline__ void lds_dma16(const VPCC_GLOBAL unsigned char* src, uint32_t lds_base) {
+  uint32_t keep;
+  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+               : "=&s"(keep) : "v"(src), "s"(lds_base) : "memory");
+}
+
+// Stages the attribute tiles of the wave's four items of group `g` of frame `f`.  `occ4`: the lane's occupancy
+// nibbles of those items (count phase).  A block row (luma) / row pair (chroma) without any occupied pixel is not
+// fetched: its lanes read the block's first occupied row instead (their LDS bytes are never looked at) — what the
+// redirect of unoccupied lanes did for the register loads.  An item without occupancy (or past the end of the frame)
+// is skipped.
+__device__ __forceinline__ void stage_attributes(CFrame& f, uint32_t g, uint32_t wave, uint32_t lane, uint32_t occ4,
+                                                 uint32_t lds_wave, const uint32_t kItems = 0xFu) {   // bit i: stage the wave's i-th item
+  if (!f.has_attr) return;
+  // (opaque: everything derived from the lane id below is loop-invariant in the kernel's step loop, and the compiler would
+  // keep it in registers — spilled ones — for the whole step instead of recomputing a few shifts here once per step)
+  asm volatile("" : "+v"(lane));
+  uint32_t x0[4], y0[4], lo[4], hi[4];                     // scalars: block origin, occupied pixel-lanes of the item (64 bits)
+#pragma unroll
+  for (uint32_t i = 0; i < 4; ++i) {
+    const uint32_t idx = g * kTileItemsPerGroup + i * kTileWaves + wave;
+    const uint32_t w0 = *(const VPCC_CONSTANT uint32_t*)(f.tiles + (idx < f.n_tiles ? idx : 0u));
+    x0[i] = w0 & 0xFFFFu; y0[i] = w0 >> 16;
+    const uint64_t m = (idx < f.n_tiles && ((kItems >> i) & 1u)) ? __ballot(((occ4 >> (4u * i)) & 0xFu) != 0u) : 0ull;
+    lo[i] = (uint32_t)m; hi[i] = (uint32_t)(m >> 32);
+  }
+  {
+    // luma: lane = layer * 32 + row * 2 + half; 16 bytes = 8 samples of row `row`
+    const uint32_t row = (lane >> 1) & 15u, half = lane & 1u;
+    // (the plane pointers are read as SCALARS and selected per lane afterwards: a select between two descriptor fields
+    // with a per-lane condition becomes a vector load of the descriptor behind a vmcnt(0) — a wait for the stores)
+    uint64_t ya = (uint64_t)f.attr_y[0], yb = (uint64_t)f.attr_y[1];
+    asm volatile("" : "+s"(ya), "+s"(yb));
+    const VPCC_GLOBAL unsigned char* plane = (const VPCC_GLOBAL unsigned char*)((lane >> 5) ? yb : ya);
+#pragma unroll
+    for (uint32_t i = 0; i < 4; ++i) {
+      const uint64_t m = ((uint64_t)hi[i] << 32) | lo[i];
+      if (m == 0ull) continue;                                                     // wave-uniform
+      const uint32_t first = (uint32_t)__builtin_ctzll(m) >> 2;                    // first occupied row
+      const uint32_t r = ((uint32_t)(m >> (4u * row)) & 0xFu) ? row : first;
+      const uint32_t off = (__umul24(y0[i] + r, f.attr_stride[0]) + x0[i] + 8u * half) * 2u;
+      lds_dma16(plane + off, lds_wave + attr_luma_off(i));
+    }
+  }
+  {
+    // chroma: lane = item-of-pair * 32 + plane * 8 + row; 16 bytes = the 8 samples of chroma row `row` of the block
+    const uint32_t which = lane >> 5, pl = (lane >> 3) & 3u, row = lane & 7u;
+    uint64_t ua = (uint64_t)f.attr_u[0], ub = (uint64_t)f.attr_u[1], va = (uint64_t)f.attr_v[0], vb = (uint64_t)f.attr_v[1];
+    asm volatile("" : "+s"(ua), "+s"(ub), "+s"(va), "+s"(vb));
+    const uint64_t pu = (pl & 2u) ? ub : ua, pv = (pl & 2u) ? vb : va;
+    const VPCC_GLOBAL unsigned char* plane = (const VPCC_GLOBAL unsigned char*)((pl & 1u) ? pv : pu);
+#pragma unroll
+    for (uint32_t k = 0; k < 2; ++k) {
+      const uint64_t ma = ((uint64_t)hi[2 * k] << 32) | lo[2 * k], mb = ((uint64_t)hi[2 * k + 1] << 32) | lo[2 * k + 1];
+      if ((ma | mb) == 0ull) continue;                                             // wave-uniform
+      const uint32_t fa = ma ? (uint32_t)__builtin_ctzll(ma) >> 3 : 0u, fb = mb ? (uint32_t)__builtin_ctzll(mb) >> 3 : 0u;
+      const uint64_t m = which ? mb : ma;
+      const uint32_t r = ((uint32_t)(m >> (8u * row)) & 0xFFu) ? row : (which ? fb : fa);
+      const uint32_t bx = which ? x0[2 * k + 1] : x0[2 * k], by = which ? y0[2 * k + 1] : y0[2 * k];
+      const uint32_t off = (__umul24((by >> 1) + r, f.attr_cstride[0]) + (bx >> 1)) * 2u;
+      if (m != 0ull) lds_dma16(plane + off, lds_wave + attr_chroma_off(2u * k));
+    }
+  }
+}
+
+// ---- convert_yuv10_to_rgb8 (src/codec.rs:661-687) of one point --------------------------------------------------
+// vpcc_colour.h: f64 FMAs on a 2^-20 grid whose low dword is the fixed-point result — no division, no floor, no float
+// compare.  When a fraction pattern could hide an exact integer (2.4e-5 of all triplets; checked on the whole 10-bit
+// cube by tests/colour_exhaustive.c) or a sample exceeds 10 bits, the lane evaluates the reference formula itself.
+// The conversion runs AFTER the compaction, per emitted point (58 % of the pixel-layers of an occupied block), on the
+// samples the point's record leads to in the item's LDS tiles.
 __device__ __forceinline__ uint32_t colour_exact(uint32_t Y, uint32_t U, uint32_t V) {
   const vpcc_color3 c = yuv10_to_rgb8((uint16_t)Y, (uint16_t)U, (uint16_t)V);
   return (uint32_t)c.r | ((uint32_t)c.g << 8) | ((uint32_t)c.b << 16);
 }
-
+// The lane's four pixels of one layer: pixels 0,1 and 2,3 share a chroma sample (src/decoder.rs:977), so the chroma
+// part of each channel is evaluated once per pair.
 __device__ __forceinline__ void colours4(const Px4& y, uint32_t u, uint32_t v, uint32_t rgb[4]) {
   const vpcc_chroma_part c01 = vpcc_colour_chroma(u & 0xFFFFu, v & 0xFFFFu);
   const vpcc_chroma_part c23 = vpcc_colour_chroma(u >> 16, v >> 16);
@@ -408,21 +486,42 @@ __device__ __forceinline__ void colours4(const Px4& y, uint32_t u, uint32_t v, u
 }
 
 // 8-B point record:
-//   x: depth | du << 16 | dv << 20 | layer << 24     (du, dv: the pixel's patch-local offsets in the block)
+//   x: depth | c << 16 | layer << 24     (c: the pixel's position in its canvas block, 16 * row + column)
 //   y: r | g << 8 | b << 16
 // A D1 record always directly follows the D0 record of its pixel (relative D1 reads its depth there).
-// Writes are unconditional: an absent point goes to the lane's dump slot behind the 512 record slots.
-constexpr uint32_t kSlotsPerWave = 512u + 64u;
+// Writes are unconditional: an absent point goes to the lane's dump slot.
+// Where the records live: the first kRecordsOwn of an item in the wave's own slots (with the 64 dump slots behind
+// them), the rest — an item has up to 512 — in the item's ATTRIBUTE TILE, which is dead once the colours of the item's
+// pixels have been computed (1 536 B = 192 records): with 24 KB of tiles per workgroup, 512 slots of its own per wave
+// would cost the fourth workgroup per CU (160 KB of LDS).
+#ifndef VPCC_RECORDS_OWN
+#define VPCC_RECORDS_OWN 320
+#endif
+constexpr uint32_t kRecordsOwn = VPCC_RECORDS_OWN;                    // 512: no record ever goes to the tile
+constexpr uint32_t kSlotsPerWave = kRecordsOwn + 64u;
+static_assert(kRecordsOwn == 512u || kRecordsOwn + kAttrItemBytes / 8u >= 512u, "an item has up to 512 points");
+static_assert(kRecordsOwn * 8u >= 768u, "pixel_ranks' scratch");
+
+// LDS byte address of record `r` (r < 512) or of dump slot kRecordsOwn + lane
+struct RecordSpace {
+  LdsByte* own;            // the wave's slots
+  LdsByte* tile;           // the item's tiles - 8 * kRecordsOwn: record r >= kRecordsOwn lies at tile + 8 r
+  __device__ __forceinline__ LdsRec* at(uint32_t r) const {
+    if constexpr (kRecordsOwn >= 512u) return (LdsRec*)(own + 8u * r);
+    return (LdsRec*)((r < kRecordsOwn ? own : tile) + 8u * r);
+  }
+  __device__ __forceinline__ LdsRec* dump(uint32_t lane) const { return (LdsRec*)(own + 8u * (kRecordsOwn + lane)); }
+};
 
 template <int J>
-__device__ __forceinline__ void put_records(const Samples& s, uint32_t dup, uint32_t pixel, uint32_t rank,
-                                            uint32_t dump, const uint32_t rgb0[4], const uint32_t rgb1[4], uint2* slots) {
+__device__ __forceinline__ void put_records(const Samples& s, uint32_t dup, uint32_t pixel, uint32_t rank, uint32_t lane,
+                                            const uint32_t rgb0[4], const uint32_t rgb1[4], const RecordSpace& rs) {
   const bool occ = (s.occ >> J) & 1u, second = occ && !((dup >> J) & 1u);
   // depth = sample / 4 (src/codec.rs:534, 548): bits 2..15 of the pixel's half of the dword
   const uint32_t d0 = __builtin_amdgcn_ubfe(J < 2 ? s.g0.lo : s.g0.hi, 2u + 16u * (J & 1), 14u);
   const uint32_t d1 = __builtin_amdgcn_ubfe(J < 2 ? s.g1.lo : s.g1.hi, 2u + 16u * (J & 1), 14u);
-  slots[occ ? rank : dump] = make_uint2(d0 | (pixel << 16), rgb0[J]);
-  slots[second ? rank + 1u : dump] = make_uint2(d1 | (pixel << 16) | (1u << 24), rgb1[J]);
+  *(occ ? rs.at(rank) : rs.dump(lane)) = Rec{d0 | (pixel << 16), rgb0[J]};
+  *(second ? rs.at(rank + 1u) : rs.dump(lane)) = Rec{d1 | (pixel << 16) | (1u << 24), rgb1[J]};
 }
 
 // Ranks of the lane's 4 pixels inside the item, emission order (src/codec.rs:382-385: v1 outer, u1 inner).
@@ -541,25 +640,20 @@ __device__ __forceinline__ void store_xyz2(VPCC_GLOBAL unsigned char* base, uint
 // for: the store loop, count + publication of the group total, the issue of the next item's loads.  Each is
 // worth 0.7-1.4 % (tools/ab.sh), together 2.5 %; holding the priority through the look-back as well costs 5 %.
 
-// "Take delivery" of prefetched samples: an empty asm that uses the registers, so the compiler places the
-// wait for their loads HERE (and knows them complete afterwards).
-__device__ __forceinline__ void take_delivery(Samples& s) {
-  asm volatile("" : "+v"(s.g0.lo), "+v"(s.g0.hi), "+v"(s.g1.lo), "+v"(s.g1.hi), "+v"(s.y0.lo), "+v"(s.y0.hi),
-               "+v"(s.y1.lo), "+v"(s.y1.hi));
-  asm volatile("" : "+v"(s.u0), "+v"(s.v0), "+v"(s.u1), "+v"(s.v1));
-}
-
-// One item from samples in registers to its points in HBM: ranks, colours, compaction of the 8-B records
-// through the wave's LDS slots, then lane <-> point (back-projection, contiguous stores at `base`).
-// `n` = the item's point count (wave-uniform, from the count phase), `dup` its duplicate nibble.
+// One item from geometry samples in registers and attribute tiles in LDS to its points in HBM: ranks, colours of the
+// lane's pixels, compaction of the 8-B records through LDS, then lane <-> point (back-projection, contiguous stores at
+// `base`).  `n` = the item's point count (wave-uniform, from the count phase), `dup` its duplicate nibble.
 template <bool kStamps = false, class Hook>
 __device__ __forceinline__ void emit_item(CFrame& f, const Item& it, const Samples& cur, uint32_t dup, uint32_t n,
-                                          uint32_t base, uint32_t lane, uint2* slots, uint32_t variant, Hook before_stores,
+                                          uint32_t base, uint32_t lane, const RecordSpace& rs, const LdsByte* luma,
+                                          const LdsByte* chroma, uint32_t variant, Hook before_stores,
                                           unsigned long long* t_acc = nullptr) {
   [[maybe_unused]] unsigned long long t_prev = kStamps ? stamp() : 0ull;
   VPCC_GLOBAL unsigned char* const gx = (VPCC_GLOBAL unsigned char*)f.out_xyz;
   VPCC_GLOBAL unsigned char* const gc = (VPCC_GLOBAL unsigned char*)f.out_rgb;
   VPCC_GLOBAL uint16_t* const gp = glw(f.out_patch);
+  typedef const LdsRec LdsU2;
+  typedef __attribute__((address_space(3))) const uint32_t LdsU1;
   // An empty item (n == 0, wave-uniform) skips both halves.  The hook sits on the joined path between them, not
   // in either branch: the compiler's branch lowering leaves bypass edges that never run ("exec == 0") around
   // conditional code, and a delivery that such an edge skips counts as missing — the price is a vmcnt(0), a wait
@@ -567,28 +661,33 @@ __device__ __forceinline__ void emit_item(CFrame& f, const Item& it, const Sampl
   if (n != 0) {
     uint32_t rk[4];
     const uint32_t cnt = 2u * (uint32_t)__builtin_popcount(cur.occ) - (uint32_t)__builtin_popcount(dup);
-    pixel_ranks(it, cur, dup, cnt, lane, reinterpret_cast<unsigned char*>(slots), rk);
+    pixel_ranks(it, cur, dup, cnt, lane, (unsigned char*)rs.own, rk);
     uint32_t rgb0[4] = {0, 0, 0, 0}, rgb1[4] = {0, 0, 0, 0};
     if (f.has_attr && !(variant & 8u)) {
-      colours4(cur.y0, cur.u0, cur.v0, rgb0);
-      if (f.map_count > 1) colours4(cur.y1, cur.u1, cur.v1, rgb1);
+      // the lane's samples from the item's tiles: pixels 4 lane .. + 3 of the block (8 B per layer), and the chroma
+      // samples of row (lane >> 2) / 2, columns 2 (lane & 3), + 1 (4 B per plane)
+      const Rec ya = *(LdsU2*)(luma + 8u * lane), yb = *(LdsU2*)(luma + 512u + 8u * lane);
+      const uint32_t co = (lane >> 3) * 16u + (lane & 3u) * 4u;
+      const uint32_t u0 = *(LdsU1*)(chroma + co), v0 = *(LdsU1*)(chroma + co + 128u);
+      const uint32_t u1 = *(LdsU1*)(chroma + co + 256u), v1 = *(LdsU1*)(chroma + co + 384u);
+      colours4(Px4{ya.x, ya.y}, u0, v0, rgb0);
+      if (f.map_count > 1) colours4(Px4{yb.x, yb.y}, u1, v1, rgb1);
     }
-    // patch-local offsets of the lane's pixels: Default (du, dv) = (4q + j, r); Swap (du, dv) = (r, 4q + j)
-    const uint32_t q4 = 4u * (lane & 3u), r = lane >> 2;
-    const bool swap = it.flags & kTileSwap;
-    const uint32_t pix0 = swap ? q4 * 16u + r : r * 16u + q4, pstep = swap ? 16u : 1u;
-    const uint32_t dump = 512u + lane;
-    put_records<0>(cur, dup, pix0, rk[0], dump, rgb0, rgb1, slots);
-    put_records<1>(cur, dup, pix0 + pstep, rk[1], dump, rgb0, rgb1, slots);
-    put_records<2>(cur, dup, pix0 + 2u * pstep, rk[2], dump, rgb0, rgb1, slots);
-    put_records<3>(cur, dup, pix0 + 3u * pstep, rk[3], dump, rgb0, rgb1, slots);
+    const uint32_t pix0 = 4u * lane;                  // 16 * row + column of the lane's first pixel in the canvas block
+    // (every lane has its samples: from here on the tiles may be overwritten — records beyond kRecordsOwn go there)
+    put_records<0>(cur, dup, pix0, rk[0], lane, rgb0, rgb1, rs);
+    put_records<1>(cur, dup, pix0 + 1u, rk[1], lane, rgb0, rgb1, rs);
+    put_records<2>(cur, dup, pix0 + 2u, rk[2], lane, rgb0, rgb1, rs);
+    put_records<3>(cur, dup, pix0 + 3u, rk[3], lane, rgb0, rgb1, rs);
     wave_sync();                                      // records written by other lanes are read below
   }
   VPCC_STAMP(7)
   before_stores();
   VPCC_STAMP(8)
   if (n == 0) return;
+#ifndef VPCC_NO_STORE_PRIO
   __builtin_amdgcn_s_setprio(1);                    // the store loop feeds the memory pipeline: issue it ahead of arithmetic waves
+#endif
 
   const uint32_t room = base < f.capacity ? f.capacity - base : 0u;   // never write past the caller's arrays
   const uint32_t nw = n < room ? n : room;
@@ -605,26 +704,24 @@ __device__ __forceinline__ void emit_item(CFrame& f, const Item& it, const Sampl
   //           128-byte lines (128 points = 768 B of positions = 384 B of colours = 256 B of partition entries) and
   //           every dwordx3 is dword-aligned.
   //   edges : the up to three points in front of b4 and the up to three behind e4 — at most 54 bytes — with ONE byte-store
-  //           instruction, lane <-> byte (lanes 0..26: head, 32..58: tail).  The pair / single / quad-remainder stores
-  //           these points used to need were 5.7 of the 12.4 store instructions per item, each with one to three
-  //           active lanes (profiles/r03/insts_per_variant.txt).
+  //           instruction, lane <-> byte (lanes 0..26: head, 32..58: tail).
   const uint32_t B = base, E = base + nw;
   const uint32_t b4 = (B + 3u) & ~3u, e4 = E & ~3u;
   auto point_of = [&](uint32_t r, uint32_t rx) -> uint2 {
     uint2 p = pack_point(pc, rx);
     if (!f.absolute_d1 && (rx >> 24) != 0)                 // relative D1: the D0 record of the pixel precedes it
-      p = relative_point(it.axes & 3u, it.flags & kTileMode1, pack_point(pc, (slots[r - 1u].x & 0xFFFFu) | (rx & 0xFF0000u)), rx & 0xFFFFu);
+      p = relative_point(it.axes & 3u, it.flags & kTileMode1, pack_point(pc, (rs.at(r - 1u)->x & 0xFFFFu) | (rx & 0xFF0000u)), rx & 0xFFFFu);
     return p;
   };
   if (b4 < e4)
     for (uint32_t a = (b4 & ~127u) + 2u * lane; a < e4; a += 128u) {
       if (a < b4) continue;                                    // (first trip: lanes in front of the bulk; whole lane pairs)
       const uint32_t k = a - B;                                // record index of the lane's first point
-      const uint2 r0 = slots[k], r1 = slots[k + 1u];
+      const Rec r0 = *rs.at(k), r1 = *rs.at(k + 1u);
       uint2 p0 = pack_point(pc, r0.x), p1 = pack_point(pc, r1.x);
       if (!f.absolute_d1) {                                    // wave-uniform
         if ((r0.x >> 24) != 0)
-          p0 = relative_point(it.axes & 3u, it.flags & kTileMode1, pack_point(pc, (slots[k - 1u].x & 0xFFFFu) | (r0.x & 0xFF0000u)), r0.x & 0xFFFFu);
+          p0 = relative_point(it.axes & 3u, it.flags & kTileMode1, pack_point(pc, (rs.at(k - 1u)->x & 0xFFFFu) | (r0.x & 0xFF0000u)), r0.x & 0xFFFFu);
         if ((r1.x >> 24) != 0)
           p1 = relative_point(it.axes & 3u, it.flags & kTileMode1, pack_point(pc, (r0.x & 0xFFFFu) | (r1.x & 0xFF0000u)), r1.x & 0xFFFFu);
       }
@@ -647,7 +744,7 @@ __device__ __forceinline__ void emit_item(CFrame& f, const Item& it, const Sampl
     const uint32_t ap = (tail ? t0 : B) + pt;                  // the lane's point, absolute
     const bool on = pt < (tail ? tn : hn) && (byte < 6u || f.has_attr) && !(variant & 32u);
     if (on) {
-      const uint2 rec = slots[ap - B];
+      const Rec rec = *rs.at(ap - B);
       const uint2 p = point_of(ap - B, rec.x);
       const uint32_t word = byte < 4u ? p.x : byte < 6u ? p.y : rec.y;
       const uint32_t sh = 8u * (byte < 4u ? byte : byte < 6u ? byte - 4u : byte - 6u);
@@ -669,7 +766,10 @@ __device__ __forceinline__ void emit_item(CFrame& f, const Item& it, const Sampl
 __device__ __forceinline__ uint32_t item_in_group(uint32_t wave, uint32_t i) { return i * kTileWaves + wave; }
 
 template <bool kStamps>
-__global__ __launch_bounds__(64 * kTileWaves) __attribute__((amdgpu_waves_per_eu(4, 4)))
+#ifndef VPCC_TILE_WAVES_PER_SIMD
+#define VPCC_TILE_WAVES_PER_SIMD 4
+#endif
+__global__ __launch_bounds__(64 * kTileWaves) __attribute__((amdgpu_waves_per_eu(VPCC_TILE_WAVES_PER_SIMD, VPCC_TILE_WAVES_PER_SIMD)))
 void k_recon_tiles(const DevFrame* __restrict__ frames, uint32_t first,
                                                      uint32_t count, uint32_t gen,
                                                      uint32_t variant_arg, const TileLaunchMap map) {
@@ -684,7 +784,8 @@ void k_recon_tiles(const DevFrame* __restrict__ frames, uint32_t first,
   // (lines shared between neighbouring blocks), but more workgroups per frame mean longer look-back chains and more
   // changes of frame.  Measured on 128-frame launches: raster planes as hipMalloc places them 4 / 8 / 16 frames in
   // flight 0.5195 / 0.5155 / 0.5016 ms; raster planes on placed blocks 0.459 / 0.4531 / 0.4537 (and 91 MB fewer
-  // reads with 8) (profiles/r03/ab_frames_in_flight*.txt); round 4, blocks in the pool's two homes: see profiles/r04/ab_kernel.txt.
+  // reads with 8); TILED planes (a block's lines are its own) 0.4052 / 0.3989 / 0.3970, S-owlii 0.9546 (8) vs 0.9417
+  // (16), reads all but equal (profiles/r03/ab_frames_in_flight*.txt, ab_tiled.txt): 16.
   const uint32_t xcd = blockIdx.x & 7u, slot = blockIdx.x >> 3;
   const uint32_t frame_groups = (count + 7u) / 8u;
   const bool rounds = frame_groups > kFramesInFlight;
@@ -703,6 +804,7 @@ void k_recon_tiles(const DevFrame* __restrict__ frames, uint32_t first,
   __shared__ uint32_t s_group, s_frame;
   __shared__ uint32_t s_tot[2][kTileItemsPerGroup];                     // point counts of the two groups in flight
   __shared__ __attribute__((aligned(16))) uint2 s_slots[kTileWaves][kSlotsPerWave];
+  __shared__ __attribute__((aligned(16))) unsigned char s_attr[kTileWaves][kAttrWaveBytes];   // attribute tiles (stage_attributes)
 
   [[maybe_unused]] unsigned long long t_prev = kStamps ? stamp() : 0ull;
   [[maybe_unused]] unsigned long long t_acc[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
@@ -710,7 +812,10 @@ void k_recon_tiles(const DevFrame* __restrict__ frames, uint32_t first,
   constexpr uint32_t K = kTileItemsPerWave;
   static_assert(K == 4, "one occupancy / duplicate nibble per item; four items of resident geometry");
 
-  uint2* slots = s_slots[wave];
+  LdsByte* const slots = (LdsByte*)s_slots[wave];
+  const LdsByte* const attr = (const LdsByte*)s_attr[wave];
+  // the LDS byte address of the wave's tiles, for the DMA's M0 (an LDS pointer is its 32-bit offset)
+  const uint32_t attr_lds = __builtin_amdgcn_readfirstlane((uint32_t)(uintptr_t)(LdsByte*)s_attr[wave]);
 
   // ---- cross-frame pipeline: the workgroup's "next" group may belong to a later frame than its "current" one
   if (xcd + 8u * label_frame >= count) return;
@@ -721,8 +826,6 @@ void k_recon_tiles(const DevFrame* __restrict__ frames, uint32_t first,
   bool have_cur = false;
   // gn*: geometry of the group just counted (next), gc*: of the group being emitted (current)
   Px4 gn0[4] = {}, gn1[4] = {}, gc0[4] = {}, gc1[4] = {};
-  Samples a_first = {};                // attribute samples of the wave's first item of the current group,
-                                       // prefetched during the previous step
   // Once its own frames have run dry a workgroup HELPS: it draws from the frames of its XCD label that still have
   // groups to hand out (the last frames of the other teams, which end up to 12 % apart: frames differ in size).
   bool helping = false;
@@ -881,9 +984,6 @@ void k_recon_tiles(const DevFrame* __restrict__ frames, uint32_t first,
       asm volatile("" : "+v"(early));
       const uint32_t first_item = g_cur * kTileItemsPerGroup + item_in_group(wave, 0);
       Item it = load_item(f.tiles + (first_item < f.n_tiles ? first_item : 0u));
-      Samples cur = a_first;                                 // attributes prefetched during the previous step
-      cur.occ = occ_cur & 0xFu;
-      cur.g0 = gc0[0]; cur.g1 = gc1[0];
       if (wave == 0 && lane == 0) {
         if (g_cur != 0 && !(variant & 1u))
           st_store(f.scan_state + g_cur, ((uint64_t)gen << kGenShift) | kPrefix | (uint64_t)(excl + total_cur));
@@ -894,38 +994,28 @@ void k_recon_tiles(const DevFrame* __restrict__ frames, uint32_t first,
       uint32_t base = excl;
       for (uint32_t k = 0; k < item_in_group(wave, 0); ++k) base += s_tot[cb][k];
 
-      // ---- 4. per item: colours, compaction of the records through LDS, then lane <-> point ---------
+      // ---- 4. per item: compaction of the records through LDS, then lane <-> point (position, colour, stores).
+      // The item's geometry has been in registers since it was counted a step ago, its attribute tiles in LDS since
+      // the end of the previous step: the loop issues no plane load at all.
 #pragma unroll
       for (uint32_t i = 0; i < K; ++i) {
-        // scalar on purpose: a branch on a VGPR value is lowered with exec masks and an "exec == 0" bypass edge —
-        // a path that never runs, but along which the compiler sees this item's prefetch loads undelivered
+        // scalar on purpose: a branch on a VGPR value is lowered with exec masks and an "exec == 0" bypass edge
         const uint32_t n = __builtin_amdgcn_readfirstlane(s_tot[cb][item_in_group(wave, i)]);
-        // Prefetch the attribute samples of the wave's next item — after its last item of this group, of
-        // its first item of the NEXT group (counted above; possibly of another frame), so that no step begins with an
-        // exposed load.  The loads are unconditional (at the very end of the workgroup's work they re-read the current
-        // item): one counter state on every path.  Nothing here depends on an outstanding vector load.
-        __builtin_amdgcn_s_setprio(1);                      // get the next item's loads out before this item's arithmetic
-        const bool within = i + 1u < K;
-        uint32_t next_item = within ? g_cur * kTileItemsPerGroup + item_in_group(wave, i + 1u)
-                                    : g_next * kTileItemsPerGroup + item_in_group(wave, 0);
-        if (!within && !have_next) next_item = g_cur * kTileItemsPerGroup + item_in_group(wave, i);
-        CFrame& fp = (within || !have_next) ? *fc : *fn;
-        const Item nit = load_item(fp.tiles + (next_item < fp.n_tiles ? next_item : 0u));
-        Samples nxt;
-        nxt.occ = within ? (occ_cur >> (4u * (i + 1u))) & 0xFu : (have_next ? occ_next & 0xFu : cur.occ);
-        nxt.g0 = within ? gc0[(i + 1u) & 3u] : gn0[0];                  // unrolled: static indices
-        nxt.g1 = within ? gc1[(i + 1u) & 3u] : gn1[0];
-        if (!(variant & 256u)) load_attributes(fp, nit, lane, nxt);
-        else { nxt.y0 = nxt.y1 = Px4{0u, 0u}; nxt.u0 = nxt.v0 = nxt.u1 = nxt.v1 = 0u; }
-
-        __builtin_amdgcn_s_setprio(0);
+        const uint32_t next_item = g_cur * kTileItemsPerGroup + item_in_group(wave, i + 1u < K ? i + 1u : i);
+        const Item nit = load_item(f.tiles + (next_item < f.n_tiles ? next_item : 0u));   // scalar: the descriptor of the wave's next item
+        Samples cur;
+        cur.occ = (occ_cur >> (4u * i)) & 0xFu;
+        cur.g0 = gc0[i]; cur.g1 = gc1[i];                                  // unrolled: static indices
         {
           const uint32_t dup = (dup_cur >> (4u * i)) & 0xFu;                 // from the count phase
-          // Take delivery of the prefetched samples before this item's stores are issued: waited for
-          // later, the in-order vmcnt would make that wait cover the stores as well.
-          emit_item<kStamps>(f, it, cur, dup, n, base, lane, slots, variant, [&]() {
-            take_delivery(nxt);
+          const RecordSpace rs{slots, (LdsByte*)attr + attr_item_off(i) - 8u * kRecordsOwn};
+          emit_item<kStamps>(f, it, cur, dup, n, base, lane, rs, attr + attr_luma_off(i), attr + attr_chroma_off(i), variant, [&]() {
             asm volatile("" : "+v"(t_ahead));
+            // The tiles of the item emitted before this one are free: their successor — the same item of the group just
+            // counted — is requested now, BEFORE this item's stores (behind them it would wait in the memory pipeline for
+            // the whole burst to drain; all sixteen tiles at the end of the step: 0.532 ms, three quarters of them here in
+            // the last item: 0.530, item by item: 0.527 — profiles/r04/ab_stage.txt).
+            if (i >= 1u && have_next && !(variant & 256u)) stage_attributes(*fn, g_next, wave, lane, occ_next, attr_lds, 1u << (i - 1u));
             if (i + 1u == K) {
               // Hand the loop-carried registers over BEFORE the last item's stores: register copies made in
               // the loop latch, behind those stores, are preceded by a vmcnt(0) (with loads and stores both in
@@ -935,30 +1025,28 @@ void k_recon_tiles(const DevFrame* __restrict__ frames, uint32_t first,
                 gc0[j] = gn0[j]; gc1[j] = gn1[j];
                 asm volatile("" : "+v"(gc0[j].lo), "+v"(gc0[j].hi), "+v"(gc1[j].lo), "+v"(gc1[j].hi));
               }
-              a_first = nxt;
-              take_delivery(a_first);
             }
           }, t_acc);
         }
         // the items between this one and the wave's next one (the other waves')
         for (uint32_t k = item_in_group(wave, i); k < item_in_group(wave, i + 1u) && k < kTileItemsPerGroup; ++k) base += s_tot[cb][k];
         it = nit;
-        cur = nxt;
       }
       VPCC_STAMP(5)
     } else if (have_next) {
-      // first step of the workgroup: nothing to emit yet; fetch the attributes of the first item just counted
-      CFrame& f = *fn;
-      const uint32_t next_item = g_next * kTileItemsPerGroup + item_in_group(wave, 0);
-      const Item nit = load_item(f.tiles + (next_item < f.n_tiles ? next_item : 0u));
-      a_first.occ = occ_next & 0xFu;
-      a_first.g0 = gn0[0]; a_first.g1 = gn1[0];
-      if (!(variant & 256u)) load_attributes(f, nit, lane, a_first);
-      take_delivery(a_first);                                // once per workgroup: keeps the item loop free of waits on `cur`
+      // first step of the workgroup: nothing to emit yet
 #pragma unroll
       for (int j = 0; j < 4; ++j) { gc0[j] = gn0[j]; gc1[j] = gn1[j]; }
       asm volatile("" : "+v"(early));                        // (never read on this path, but pending in the compiler's books)
       asm volatile("" : "+v"(t_ahead));
+    }
+    // ---- 5. the attribute tiles of the wave's last item of the group just counted (the tiles of its first three were
+    // requested in the item loop as their predecessors' became free): every wave stages and reads its own tiles, and
+    // the data has a count phase's two round trips and three items to arrive.
+    if (have_next && !(variant & 256u)) {
+      __builtin_amdgcn_s_setprio(1);
+      stage_attributes(*fn, g_next, wave, lane, occ_next, attr_lds, have_cur ? 0x8u : 0xFu);   // (a workgroup's first step: all four)
+      __builtin_amdgcn_s_setprio(0);
     }
     if (!have_next) break;
 #ifdef VPCC_DIAGNOSTIC
