@@ -350,6 +350,15 @@ int vpcc_decoder_open_v3c(const char* bin_path, const char* occupancy_yuv, const
                           const char* attribute_yuv, uint32_t occupancy_precision, const int* devices,
                           int n_devices, vpcc_decoder** out);
 /* VPCC_ERR_STATE when called twice (the reference panics: "can only be started once"). */
+/* The reference's post-processing switches (Params::apply_geo_smoothing_type / apply_attr_smoothing_type, src/lib.rs:45-46:
+ * private and always false there, with unimplemented!() behind them, src/decoder.rs:291-299).  Between open and start.
+ * Geometry smoothing runs for a GOF when its switch is on AND the GOF carries a geometry-smoothing SEI
+ * (src/decoder.rs:291, 630-637; grid size and threshold are the SEI's) — or, for inputs without syntax (a .vpccgof
+ * container), with `params`' geometry_bitdepth_3d / grid_size / threshold when grid_size >= 2.  Colour smoothing runs
+ * when its switch is on, with `params`' color_* fields (the reference parses no attribute-smoothing SEI).  The filters are
+ * this library's own specification (vpcc_gof_smooth); frames are delivered smoothed.  `params` may be NULL. */
+int  vpcc_decoder_set_smoothing(vpcc_decoder* dec, int apply_geo_smoothing, int apply_attr_smoothing,
+                                const vpcc_smoothing_params* params);
 int  vpcc_decoder_start(vpcc_decoder* dec);
 /* 1 and the next frame (pointers valid until the next call), or 0 at end of stream — also after a
  * failure in the worker, like the reference's consumer sees None after a worker panic. */

@@ -62,6 +62,59 @@ def test_decoder_on_a_v3c_stream_with_raw_decoded_video(tmp_path):
     d.close()
 
 
+def test_decoder_applies_the_smoothing_filters(tmp_path):
+    """The reference's post-processing switches (apply_geo_smoothing_type / apply_attr_smoothing_type, src/lib.rs:45-46):
+    off, the stream is delivered as reconstructed whatever SEI it carries; on, a GOF WITH a geometry-smoothing SEI is
+    filtered with the SEI's grid size and threshold (src/decoder.rs:291-299) and one without is not; colour smoothing
+    follows its own switch.  Expected output: oracle reconstruction + oracle/vpcc_smoothing_spec.c."""
+    import v3c_writer as W
+    gofs = [[cases.overlapping_3d_frame(i) for i in range(2)], [cases.overlapping_3d_frame(2 + i) for i in range(2)],
+            [cases.overlapping_3d_frame(4)]]
+    seis = [(8, 2), None, (4, 1)]
+    paths = W.write_sequence(tmp_path, gofs, seis=seis)
+    kw = dict(occupancy_yuv=paths["occ"], geometry_yuv=paths["geo"], attribute_yuv=paths["attr"])
+    expected = [(f, sei) for g, sei in zip(gofs, seis) for f in g]
+
+    def run(geometry, color):
+        d = recon.Decoder(paths["bin"], **kw)
+        if geometry or color:
+            d.set_smoothing(geometry=geometry, color=color, color_grid_size=8, color_threshold_smoothing=10, color_threshold_difference=100)
+        d.start()
+        frames = list(d)
+        assert d.error() == "" and len(frames) == len(expected)
+        d.close()
+        return frames
+
+    moved = 0
+    for geometry, color in ((False, False), (True, False), (True, True), (False, True)):
+        for got, (f, sei) in zip(run(geometry, color), expected):
+            st, ref = ob.reconstruct(f)
+            xyz, rgb, part = ob.xyz_array(ref), ob.rgb_array(ref), ref["partition"].astype(np.uint16)
+            if geometry and sei:
+                xs = ob.spec_smooth_geometry(xyz, part, 10, sei[0], sei[1])
+                moved += int(np.any(xs != xyz))
+                xyz = xs
+            if color:
+                rgb = ob.spec_smooth_color(xyz, rgb, part, 10, 8, 10, 100)
+            assert got["n"] == ref["n"] and np.array_equal(got["xyz"], xyz) and np.array_equal(got["rgb"], rgb), (geometry, color, sei)
+    assert moved >= 4                                   # the SEI GOFs really were filtered
+
+    # a container has no syntax: geometry smoothing with the parameters given
+    path = tmp_path / "c.vpccgof"
+    container.write_container(path, gofs[:1])
+    d = recon.Decoder(path)
+    d.set_smoothing(geometry=True, grid_size=8, threshold=2)
+    d.start()
+    for got, f in zip(list(d), gofs[0]):
+        st, ref = ob.reconstruct(f)
+        part = ref["partition"].astype(np.uint16)
+        assert np.array_equal(got["xyz"], ob.spec_smooth_geometry(ob.xyz_array(ref), part, 10, 8, 2))
+        assert np.array_equal(got["rgb"], ob.rgb_array(ref))
+    with pytest.raises(recon.VpccError):
+        d.set_smoothing(geometry=False)                 # after start
+    d.close()
+
+
 def test_decoder_v3c_short_video_and_unsupported_stream(tmp_path):
     import v3c_writer as W
     gofs = [[cases.medium_frame(i) for i in range(2)]]

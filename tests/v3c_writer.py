@@ -213,8 +213,9 @@ def pdus_of_frame(frame, bits3=10):
     return out
 
 
-def write_sequence(dirpath, gofs, bits3=10):
-    """gofs: list of lists of frame dicts of one size.  Writes s.bin, occ.yuv, geo.yuv, attr.yuv; returns the paths."""
+def write_sequence(dirpath, gofs, bits3=10, seis=None):
+    """gofs: list of lists of frame dicts of one size.  Writes s.bin, occ.yuv, geo.yuv, attr.yuv; returns the paths.
+    seis: per GOF None or (grid_size, threshold) of a prefix geometry-smoothing SEI."""
     import numpy as np
     import os
     f0 = gofs[0][0]
@@ -223,8 +224,8 @@ def write_sequence(dirpath, gofs, bits3=10):
              map_count_minus1=f0["map_count"] - 1, attribute_count=1 if f0["attribute_count"] else 0,
              use_eight_orientations=1 if any(int(q["orientation"]) > 1 for g in gofs for f in g for q in f["patches"]) else 0)
     units = []
-    for g in gofs:
-        units += gof_units(p, [pdus_of_frame(f, bits3) for f in g])
+    for k, g in enumerate(gofs):
+        units += gof_units(p, [pdus_of_frame(f, bits3) for f in g], sei=seis[k] if seis else None)
     paths = {k: os.path.join(str(dirpath), n) for k, n in (("bin", "s.bin"), ("occ", "occ.yuv"), ("geo", "geo.yuv"), ("attr", "attr.yuv"))}
     with open(paths["bin"], "wb") as o:
         o.write(sample_stream(units))

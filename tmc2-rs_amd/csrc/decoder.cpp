@@ -242,6 +242,35 @@ void Decoder::worker() {
   struct InFlight {
     std::vector<const vpcc_frame_desc*> frames;       // the unit's frames in presentation order
     std::vector<Part> part;
+    vpcc_smoothing_params smooth{};                   // flags != 0: the unit's frames are smoothed behind their reconstruction
+  };
+  // What the post-processing switches make of a GOF (src/decoder.rs:291-299): geometry smoothing needs the switch AND the
+  // SEI (or, for inputs without syntax, the parameters given in Params); colour smoothing its switch and an attribute.
+  auto smoothing_of = [&](const DecodedGof& g) {
+    vpcc_smoothing_params sp{};
+    const bool has_attr = !g.frames.empty() && g.frames[0].attribute_count > 0;
+    if (params_.apply_geo_smoothing_type) {
+      const vpcc_smoothing_params& src = g.sei_smoothing.flags ? g.sei_smoothing : params_.geo_smoothing_without_sei;
+      if (src.grid_size >= 2) {
+        sp.flags |= VPCC_SMOOTH_GEOMETRY;
+        sp.geometry_bitdepth_3d = src.geometry_bitdepth_3d;
+        sp.grid_size = src.grid_size;
+        sp.threshold = src.threshold;
+      }
+    }
+    if (params_.apply_attr_smoothing_type && has_attr && params_.attr_smoothing.color_grid_size >= 2) {
+      sp.flags |= VPCC_SMOOTH_COLOR;
+      if (!sp.geometry_bitdepth_3d)
+        sp.geometry_bitdepth_3d = params_.attr_smoothing.geometry_bitdepth_3d ? params_.attr_smoothing.geometry_bitdepth_3d
+                                : g.sei_smoothing.geometry_bitdepth_3d ? g.sei_smoothing.geometry_bitdepth_3d : 10u;
+      sp.color_grid_size = params_.attr_smoothing.color_grid_size;
+      sp.color_threshold_smoothing = params_.attr_smoothing.color_threshold_smoothing;
+      sp.color_threshold_difference = params_.attr_smoothing.color_threshold_difference;
+    }
+    return sp;
+  };
+  auto same_smoothing = [](const vpcc_smoothing_params& a, const vpcc_smoothing_params& b) {
+    return std::memcmp(&a, &b, sizeof a) == 0;
   };
   auto now = [] { return std::chrono::steady_clock::now(); };
   auto secs = [](std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point b) {
@@ -255,11 +284,13 @@ void Decoder::worker() {
     for (size_t d = 0; d < G; ++d) {
       Part* p = &f->part[d];
       if (p->frames.empty()) continue;
-      p->launched = lanes[d]->post([p, pinned, now, secs](vpcc_ctx* c) {
+      const vpcc_smoothing_params sp = f->smooth;
+      p->launched = lanes[d]->post([p, pinned, now, secs, sp](vpcc_ctx* c) {
         const auto t0 = now();
         int st = vpcc_gof_create(c, p->frames.data(), (uint32_t)p->frames.size(), VPCC_MEM_HOST, 0,
-                                 (pinned ? VPCC_GOF_ASYNC_UPLOAD : 0u) | VPCC_GOF_PROFILE, &p->g);
+                                 (pinned ? VPCC_GOF_ASYNC_UPLOAD : 0u) | VPCC_GOF_PROFILE | (sp.flags ? VPCC_GOF_WANT_PATCH_INDEX : 0u), &p->g);
         if (st == VPCC_OK) st = vpcc_gof_reconstruct(p->g, 0, (uint32_t)p->frames.size(), nullptr);   // ONE launch, asynchronous
+        if (st == VPCC_OK && sp.flags) st = vpcc_gof_smooth(p->g, 0, (uint32_t)p->frames.size(), &sp, nullptr);   // src/decoder.rs:291-299
         if (st) p->err = std::string(vpcc_status_string(st)) + ": " + vpcc_last_error(c);
         p->launch_seconds = secs(t0, now());
         return st;
@@ -306,6 +337,7 @@ void Decoder::worker() {
     };
     bytes = gof_bytes(gofs_[k]);
     while (k != 0 && end < gofs_.size() && end - k < kGofsPerLaunch) {
+      if (!same_smoothing(smoothing_of(gofs_[k]), smoothing_of(gofs_[end]))) break;    // one set of filter parameters per launch
       const uint64_t more = gof_bytes(gofs_[end]);
       if ((bytes + more) / G > (uint64_t(16) << 30)) break;
       bytes += more;
@@ -331,6 +363,7 @@ void Decoder::worker() {
   auto launch_upto = [&](size_t last) {
     while (launched < units.size() && launched <= last) {
       inflight.emplace_back();
+      inflight.back().smooth = smoothing_of(gofs_[units[launched].first]);
       for (size_t q = units[launched].first; q < units[launched].second; ++q)
         for (const vpcc_frame_desc& fr : gofs_[q].frames) inflight.back().frames.push_back(&fr);
       launch(&inflight.back());
@@ -505,11 +538,17 @@ bool PlyWriter::write(const std::string& path) const {
 
 // ------------------------------------------------------------------ C ABI of the host mirror
 struct vpcc_decoder {
-  tmc2rs::Decoder dec;
+  tmc2rs::Params params;                    // may still change between open and start (vpcc_decoder_set_smoothing)
+  std::unique_ptr<tmc2rs::Decoder> made;    // Decoder::new happens at vpcc_decoder_start
+  bool started = false;
   std::optional<tmc2rs::PointSet3> cur;
   std::string err;
   double first_frame_seconds = 0;           // vpcc_decoder_drain: start-up latency (contexts, page-locking, first GOF)
-  explicit vpcc_decoder(tmc2rs::Params p) : dec(std::move(p)) {}
+  explicit vpcc_decoder(tmc2rs::Params p) : params(std::move(p)) {}
+  tmc2rs::Decoder& dec_ref() {
+    if (!made) made = std::make_unique<tmc2rs::Decoder>(params);
+    return *made;
+  }
 };
 
 extern "C" int vpcc_decoder_open(const char* path, const int* devices, int n_devices, vpcc_decoder** out) {
@@ -534,10 +573,24 @@ extern "C" int vpcc_decoder_open_v3c(const char* bin_path, const char* occupancy
   return VPCC_OK;
 }
 
+extern "C" int vpcc_decoder_set_smoothing(vpcc_decoder* d, int apply_geo_smoothing, int apply_attr_smoothing,
+                                          const vpcc_smoothing_params* params) {
+  if (!d) return VPCC_ERR_INVALID_ARG;
+  if (d->started) { d->err = "vpcc_decoder_set_smoothing after vpcc_decoder_start"; return VPCC_ERR_STATE; }
+  d->params.apply_geo_smoothing_type = apply_geo_smoothing != 0;
+  d->params.apply_attr_smoothing_type = apply_attr_smoothing != 0;
+  if (params) {
+    d->params.attr_smoothing = *params;
+    d->params.geo_smoothing_without_sei = *params;
+  }
+  return VPCC_OK;
+}
+
 extern "C" int vpcc_decoder_start(vpcc_decoder* d) {
   if (!d) return VPCC_ERR_INVALID_ARG;
   try {
-    d->dec.start();
+    d->started = true;
+    d->dec_ref().start();
   } catch (const std::logic_error& e) {
     d->err = e.what();
     return VPCC_ERR_STATE;
@@ -551,7 +604,7 @@ extern "C" int vpcc_decoder_start(vpcc_decoder* d) {
 extern "C" int vpcc_decoder_recv_frame(vpcc_decoder* d, size_t* n_points, const vpcc_point3** xyz,
                                        const vpcc_color3** rgb) {
   if (!d || !n_points) return 0;
-  d->cur = d->dec.recv_frame();
+  d->cur = d->dec_ref().recv_frame();
   if (!d->cur) return 0;                      // None: end of stream (or the worker failed: vpcc_decoder_error)
   *n_points = d->cur->len();
   if (xyz) *xyz = d->cur->positions.data();
@@ -561,14 +614,14 @@ extern "C" int vpcc_decoder_recv_frame(vpcc_decoder* d, size_t* n_points, const 
 
 extern "C" const char* vpcc_decoder_error(vpcc_decoder* d) {
   if (!d) return "";
-  return d->dec.last_error().empty() ? d->err.c_str() : d->dec.last_error().c_str();   // the worker's error wins
+  return d->dec_ref().last_error().empty() ? d->err.c_str() : d->dec_ref().last_error().c_str();   // the worker's error wins
 }
 
 extern "C" int vpcc_decoder_drain(vpcc_decoder* d, uint64_t* frames, uint64_t* points, double* seconds) {
   if (!d) return VPCC_ERR_INVALID_ARG;
   const auto t0 = std::chrono::steady_clock::now();
   uint64_t nf = 0, np = 0;
-  while (auto fr = d->dec.recv_frame()) {
+  while (auto fr = d->dec_ref().recv_frame()) {
     if (nf == 0) d->first_frame_seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
     ++nf;
     np += fr->len();
@@ -577,14 +630,14 @@ extern "C" int vpcc_decoder_drain(vpcc_decoder* d, uint64_t* frames, uint64_t* p
   if (frames) *frames = nf;
   if (points) *points = np;
   if (seconds) *seconds = s;
-  return d->dec.last_error().empty() ? VPCC_OK : VPCC_ERR_DEVICE;
+  return d->dec_ref().last_error().empty() ? VPCC_OK : VPCC_ERR_DEVICE;
 }
 
 extern "C" double vpcc_decoder_first_frame_seconds(const vpcc_decoder* d) { return d ? d->first_frame_seconds : 0.0; }
 
 extern "C" int vpcc_decoder_stats(const vpcc_decoder* d, vpcc_decoder_stats_t* out) {
   if (!d || !out) return VPCC_ERR_INVALID_ARG;
-  *out = d->dec.stats();
+  *out = d->made ? d->made->stats() : vpcc_decoder_stats_t{};
   return VPCC_OK;
 }
 

@@ -37,6 +37,18 @@ struct Params {                       // src/lib.rs:23-57
   std::string occupancy_yuv_path, geometry_yuv_path, attribute_yuv_path;
   uint32_t occupancy_precision = 4;   // frame_width / occupancy video width (the reference derives it from
                                       // the decoded video, src/decoder.rs:194; a raw file carries no size)
+  // Post-processing switches of the reference's Params (src/lib.rs:45-46: private and always false there, and
+  // `unimplemented!()` behind them, src/decoder.rs:291-299).  Geometry smoothing runs when the switch is on AND the GOF
+  // carries a geometry-smoothing SEI (src/decoder.rs:291, 630-637): grid size and threshold are the SEI's.  The
+  // reference parses no attribute-smoothing SEI (src/bitstream/reader.rs:1370-1505 reads the geometry one only), so the
+  // colour filter takes its grid size and thresholds from `attr_smoothing` (ColorSmoothingParams, src/codec.rs:180-186)
+  // whenever its switch is on.  Both filters are this library's own specification (oracle/vpcc_smoothing_spec.h).
+  bool apply_geo_smoothing_type = false;
+  bool apply_attr_smoothing_type = false;
+  vpcc_smoothing_params attr_smoothing{};   // color_grid_size, color_threshold_smoothing, color_threshold_difference
+  // Inputs that carry no SEI (a .vpccgof container): geometry smoothing with these parameters when the switch is on
+  // and grid_size >= 2 (geometry_bitdepth_3d, grid_size, threshold).
+  vpcc_smoothing_params geo_smoothing_without_sei{};
   explicit Params(std::string path = {}) : compressed_stream_path(std::move(path)) {}
 };
 
@@ -145,6 +157,8 @@ class BoundedChannel {
 // One decoded GOF: frame descriptors pointing into the container buffer.
 struct DecodedGof {
   std::vector<vpcc_frame_desc> frames;
+  // the GOF's geometry-smoothing SEI (V3C input; flags == 0: none): geometry_bitdepth_3d, grid_size, threshold
+  vpcc_smoothing_params sei_smoothing{};
   std::vector<std::vector<vpcc_patch>> patch_store;   // V3C input: patch tables built by the syntax parser
 };
 

@@ -228,6 +228,7 @@ def load_library():
     lib.vpcc_gof_frame_status.argtypes = [vp, u32]
     lib.vpcc_gof_kernel_times.argtypes = [vp, C.POINTER(C.c_char_p), C.POINTER(C.c_float), C.c_int]
     lib.vpcc_gof_profile_interval.argtypes = [vp, u32]
+    lib.vpcc_decoder_set_smoothing.argtypes = [vp, C.c_int, C.c_int, C.POINTER(SmoothingParams)]
     lib.vpcc_ctx_reserve.argtypes = [vp, C.c_uint64, C.POINTER(PoolInfo)]
     lib.vpcc_ctx_pool_info.argtypes = [vp, C.POINTER(PoolInfo)]
     lib.vpcc_gof_kernel_time_means.argtypes = [vp, u32, C.POINTER(C.c_char_p), C.POINTER(C.c_float),

@@ -251,6 +251,19 @@ class Decoder:
         if st:
             raise VpccError(st, "vpcc_decoder_open")
 
+    def set_smoothing(self, geometry=False, color=False, bitdepth=10, grid_size=0, threshold=0, color_grid_size=0,
+                      color_threshold_smoothing=0, color_threshold_difference=0):
+        """vpcc_decoder_set_smoothing: the reference's apply_geo_smoothing_type / apply_attr_smoothing_type switches;
+        grid_size / threshold are used for inputs without a geometry-smoothing SEI only."""
+        p = _abi.SmoothingParams()
+        p.geometry_bitdepth_3d = bitdepth
+        p.grid_size, p.threshold = grid_size, threshold
+        p.color_grid_size = color_grid_size
+        p.color_threshold_smoothing, p.color_threshold_difference = color_threshold_smoothing, color_threshold_difference
+        st = self.lib.vpcc_decoder_set_smoothing(self.h, int(geometry), int(color), C.byref(p))
+        if st:
+            raise VpccError(st, "vpcc_decoder_set_smoothing", self.error())
+
     def start(self):
         st = self.lib.vpcc_decoder_start(self.h)
         if st:
