@@ -166,7 +166,10 @@ int  vpcc_ctx_bind_thread(vpcc_ctx* ctx, int* node_out);
  * then plain allocations.  When the allocation turns out to lie in one kind only (on some GPUs the first 60 GB of VRAM
  * are alike), a second one of half its size is looked for further away — behind 16-GiB spacers that are freed again,
  * up to four times, while a third of the device's memory stays free — and kept as the other home: the pool then holds
- * 1.5 x `bytes`.  30-50 ms for 32 GiB.  Call it once, before the context's first gof.  VPCC_ERR_STATE: the context has
+ * 1.5 x `bytes`.  30-50 ms for 32 GiB.  The pool of a destroyed context stays with the process and is taken over,
+ * classification included, by the next context that reserves one on the device (memory given back to the driver is
+ * wiped before it is handed out again, and every allocation of the process waits for that).  Call it once, before or
+ * beside the context's first gofs (it may run on a thread of its own; gofs created meanwhile allocate as without it).  VPCC_ERR_STATE: the context has
  * a pool; VPCC_ERR_DEVICE: no memory for it (the context works as before). */
 typedef struct vpcc_pool_info {
   uint64_t bytes;              /* size of the pool (0: none)                                                    */
@@ -179,6 +182,8 @@ typedef struct vpcc_pool_info {
   float    ms_spent;           /* allocation + classification, wall clock                                       */
   uint32_t other_home;         /* blocks that had to go to the other home                                       */
   uint32_t fallbacks;          /* blocks that did not fit the pool at all (allocations of their own)            */
+  uint32_t reused;             /* 1: the pool of an earlier context of this process, taken over as it was       */
+  uint32_t reserved0;
 } vpcc_pool_info;
 int  vpcc_ctx_reserve(vpcc_ctx* ctx, uint64_t bytes, vpcc_pool_info* out /* may be NULL */);
 int  vpcc_ctx_pool_info(vpcc_ctx* ctx, vpcc_pool_info* out);

@@ -216,9 +216,10 @@ def test_pool_homes_hold_the_blocks_not_the_results():
     without a pool and of the oracle; blocks return to the pool when their gof goes; a gof that does not fit falls back."""
     c = recon.Context(0)
     info = c.reserve(36)                                          # a context of its own: the pool lives as long as it does
-    assert info["GiB"] in (36, 54) and info["granules"] == info["GiB"] and info["kinds"] in (1, 2), info   # (54: the second home lay further away)
+    # (36 GiB; 54 when the second home lay further away; more when an earlier context of this process left its pool behind)
+    assert info["GiB"] >= 36 and info["granules"] == info["GiB"] and info["kinds"] in (1, 2), info
     assert sum(info["GiB_of_kind"]) == info["GiB"] and info["in_use_MB"] == [0, 0]
-    assert info["probe_GBps_same_kind"] > 500, info
+    assert info["probe_GBps_same_kind"] > 500 or info["taken_over_from_an_earlier_context"], info
     distinct = [synth.longdress_frame(i) for i in range(5)]
     refs5 = [ob.reconstruct(f)[1] for f in distinct]
     n = 20                                                        # frames 0-7 and 16-19: part 0, frames 8-15: part 1
@@ -251,9 +252,9 @@ def test_pool_homes_hold_the_blocks_not_the_results():
 
 def test_pool_too_small_falls_back():
     c = recon.Context(0)
-    c.reserve(2)
-    frames = [synth.longdress_frame(i % 3) for i in range(128)]     # 2.3 GB of planes + 3.6 GB of outputs: more than the pool
-    g = c.gof(frames, capacity=3_000_000)                           # holds even with a second slab (2 + 2 GiB)
+    gib = c.reserve(2)["GiB"]                                       # (2; up to 6 with a second slab or a pool taken over)
+    frames = [synth.longdress_frame(i % 3) for i in range(128)]     # 2.3 GB of planes + more output capacity than the pool holds
+    g = c.gof(frames, capacity=int(gib * 2**30 / (128 * 9)) + 1_000_000)
     assert c.pool_info()["blocks_outside_pool"] >= 1
     g.reconstruct()
     for i in (0, 64, 127):

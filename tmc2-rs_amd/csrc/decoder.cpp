@@ -192,11 +192,11 @@ void Decoder::worker() {
   for (size_t d = 0; d < G; ++d)
     if (lanes[d]->post([](vpcc_ctx* c) { return c ? 0 : 1; }).get()) { fail("vpcc_ctx_create failed: no usable gfx950 device (no CPU fallback)"); return; }
   step("contexts ready");
-  // Two homes (vpcc_ctx_reserve): every lane's context gets its pool — on a thread of its own beside the lane, so that
-  // neither the first frame nor the uploads wait for the allocation and its classification (30-50 ms; more when the
-  // driver is still wiping memory an earlier process gave back).  Gofs created before it is ready allocate as before;
-  // all later ones keep their planes and outputs in it, spread over both kinds of VRAM regions.  Streams of a single
-  // unit do not bother; VPCC_DECODER_POOL_GIB=0 switches it off.
+  // Two homes (vpcc_ctx_reserve): every lane's context gets its pool — on a thread of its own while this thread
+  // page-locks the input (50-130 ms of host work; the allocation and its classification take 30-50 ms of an otherwise
+  // idle GPU: timed beside uploads and kernels the classification goes wrong), joined before the first unit is launched.
+  // Every gof then keeps its planes and outputs in it, spread over both kinds of VRAM regions.  Streams of a single
+  // GOF do not bother; VPCC_DECODER_POOL_GIB=0 switches it off.
   struct Reservers {
     std::vector<std::thread> t;
     ~Reservers() { for (auto& x : t) if (x.joinable()) x.join(); }      // before the lanes (and their contexts) go
@@ -227,6 +227,8 @@ void Decoder::worker() {
   if (!file_.empty())
     pinned = lanes[0]->post([&](vpcc_ctx* c) { return vpcc_host_pin(c, file_.data(), file_.size()); }).get() == VPCC_OK;
   step("input page-locked");
+  for (auto& x : reservers.t) if (x.joinable()) x.join();
+  step("pools reserved");
   struct Unpin {
     Lane* l; const void* p; bool on;
     ~Unpin() { if (on) l->post([this](vpcc_ctx* c) { return vpcc_host_unpin(c, p); }).get(); }

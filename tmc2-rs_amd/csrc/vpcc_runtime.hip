@@ -162,6 +162,8 @@ extern "C" const char* vpcc_status_string(int status) {
   }
 }
 
+namespace { void retire_pool(vpcc_ctx* ctx); }
+
 extern "C" int vpcc_ctx_create(int device_id, vpcc_ctx** out) {
   if (!out) return VPCC_ERR_INVALID_ARG;
   *out = nullptr;
@@ -188,7 +190,7 @@ extern "C" void vpcc_ctx_destroy(vpcc_ctx* ctx) {
   if (!ctx) return;
   (void)hipSetDevice(ctx->device);
   for (auto& a : ctx->arena_cache) (void)hipFree(a.first);
-  for (void* q : ctx->pool.slabs) (void)hipFree(q);
+  retire_pool(ctx);
   for (auto& b : ctx->block_cache) (void)hipFree(b.ptr);
   if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
   if (ctx->copy_stream) (void)hipStreamDestroy(ctx->copy_stream);
@@ -283,6 +285,26 @@ extern "C" uint64_t vpcc_frame_capacity_bound(const vpcc_frame_desc* frame) {
 // ------------------------------------------------------------ pool ("two homes")
 namespace {
 
+// Pools of destroyed contexts stay with the process, by device: memory given back to the driver is wiped before it is
+// handed out again (about 40 GB/s), and every allocation of the process waits for that — a second Decoder opened right
+// behind the first would spend seconds in hipMalloc.  The next vpcc_ctx_reserve on the device takes a kept pool over as
+// it is, classification included.
+std::mutex g_kept_pools_mutex;
+std::vector<std::pair<int, vpcc_ctx::Pool>> g_kept_pools;      // (device, pool); never freed: the process's memory
+
+void retire_pool(vpcc_ctx* ctx) {
+  std::lock_guard<std::mutex> lock(ctx->pool_mutex);
+  vpcc_ctx::Pool& P = ctx->pool;
+  if (!P.reserved()) return;
+  if (P.info.in_use[0] == 0 && P.info.in_use[1] == 0) {          // every gof of the context is gone: the pool is whole
+    std::lock_guard<std::mutex> keep(g_kept_pools_mutex);
+    g_kept_pools.emplace_back(ctx->device, std::move(P));
+  } else {
+    for (void* q : P.slabs) (void)hipFree(q);
+  }
+  P = vpcc_ctx::Pool{};
+}
+
 // Blocks of destroyed gofs that did not come from the pool are kept for the next gof of the same size: hipMalloc /
 // hipFree cost milliseconds and hipFree synchronises the whole device, which would stall a GOF pipeline.
 constexpr size_t kBlockCacheEntries = 8;
@@ -375,6 +397,24 @@ extern "C" int vpcc_ctx_reserve(vpcc_ctx* ctx, uint64_t bytes, vpcc_pool_info* o
   if (hipSetDevice(ctx->device) != hipSuccess) return VPCC_ERR_DEVICE;
   const auto t0 = std::chrono::steady_clock::now();
   const bool trace = getenv("VPCC_RUNTIME_TRACE") != nullptr;
+  {
+    // a pool an earlier context of this process left behind on the device, if it is big enough (and not twice as big)
+    std::lock_guard<std::mutex> keep(g_kept_pools_mutex);
+    for (size_t k = 0; k < g_kept_pools.size(); ++k) {
+      vpcc_ctx::Pool& K = g_kept_pools[k].second;
+      if (g_kept_pools[k].first != ctx->device || K.info.bytes < n * G || K.info.bytes > 3 * n * G) continue;
+      K.info.ms_spent = 0.f;
+      K.info.reused = 1;
+      K.info.other_home = K.info.fallbacks = 0;
+      if (out) *out = K.info;
+      if (trace) fprintf(stderr, "[vpcc] pool: took over the %llu-GiB pool an earlier context left on device %d\n",
+                         (unsigned long long)(K.info.bytes >> 30), ctx->device);
+      std::lock_guard<std::mutex> lock(ctx->pool_mutex);
+      ctx->pool = std::move(K);
+      g_kept_pools.erase(g_kept_pools.begin() + k);
+      return VPCC_OK;
+    }
+  }
   vpcc_ctx::Pool P;
   void* base = nullptr;
   if (hipMalloc(&base, n * G) != hipSuccess) {
@@ -403,6 +443,14 @@ extern "C" int vpcc_ctx_reserve(vpcc_ctx* ctx, uint64_t bytes, vpcc_pool_info* o
   };
   std::vector<float> rate(n, 0.f);
   for (size_t j = 1; j < n; ++j) rate[j] = probe(ref + j * G);
+  {
+    // a rate well away from both levels (somebody else used the GPU during that probe): measured again, the faster counts
+    float lo0 = rate[1], hi0 = rate[1];
+    for (size_t j = 1; j < n; ++j) { lo0 = std::min(lo0, rate[j]); hi0 = std::max(hi0, rate[j]); }
+    for (size_t j = 1; j < n && hi0 > 1.15f * lo0; ++j)
+      if (rate[j] > 1.06f * lo0 && rate[j] < 0.94f * hi0)
+        for (int again = 0; again < 2; ++again) rate[j] = std::max(rate[j], probe(ref + j * G));
+  }
   std::vector<float> sorted(rate.begin() + 1, rate.end());
   std::sort(sorted.begin(), sorted.end());
   const float lo = sorted.front(), hi = sorted.back(), med = sorted[sorted.size() / 2];

@@ -167,7 +167,7 @@ class PoolInfo(C.Structure):              # vpcc_pool_info
     _fields_ = [("bytes", C.c_uint64), ("granules", C.c_uint32), ("kinds", C.c_uint32),
                 ("bytes_of_kind", C.c_uint64 * 2), ("in_use", C.c_uint64 * 2),
                 ("probe_gbps_same", C.c_float), ("probe_gbps_other", C.c_float), ("ms_spent", C.c_float),
-                ("other_home", C.c_uint32), ("fallbacks", C.c_uint32)]
+                ("other_home", C.c_uint32), ("fallbacks", C.c_uint32), ("reused", C.c_uint32), ("reserved0", C.c_uint32)]
 
 
 class DecoderStats(C.Structure):          # vpcc_decoder_stats_t

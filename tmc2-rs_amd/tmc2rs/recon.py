@@ -64,7 +64,8 @@ class Context:
                 "GiB_of_kind": [int(p.bytes_of_kind[0] >> 30), int(p.bytes_of_kind[1] >> 30)],
                 "in_use_MB": [int(p.in_use[0] >> 20), int(p.in_use[1] >> 20)],
                 "probe_GBps_same_kind": round(p.probe_gbps_same, 0), "probe_GBps_two_kinds": round(p.probe_gbps_other, 0),
-                "ms_spent": round(p.ms_spent, 1), "blocks_in_other_home": int(p.other_home), "blocks_outside_pool": int(p.fallbacks)}
+                "ms_spent": round(p.ms_spent, 1), "blocks_in_other_home": int(p.other_home), "blocks_outside_pool": int(p.fallbacks),
+                "taken_over_from_an_earlier_context": bool(p.reused)}
 
     def reserve(self, gib):
         """vpcc_ctx_reserve: one allocation of `gib` GiB, classified by kind of VRAM region; every later gof of this
