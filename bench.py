@@ -449,44 +449,6 @@ def main():
             roofline["smoothing_algorithmic_bytes_per_launch"] = smooth_bytes
             roofline["reconstruction_algorithmic_bytes_per_launch"] = alg_bytes
 
-    # ---- end to end: host buffers in, host buffers out (C++ Decoder) -----------------------------
-    e2e = None
-    if rank == 0 and world == 1 and not args.no_end_to_end and not args.smooth and not args.general:
-        import tempfile
-        from tmc2rs import container
-        d = tempfile.mkdtemp(dir="/dev/shm" if os.path.isdir("/dev/shm") else None)
-        path = os.path.join(d, "bench_e2e.vpccgof")
-        try:
-            container.write_container(path, [frames] * args.e2e_gofs)
-            size = os.path.getsize(path)
-            dec = recon.Decoder(path, devices=(local_rank,))
-            dec.start()
-            nf, npts, sec = dec.drain()
-            t_first = dec.first_frame_seconds()
-            dstats = dec.stats()
-            dec.close()
-            points_per_gof = int(counts[:args.frames].sum())
-            assert nf == args.frames * args.e2e_gofs and npts == points_per_gof * args.e2e_gofs, "Decoder output differs"
-            # Two bounds of the steady rate: the whole run includes the start-up (contexts, page-locking, first GOF);
-            # the rate after the first frame profits from the uploads of the next units that were already running
-            # during the start-up (two units of look-ahead).
-            after = (sec - t_first) / max(nf - 1, 1)
-            e2e = {"whole_run_frames_per_s": round(nf / sec, 1), "after_first_frame_frames_per_s": round(1.0 / after, 1),
-                   "whole_run_Mpoints_per_s": round(npts / sec / 1e6, 1),
-                   "h2d_GBps_whole_run": round(size / sec / 1e9, 2), "d2h_GBps_whole_run": round(npts * 9 / sec / 1e9, 2),
-                   "startup_s": round(t_first, 3),
-                   # the product's own launches: GOF 0 alone, then every resident run of up to four GOFs in ONE launch
-                   "launches": dstats["launches"], "max_frames_per_launch": dstats["max_frames_per_launch"],
-                   "kernel_seconds": round(dstats["kernel_seconds"], 6),
-                   "kernels_share_of_wall": round(dstats["kernel_seconds"] / sec, 4),
-                   "lane_numa_nodes": dstats["numa_node"],
-                   "sample": f"{args.e2e_gofs} GOFs x {args.frames} frames through tmc2rs::Decoder (pinned container -> "
-                             f"H2D -> kernels -> D2H -> consumer)"}
-        finally:
-            if os.path.exists(path):
-                os.remove(path)
-            os.rmdir(d)
-
     # ---- BASELINE configs 5 and 4 beside the headline (N=1, rank 0): short legs with their own verification -----
     def spec_check(g_, fr_list, entries):
         """Smoothed output of batch entries against oracle reconstruction + oracle/vpcc_smoothing_spec.c (checker only)."""
@@ -576,6 +538,54 @@ def main():
         if not (other["owlii"]["equals_oracle"] and other["smooth"]["equals_spec"]):
             print(f"bench.py: other_configs failed verification: {other}", file=sys.stderr)
             sys.exit(3)
+
+    # ---- end to end: host buffers in, host buffers out (C++ Decoder) -----------------------------
+    # The Decoder's lanes make contexts of their own, with the same pool policy: this process's context goes first, and
+    # the lane takes its pool over as it is (vpcc_ctx_reserve keeps retired pools with the process).
+    for g_ in gofs:
+        g_.close()
+    gofs = []
+    ctx.close()
+    e2e = None
+    if rank == 0 and world == 1 and not args.no_end_to_end and not args.smooth and not args.general:
+        import tempfile
+        from tmc2rs import container
+        d = tempfile.mkdtemp(dir="/dev/shm" if os.path.isdir("/dev/shm") else None)
+        path = os.path.join(d, "bench_e2e.vpccgof")
+        try:
+            container.write_container(path, [frames] * args.e2e_gofs)
+            size = os.path.getsize(path)
+            dec = recon.Decoder(path, devices=(local_rank,))
+            dec.start()
+            nf, npts, sec = dec.drain()
+            t_first = dec.first_frame_seconds()
+            dstats = dec.stats()
+            dec.close()
+            points_per_gof = int(counts[:args.frames].sum())
+            assert nf == args.frames * args.e2e_gofs and npts == points_per_gof * args.e2e_gofs, "Decoder output differs"
+            # Two bounds of the steady rate: the whole run includes the start-up (contexts, page-locking, first GOF);
+            # the rate after the first frame profits from the uploads of the next units that were already running
+            # during the start-up (two units of look-ahead).
+            after = (sec - t_first) / max(nf - 1, 1)
+            e2e = {"whole_run_frames_per_s": round(nf / sec, 1), "after_first_frame_frames_per_s": round(1.0 / after, 1),
+                   "whole_run_Mpoints_per_s": round(npts / sec / 1e6, 1),
+                   "h2d_GBps_whole_run": round(size / sec / 1e9, 2), "d2h_GBps_whole_run": round(npts * 9 / sec / 1e9, 2),
+                   "startup_s": round(t_first, 3),
+                   # the product's own launches: GOF 0 alone, then every resident run of up to four GOFs in ONE launch
+                   "launches": dstats["launches"], "max_frames_per_launch": dstats["max_frames_per_launch"],
+                   "kernel_seconds": round(dstats["kernel_seconds"], 6),
+                   "kernels_share_of_wall": round(dstats["kernel_seconds"] / sec, 4),
+                   # host work of a unit on its lane's thread — validation, planning of the work lists (8 helper threads),
+                   # descriptors, the enqueue of ingest and launch — summed over units, per frame: it runs while the
+                   # previous unit's transfers do (two units of look-ahead)
+                   "host_plan_and_enqueue_us_per_frame": round(dstats["launch_seconds"] / max(nf, 1) * 1e6, 1),
+                   "lane_numa_nodes": dstats["numa_node"],
+                   "sample": f"{args.e2e_gofs} GOFs x {args.frames} frames through tmc2rs::Decoder (pinned container -> "
+                             f"H2D -> kernels -> D2H -> consumer)"}
+        finally:
+            if os.path.exists(path):
+                os.remove(path)
+            os.rmdir(d)
 
     # ---- CPU baseline: the oracle (port of the reference algorithm), single thread, rank 0, N=1 ---
     cpu = None

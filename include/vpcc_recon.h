@@ -279,6 +279,16 @@ int vpcc_gof_device_outputs(vpcc_gof* gof, uint32_t frame, void** d_xyz, void** 
 int vpcc_gof_download(vpcc_gof* gof, uint32_t frame, vpcc_point3* xyz_out, vpcc_color3* rgb_out,
                       uint16_t* patch_index_out, size_t capacity, size_t* n_points);
 
+/* The same without the wait: the copies are enqueued on the context's download stream (the first call waits for the
+ * frame's point count), `*n_points` is final on return, and the arrays are complete once vpcc_gof_download_wait(gof,
+ * frame) has returned — which, unlike every other call on a gof, may come from another thread than the one that drives
+ * the context (it touches nothing but the frame's completion event).  Many small synchronous downloads leave the link
+ * idle between them (16 GB/s for 7-MB frames); a window of asynchronous ones keeps the copy engine fed.  Page-locked
+ * destinations (vpcc_host_alloc / vpcc_host_pin), or the copies are not asynchronous. */
+int vpcc_gof_download_async(vpcc_gof* gof, uint32_t frame, vpcc_point3* xyz_out, vpcc_color3* rgb_out,
+                            uint16_t* patch_index_out, size_t capacity, size_t* n_points);
+int vpcc_gof_download_wait(vpcc_gof* gof, uint32_t frame);
+
 /* Per-frame status of the last reconstruct: VPCC_OK or VPCC_ERR_CAPACITY. */
 int vpcc_gof_frame_status(vpcc_gof* gof, uint32_t frame);
 

@@ -422,6 +422,7 @@ void Decoder::worker() {
       for (size_t d = 0; d < G; ++d) stats_.kernel_seconds += cur.part[d].kernel_seconds;
       t_counts += secs(t0, now());
       if (k == 0) step("first unit reconstructed (point counts back)");
+      if (trace_steps && k) { char b[64]; std::snprintf(b, sizeof b, "unit %zu (%zu frames): point counts back", k, n); step(b); }
     }
     // Downloads are posted a window of frames ahead of the hand-over — every lane works through its own
     // frames while earlier ones are delivered in presentation order (src/decoder.rs:188) — but not the whole
@@ -449,22 +450,26 @@ void Decoder::worker() {
           ps->positions.adopt(std::move(bx), np);
           if (ps->with_colors) ps->colors.adopt(std::move(bc), np);
           size_t got = 0;
-          const int st = vpcc_gof_download(p->g, (uint32_t)local, ps->positions.data(), ps->with_colors ? ps->colors.data() : nullptr,
-                                           nullptr, np ? np : 1, &got);
+          // asynchronous: the copies of a window of frames queue up on the download stream; the worker waits for a
+          // frame's completion event itself (vpcc_gof_download_wait below), the lane goes on
+          const int st = vpcc_gof_download_async(p->g, (uint32_t)local, ps->positions.data(), ps->with_colors ? ps->colors.data() : nullptr,
+                                                 nullptr, np ? np : 1, &got);
           if (st || got != np) { *e = st ? vpcc_last_error(c) : "point count changed between calls"; return st ? st : (int)VPCC_ERR_DEVICE; }
           return 0;
         });
       }
     };
     auto settle = [&](size_t from) {                       // downloads in flight write into `sets`
-      for (size_t q = from; q < posted; ++q) done[q].wait();
+      for (size_t q = from; q < posted; ++q)
+        if (done[q].get() == VPCC_OK) (void)vpcc_gof_download_wait(cur.part[q % G].g, (uint32_t)(q / G));
     };
     post_downloads(window);                                // this unit's first frames before the lanes hear of the next units
     launch_upto(k + kAhead);
     for (size_t f = 0; f < n; ++f) {
       post_downloads(f + window);
       const auto t0 = now();
-      const int st = done[f].get();
+      int st = done[f].get();
+      if (!st && vpcc_gof_download_wait(cur.part[f % G].g, (uint32_t)(f / G)) != VPCC_OK) { st = VPCC_ERR_DEVICE; derr[f] = "download failed"; }
       const auto t1 = now();
       t_download += secs(t0, t1);
       bool sent = false;
@@ -472,6 +477,7 @@ void Decoder::worker() {
         sent = chan_.send(std::move(sets[f]));
         t_send += secs(t1, now());
         if (k == 0 && f == 0) step("first frame handed over");
+        if (trace_steps && k && (f == 0 || f + 1 == n)) { char b[64]; std::snprintf(b, sizeof b, "unit %zu: frame %zu handed over", k, f); step(b); }
       }
       if (st || !sent) {                                   // device error, or receiver dropped (src/decoder.rs:311-313)
         settle(f + 1);

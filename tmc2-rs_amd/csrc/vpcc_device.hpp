@@ -188,6 +188,13 @@ void plan_tile_launch(const uint32_t* tiles, uint32_t count, uint32_t resident_p
 void launch_tiles(const DevFrame* d_frames, uint32_t first, uint32_t count, uint32_t max_groups, uint32_t gen,
                   const TileLaunchMap& map, uint32_t resident_per_xcd,
                   void* stream);
+// One piece of the plane ingest by kernel (k_ingest_planes): `bytes` (<= 64 KB) of page-locked host memory, through its
+// device-visible address, to device memory; src and dst are congruent modulo 16.
+struct IngestPiece { const void* src; void* dst; uint32_t bytes, pad; };
+constexpr uint32_t kIngestPieceBytes = 65536;
+void launch_ingest_planes(const IngestPiece* d_pieces, uint32_t n, void* stream);
+// up to three arrays (bytes = low half, pad = high half of the size; 0: unused) from device memory to page-locked host memory
+void launch_push_results(const IngestPiece pieces[3], void* stream);
 // vpcc_ctx_reserve's probe: the tile kernel's output pattern between two arrays (positions: items * 1824 B, colours: items * 912 B)
 void launch_probe_outputs(unsigned char* xyz, unsigned char* rgb, uint32_t items, void* stream);
 void launch_upsample_occupancy(const DevFrame* d_frames, uint32_t frame, uint8_t* d_out, uint32_t width,

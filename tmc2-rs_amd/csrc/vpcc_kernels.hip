@@ -15,6 +15,9 @@
 // (-ffp-contract=off) so that it is bit-identical to the Rust code.
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
+#include <cstdlib>
+
 #include "vpcc_device.hpp"
 #include "vpcc_devfn.hpp"
 
@@ -179,6 +182,74 @@ void launch_emit(const DevFrame* d_frames, uint32_t first, uint32_t count, uint3
   if (!count || !max_vb) return;
   hipLaunchKernelGGL(k_emit, dim3(max_vb, count), dim3(256), 0, (hipStream_t)stream, d_frames, first);
 }
+// Plane ingest by the GPU itself: every workgroup pulls 64-KB pieces of page-locked HOST memory over PCIe (zero-copy
+// reads, 16 B per lane, coalesced) and stores them in HBM.  One launch moves all planes of a gof: 57 GB/s with 64
+// workgroups and more — the rate of ONE big hipMemcpyAsync, where the 1 280 plane-sized copies (0.1-3.6 MB) of a
+// 128-frame unit reach 34 GB/s on the copy engines (tools/micro/zero_copy.hip, profiles/r04/zero_copy.txt).
+// A piece's source and destination are congruent modulo 16 (the runtime places the destination so); up to 15 bytes in
+// front of and behind the aligned body go byte by byte.
+__global__ __launch_bounds__(256) void k_ingest_planes(const IngestPiece* __restrict__ pieces, uint32_t n) {
+  typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+  for (uint32_t c = blockIdx.x; c < n; c += gridDim.x) {
+    const IngestPiece k = pieces[c];
+    const VPCC_GLOBAL unsigned char* src = (const VPCC_GLOBAL unsigned char*)k.src;
+    VPCC_GLOBAL unsigned char* dst = (VPCC_GLOBAL unsigned char*)k.dst;
+    const uint32_t head = min((uint32_t)((16u - ((uintptr_t)k.src & 15u)) & 15u), k.bytes);
+    const uint32_t n16 = (k.bytes - head) >> 4, tail = (k.bytes - head) & 15u;
+    if (threadIdx.x < head) dst[threadIdx.x] = src[threadIdx.x];
+    if (threadIdx.x < tail) dst[head + 16u * n16 + threadIdx.x] = src[head + 16u * n16 + threadIdx.x];
+    const VPCC_GLOBAL u32x4* s16 = (const VPCC_GLOBAL u32x4*)(src + head);
+    VPCC_GLOBAL u32x4* d16 = (VPCC_GLOBAL u32x4*)(dst + head);
+    for (uint32_t i = threadIdx.x; i < n16; i += 1024u) {
+      u32x4 v[4];
+#pragma unroll
+      for (uint32_t q = 0; q < 4; ++q) if (i + 256u * q < n16) v[q] = __builtin_nontemporal_load(s16 + i + 256u * q);
+#pragma unroll
+      for (uint32_t q = 0; q < 4; ++q) if (i + 256u * q < n16) d16[i + 256u * q] = v[q];
+    }
+  }
+}
+// Sixteen workgroups pull at the link's rate already (55 GB/s alone; 8 / 16 / 64 / 256 workgroups in the Decoder: 2 467 /
+// 2 648 / 2 686 / 2 635 frames/s without downloads — profiles/r04/zero_copy.txt, e2e.txt).
+constexpr uint32_t kIngestWorkgroups = 16;
+void launch_ingest_planes(const IngestPiece* d_pieces, uint32_t n, void* stream) {
+  if (!n) return;
+  hipLaunchKernelGGL(k_ingest_planes, dim3(std::min<uint32_t>(n, kIngestWorkgroups)), dim3(256), 0, (hipStream_t)stream, d_pieces, n);
+}
+
+// The other direction: up to three arrays of one frame's result pushed into page-locked host memory by a kernel (the
+// pieces by value: nothing to upload).  Beside the ingest kernel a hipMemcpyAsync device-to-host gets 17 GB/s, this 38.
+struct PushList { IngestPiece p[3]; };
+__global__ __launch_bounds__(256) void k_push_results(const PushList list) {
+  typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+#pragma unroll
+  for (uint32_t a = 0; a < 3; ++a) {
+    const IngestPiece k = list.p[a];
+    if (!k.bytes && !k.pad) continue;
+    const size_t bytes = ((size_t)k.pad << 32) | k.bytes;                     // (an array may exceed 4 GB: pad holds the high half)
+    const VPCC_GLOBAL unsigned char* src = (const VPCC_GLOBAL unsigned char*)k.src;
+    VPCC_GLOBAL unsigned char* dst = (VPCC_GLOBAL unsigned char*)k.dst;
+    // device arrays are 256-byte aligned; the host side decides: aligned body only when dst is 16-byte aligned too
+    const bool wide = (((uintptr_t)k.src | (uintptr_t)k.dst) & 15u) == 0;
+    const size_t n16 = wide ? bytes >> 4 : 0;
+    const VPCC_GLOBAL u32x4* s16 = (const VPCC_GLOBAL u32x4*)src;
+    VPCC_GLOBAL u32x4* d16 = (VPCC_GLOBAL u32x4*)dst;
+    for (size_t i = (size_t)blockIdx.x * 1024u + threadIdx.x; i < n16; i += (size_t)gridDim.x * 1024u) {
+      u32x4 v[4];
+#pragma unroll
+      for (uint32_t q = 0; q < 4; ++q) if (i + 256u * q < n16) v[q] = s16[i + 256u * q];
+#pragma unroll
+      for (uint32_t q = 0; q < 4; ++q) if (i + 256u * q < n16) __builtin_nontemporal_store(v[q], d16 + i + 256u * q);
+    }
+    for (size_t i = 16u * n16 + (size_t)blockIdx.x * 256u + threadIdx.x; i < bytes; i += (size_t)gridDim.x * 256u) dst[i] = src[i];
+  }
+}
+void launch_push_results(const IngestPiece pieces[3], void* stream) {
+  PushList l;
+  for (int a = 0; a < 3; ++a) l.p[a] = pieces[a];
+  hipLaunchKernelGGL(k_push_results, dim3(kIngestWorkgroups), dim3(256), 0, (hipStream_t)stream, l);
+}
+
 // The reconstruction kernel's output pattern, alone: 4 096 waves, each writing runs of 304 points — 1 824 B of positions into
 // `xyz`, 912 B of colours into `rgb` — with the kernel's store instructions (12 B per lane non-temporal, colours from the
 // even lanes, runs of neighbouring waves adjacent).  Its rate tells whether the two arrays lie in one kind of VRAM region

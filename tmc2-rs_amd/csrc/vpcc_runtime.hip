@@ -29,6 +29,9 @@ struct vpcc_ctx {
   int device = 0;
   hipStream_t stream = nullptr;        // kernels and D2H
   hipStream_t copy_stream = nullptr;   // H2D plane ingest: overlaps the kernels of the previous GOF
+  hipStream_t setup_stream = nullptr;  // descriptors and work lists of a new gof (small copies from pageable host memory: the
+                                       // caller's thread waits for each — on the copy stream that was a wait for the 40-ms
+                                       // ingest of the gof before)
   hipStream_t d2h_stream = nullptr;    // result downloads: wait for ONE gof's kernels only (results_ready), not for
                                        // whatever else has been queued behind them on the compute stream
   std::string last_error;
@@ -98,6 +101,8 @@ struct vpcc_gof {
   uint32_t* h_counts = nullptr;        // pinned: counts[n_frames] then errors[n_frames]
   bool counts_valid = false;
   bool launched = false;
+  std::vector<IngestPiece> ingest;     // plane ingest by kernel: the pieces (alive while their upload may read them)
+  std::vector<hipEvent_t> download_done;   // vpcc_gof_download_async: one per frame
   hipEvent_t upload_done = nullptr;
   hipEvent_t results_ready = nullptr;   // recorded behind the last kernel launched on this gof
   hipStream_t last_stream = nullptr;
@@ -178,6 +183,7 @@ extern "C" int vpcc_ctx_create(int device_id, vpcc_ctx** out) {
   ctx->resident_tile_wgs_per_xcd = (uint32_t)std::max(1, prop.multiProcessorCount / 8) * 4u;
   if (hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) != hipSuccess ||
       hipStreamCreateWithFlags(&ctx->copy_stream, hipStreamNonBlocking) != hipSuccess ||
+      hipStreamCreateWithFlags(&ctx->setup_stream, hipStreamNonBlocking) != hipSuccess ||
       hipStreamCreateWithFlags(&ctx->d2h_stream, hipStreamNonBlocking) != hipSuccess) {
     delete ctx;
     return VPCC_ERR_DEVICE;
@@ -194,6 +200,7 @@ extern "C" void vpcc_ctx_destroy(vpcc_ctx* ctx) {
   for (auto& b : ctx->block_cache) (void)hipFree(b.ptr);
   if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
   if (ctx->copy_stream) (void)hipStreamDestroy(ctx->copy_stream);
+  if (ctx->setup_stream) (void)hipStreamDestroy(ctx->setup_stream);
   if (ctx->d2h_stream) (void)hipStreamDestroy(ctx->d2h_stream);
   delete ctx;
 }
@@ -249,7 +256,7 @@ extern "C" int vpcc_host_pin(vpcc_ctx* ctx, const void* ptr, size_t bytes) {
   if (!ctx || !ptr || !bytes) return VPCC_ERR_INVALID_ARG;
   HIP_TRY(ctx, hipSetDevice(ctx->device));
   // Portable: every device (every vpcc_ctx of the process) may DMA from it, not only ctx's
-  HIP_TRY(ctx, hipHostRegister(const_cast<void*>(ptr), bytes, hipHostRegisterPortable));
+  HIP_TRY(ctx, hipHostRegister(const_cast<void*>(ptr), bytes, hipHostRegisterPortable | hipHostRegisterMapped));   // mapped: the ingest kernel reads it in place
   return VPCC_OK;
 }
 
@@ -544,12 +551,14 @@ extern "C" void vpcc_gof_destroy(vpcc_gof* gof) {
   if (gof->last_stream) (void)hipStreamSynchronize(gof->last_stream);
   (void)hipStreamSynchronize(gof->ctx->stream);
   (void)hipStreamSynchronize(gof->ctx->copy_stream);
+  (void)hipStreamSynchronize(gof->ctx->setup_stream);
   (void)hipStreamSynchronize(gof->ctx->d2h_stream);
   for (auto& l : gof->history)
     for (auto& t : l.k) {
       (void)hipEventDestroy(t.start);
       (void)hipEventDestroy(t.stop);
     }
+  for (hipEvent_t e : gof->download_done) if (e) (void)hipEventDestroy(e);
   if (gof->upload_done) (void)hipEventDestroy(gof->upload_done);
   if (gof->results_ready) (void)hipEventDestroy(gof->results_ready);
   if (gof->smooth_grid) (void)hipFree(gof->smooth_grid);
@@ -660,6 +669,7 @@ int gof_create_impl(vpcc_ctx* ctx, const vpcc_frame_desc* frames, uint32_t n_fra
   auto part_of = [&](uint32_t i) { return (int)((i >> 3) % vpcc_ctx::kParts); };
   // kind 0 planes / 1 outputs
   auto takek = [&](uint32_t i, int kind, int, size_t bytes) { return LB[2 * part_of(i) + kind].take(bytes); };
+  size_t ingest_bound = 0;
   for (uint32_t i = 0; i < n_frames; ++i) {
     const vpcc_frame_desc& F = frames[i];
     const FramePlan& P = g->plans[i];
@@ -673,17 +683,23 @@ int gof_create_impl(vpcc_ctx* ctx, const vpcc_frame_desc* frames, uint32_t n_fra
     o.rgb = F.attribute_count ? takek(i, 1, 1, sizeof(vpcc_color3) * cap) : 0;   //  this order — the smoothing kernels' 8-byte loads
     o.pidx = (gof_flags & VPCC_GOF_WANT_PATCH_INDEX) ? takek(i, 1, 0, sizeof(uint16_t) * cap) : 0;   // read a few bytes past an element)
     if (own_planes) {
-      o.occ = takek(i, 0, 0, (size_t)F.occupancy.width * F.occupancy.height);
+      // (+ 16: a plane pulled by the ingest kernel starts 0 or 8 bytes behind its 256-byte boundary — where its source does modulo 16)
+      auto plane = [&](int sub, size_t bytes) { ingest_bound += bytes / kIngestPieceBytes + 1; return takek(i, 0, sub, bytes + 16); };
+      o.occ = plane(0, (size_t)F.occupancy.width * F.occupancy.height);
       for (uint32_t m = 0; m < F.map_count; ++m) {
-        o.geo[m] = takek(i, 0, 0, (size_t)F.geometry[m].width * F.geometry[m].height * 2);
+        o.geo[m] = plane(0, (size_t)F.geometry[m].width * F.geometry[m].height * 2);
         if (F.attribute_count) {
-          o.ay[m] = takek(i, 0, 1, (size_t)F.attribute[m].width * F.attribute[m].height * 2);
-          o.au[m] = takek(i, 0, 1, chroma_elems(F.attribute[m]) * 2);
-          o.av[m] = takek(i, 0, 1, chroma_elems(F.attribute[m]) * 2);
+          o.ay[m] = plane(1, (size_t)F.attribute[m].width * F.attribute[m].height * 2);
+          o.au[m] = plane(1, chroma_elems(F.attribute[m]) * 2);
+          o.av[m] = plane(1, chroma_elems(F.attribute[m]) * 2);
         }
       }
     }
   }
+  // Plane ingest by kernel (k_ingest_planes) for page-locked host planes (VPCC_GOF_ASYNC_UPLOAD says they are; vpcc_host_pin
+  // maps them for the device): one launch instead of ten hipMemcpyAsync per frame.  VPCC_NO_PULL_INGEST=1: the copy engines.
+  const bool pull = kind == VPCC_MEM_HOST && (gof_flags & VPCC_GOF_ASYNC_UPLOAD) && !getenv("VPCC_NO_PULL_INGEST");
+  const size_t off_ingest = pull ? L.take(sizeof(IngestPiece) * ingest_bound) : 0;
   g->arena_bytes = L.total;
   for (size_t k = 0; k < ctx->arena_cache.size(); ++k) {          // smallest cached arena that fits
     auto& a = ctx->arena_cache[k];
@@ -715,7 +731,7 @@ int gof_create_impl(vpcc_ctx* ctx, const vpcc_frame_desc* frames, uint32_t n_fra
 
   const auto t_fill = std::chrono::steady_clock::now();
   // 3. fill descriptors and upload (plane ingest on the copy stream)
-  hipStream_t s = ctx->copy_stream;
+  hipStream_t s = ctx->copy_stream, sd = ctx->setup_stream;
   for (uint32_t i = 0; i < n_frames; ++i) {
     const vpcc_frame_desc& F = frames[i];
     const FramePlan& P = g->plans[i];
@@ -755,30 +771,42 @@ int gof_create_impl(vpcc_ctx* ctx, const vpcc_frame_desc* frames, uint32_t n_fra
         }
       }
     } else {
-      D.occ = (const uint8_t*)(kb(i, 0, 0) + o.occ); D.occ_stride = F.occupancy.width;
-      int st = copy_plane(ctx, kb(i, 0, 0) + o.occ, F.occupancy.y, 1, F.occupancy.width, F.occupancy.height,
-                          F.occupancy.stride, s, dir);
-      if (st) return st;
+      // One plane of the caller's into its place in the gof's planes block; returns where it lies there.  Tight planes in
+      // page-locked memory whose address is a multiple of eight are left to the ingest kernel (the place is moved by
+      // src mod 16, so that 16-byte pieces line up on both sides); everything else goes through the copy engines.
+      int st = VPCC_OK;
+      auto ingest_plane = [&](char* dst, const void* src, size_t elem, uint32_t width, uint32_t height, uint32_t stride) -> const void* {
+        void* dev_src = nullptr;
+        if (pull && stride == width && ((uintptr_t)src & 7u) == 0 &&
+            hipHostGetDevicePointer(&dev_src, const_cast<void*>(src), 0) == hipSuccess && dev_src) {
+          dst += (uintptr_t)src & 15u;
+          const size_t bytes = (size_t)width * height * elem;
+          for (size_t at = 0; at < bytes; at += kIngestPieceBytes)
+            g->ingest.push_back(IngestPiece{(const char*)dev_src + at, dst + at, (uint32_t)std::min<size_t>(kIngestPieceBytes, bytes - at), 0u});
+          return dst;
+        }
+        (void)hipGetLastError();
+        if (!st) st = copy_plane(ctx, dst, src, elem, width, height, stride, s, dir);
+        return dst;
+      };
+      D.occ = (const uint8_t*)ingest_plane(kb(i, 0, 0) + o.occ, F.occupancy.y, 1, F.occupancy.width, F.occupancy.height, F.occupancy.stride);
+      D.occ_stride = F.occupancy.width;
       for (uint32_t m = 0; m < F.map_count; ++m) {
         const vpcc_image_u16& G = F.geometry[m];
-        D.geo[m] = (const uint16_t*)(kb(i, 0, 0) + o.geo[m]); D.geo_stride[m] = G.width;
-        st = copy_plane(ctx, kb(i, 0, 0) + o.geo[m], G.y, 2, G.width, G.height, G.stride, s, dir);
-        if (st) return st;
+        D.geo[m] = (const uint16_t*)ingest_plane(kb(i, 0, 0) + o.geo[m], G.y, 2, G.width, G.height, G.stride);
+        D.geo_stride[m] = G.width;
         if (F.attribute_count) {
           const vpcc_image_u16& A = F.attribute[m];
-          D.attr_y[m] = (const uint16_t*)(kb(i, 0, 1) + o.ay[m]);
-          D.attr_u[m] = (const uint16_t*)(kb(i, 0, 1) + o.au[m]);
-          D.attr_v[m] = (const uint16_t*)(kb(i, 0, 1) + o.av[m]);
-          D.attr_stride[m] = A.width; D.attr_cstride[m] = A.cstride;
-          st = copy_plane(ctx, kb(i, 0, 1) + o.ay[m], A.y, 2, A.width, A.height, A.stride, s, dir);
-          if (st) return st;
+          D.attr_y[m] = (const uint16_t*)ingest_plane(kb(i, 0, 1) + o.ay[m], A.y, 2, A.width, A.height, A.stride);
           // chroma keeps its source stride: the reference indexes it as a flat array
           // (v/2)*(width/2)+(u/2), src/decoder.rs:977, which for odd widths runs across rows
           const size_t ce = chroma_elems(A);
-          HIP_TRY(ctx, hipMemcpyAsync(kb(i, 0, 1) + o.au[m], A.u, ce * 2, dir, s));
-          HIP_TRY(ctx, hipMemcpyAsync(kb(i, 0, 1) + o.av[m], A.v, ce * 2, dir, s));
+          D.attr_u[m] = (const uint16_t*)ingest_plane(kb(i, 0, 1) + o.au[m], A.u, 2, (uint32_t)ce, 1, (uint32_t)ce);
+          D.attr_v[m] = (const uint16_t*)ingest_plane(kb(i, 0, 1) + o.av[m], A.v, 2, (uint32_t)ce, 1, (uint32_t)ce);
+          D.attr_stride[m] = A.width; D.attr_cstride[m] = A.cstride;
         }
       }
+      if (st) return st;
     }
     // The tile kernel loads both layers and the attribute planes unconditionally (branch-free loads keep
     // several items in flight): absent planes alias present ones; their samples are never used.
@@ -794,21 +822,34 @@ int gof_create_impl(vpcc_ctx* ctx, const vpcc_frame_desc* frames, uint32_t n_fra
       }
     if (!P.patches.empty())
       HIP_TRY(ctx, hipMemcpyAsync(base + o.patches, P.patches.data(), sizeof(DevPatch) * P.patches.size(),
-                                  hipMemcpyHostToDevice, s));
+                                  hipMemcpyHostToDevice, sd));
     if (!P.vblocks.empty())
       HIP_TRY(ctx, hipMemcpyAsync(base + o.vblocks, P.vblocks.data(), sizeof(VBlock) * P.vblocks.size(),
-                                  hipMemcpyHostToDevice, s));
+                                  hipMemcpyHostToDevice, sd));
     if (!P.tiles.empty())
       HIP_TRY(ctx, hipMemcpyAsync(base + o.items, P.tiles.data(), sizeof(TileItem) * P.tiles.size(),
-                                  hipMemcpyHostToDevice, s));
+                                  hipMemcpyHostToDevice, sd));
   }
   // the tile kernel needs every frame eligible and its vector loads aligned on the final pointers
   bool tiles_ok = all_simple && !(gof_flags & VPCC_GOF_FORCE_GENERAL);
   for (uint32_t i = 0; i < n_frames && tiles_ok; ++i) tiles_ok = tile_planes_aligned(g->h_frames[i]);
   g->general = !tiles_ok;
-  HIP_TRY(ctx, hipMemcpyAsync(g->d_frames, g->h_frames.data(), sizeof(DevFrame) * n_frames, hipMemcpyHostToDevice, s));
-  HIP_TRY(ctx, hipMemsetAsync(g->d_counts, 0, sizeof(uint32_t) * n_frames, s));
-  HIP_TRY(ctx, hipMemsetAsync(base + ctrl_begin, 0, g->ctrl_bytes, s));
+  HIP_TRY(ctx, hipMemcpyAsync(g->d_frames, g->h_frames.data(), sizeof(DevFrame) * n_frames, hipMemcpyHostToDevice, sd));
+  HIP_TRY(ctx, hipMemsetAsync(g->d_counts, 0, sizeof(uint32_t) * n_frames, sd));
+  HIP_TRY(ctx, hipMemsetAsync(base + ctrl_begin, 0, g->ctrl_bytes, sd));
+  IngestPiece* d_pieces = (IngestPiece*)(base + off_ingest);
+  if (!g->ingest.empty()) {
+    if (g->ingest.size() > ingest_bound) return fail(ctx, VPCC_ERR_STATE, "ingest piece list overflow");
+    HIP_TRY(ctx, hipMemcpyAsync(d_pieces, g->ingest.data(), sizeof(IngestPiece) * g->ingest.size(), hipMemcpyHostToDevice, sd));
+  }
+  // the planes follow on the copy stream (plane copies of the fallback path are queued there already; nothing of them
+  // depends on the descriptors), behind the set-up: upload_done then stands for both
+  HIP_TRY(ctx, hipEventRecord(g->upload_done, sd));
+  HIP_TRY(ctx, hipStreamWaitEvent(s, g->upload_done, 0));
+  if (!g->ingest.empty()) {
+    launch_ingest_planes(d_pieces, (uint32_t)g->ingest.size(), s);
+    HIP_TRY(ctx, hipGetLastError());
+  }
   HIP_TRY(ctx, hipEventRecord(g->upload_done, s));
   if (getenv("VPCC_RUNTIME_TRACE")) {
     const auto t_end = std::chrono::steady_clock::now();
@@ -1007,9 +1048,10 @@ extern "C" int vpcc_gof_frame_status(vpcc_gof* g, uint32_t frame) {
   return g->h_counts[frame] > g->capacity ? VPCC_ERR_CAPACITY : VPCC_OK;
 }
 
-extern "C" int vpcc_gof_download(vpcc_gof* g, uint32_t frame, vpcc_point3* xyz_out, vpcc_color3* rgb_out,
-                                 uint16_t* patch_index_out, size_t capacity, size_t* n_points) {
-  if (!g || frame >= g->n_frames || !n_points) return VPCC_ERR_INVALID_ARG;
+namespace {
+// Enqueues the copies of one frame's result on the download stream (behind the gof's latest kernels).
+int enqueue_download(vpcc_gof* g, uint32_t frame, vpcc_point3* xyz_out, vpcc_color3* rgb_out, uint16_t* patch_index_out,
+                     size_t capacity, size_t* n_points, bool push_allowed) {
   vpcc_ctx* ctx = g->ctx;
   HIP_TRY(ctx, hipSetDevice(ctx->device));
   int st = fetch_counts(g);
@@ -1020,17 +1062,60 @@ extern "C" int vpcc_gof_download(vpcc_gof* g, uint32_t frame, vpcc_point3* xyz_o
   const DevFrame& D = g->h_frames[frame];
   hipStream_t s = ctx->d2h_stream;
   HIP_TRY(ctx, hipStreamWaitEvent(s, g->results_ready, 0));   // the latest kernels on this gof (incl. smoothing)
+  if (patch_index_out && !D.out_patch) return fail(ctx, VPCC_ERR_STATE, "gof was created without VPCC_GOF_WANT_PATCH_INDEX");
   if (n) {
-    if (xyz_out) HIP_TRY(ctx, hipMemcpyAsync(xyz_out, D.out_xyz, n * sizeof(vpcc_point3), hipMemcpyDeviceToHost, s));
-    if (rgb_out && D.out_rgb)
-      HIP_TRY(ctx, hipMemcpyAsync(rgb_out, D.out_rgb, n * sizeof(vpcc_color3), hipMemcpyDeviceToHost, s));
-    if (patch_index_out) {
-      if (!D.out_patch) return fail(ctx, VPCC_ERR_STATE, "gof was created without VPCC_GOF_WANT_PATCH_INDEX");
-      HIP_TRY(ctx, hipMemcpyAsync(patch_index_out, D.out_patch, n * sizeof(uint16_t), hipMemcpyDeviceToHost, s));
+    // Page-locked destinations (all of them: one launch) are written by a kernel — beside the ingest kernel of the next
+    // unit a device-to-host hipMemcpyAsync crawls (k_push_results); anything else goes through the copy engine.
+    struct Arr { void* dst; const void* src; size_t bytes; } arr[3] = {
+        {xyz_out, D.out_xyz, n * sizeof(vpcc_point3)},
+        {D.out_rgb ? (void*)rgb_out : nullptr, D.out_rgb, n * sizeof(vpcc_color3)},
+        {patch_index_out, D.out_patch, n * sizeof(uint16_t)}};
+    IngestPiece pieces[3] = {};
+    bool push = push_allowed && !getenv("VPCC_NO_PUSH_DOWNLOAD");
+    for (int a = 0; a < 3 && push; ++a) {
+      if (!arr[a].dst) continue;
+      void* dev_dst = nullptr;
+      if (hipHostGetDevicePointer(&dev_dst, arr[a].dst, 0) != hipSuccess || !dev_dst) { (void)hipGetLastError(); push = false; break; }
+      pieces[a] = IngestPiece{arr[a].src, dev_dst, (uint32_t)arr[a].bytes, (uint32_t)(arr[a].bytes >> 32)};
     }
-    HIP_TRY(ctx, hipStreamSynchronize(s));
+    if (push) {
+      launch_push_results(pieces, s);
+      HIP_TRY(ctx, hipGetLastError());
+    } else {
+      for (int a = 0; a < 3; ++a)
+        if (arr[a].dst) HIP_TRY(ctx, hipMemcpyAsync(arr[a].dst, arr[a].src, arr[a].bytes, hipMemcpyDeviceToHost, s));
+    }
   }
   return VPCC_OK;
+}
+}  // namespace
+
+extern "C" int vpcc_gof_download(vpcc_gof* g, uint32_t frame, vpcc_point3* xyz_out, vpcc_color3* rgb_out,
+                                 uint16_t* patch_index_out, size_t capacity, size_t* n_points) {
+  if (!g || frame >= g->n_frames || !n_points) return VPCC_ERR_INVALID_ARG;
+  const int st = enqueue_download(g, frame, xyz_out, rgb_out, patch_index_out, capacity, n_points, false);
+  if (st) return st;
+  if (*n_points) HIP_TRY(g->ctx, hipStreamSynchronize(g->ctx->d2h_stream));
+  return VPCC_OK;
+}
+
+extern "C" int vpcc_gof_download_async(vpcc_gof* g, uint32_t frame, vpcc_point3* xyz_out, vpcc_color3* rgb_out,
+                                       uint16_t* patch_index_out, size_t capacity, size_t* n_points) {
+  if (!g || frame >= g->n_frames || !n_points) return VPCC_ERR_INVALID_ARG;
+  if (g->download_done.empty()) {                             // one event per frame, made at the first asynchronous download
+    g->download_done.assign(g->n_frames, nullptr);
+    for (hipEvent_t& e : g->download_done) HIP_TRY(g->ctx, hipEventCreateWithFlags(&e, hipEventDisableTiming));
+  }
+  const int st = enqueue_download(g, frame, xyz_out, rgb_out, patch_index_out, capacity, n_points, true);
+  if (st) return st;
+  HIP_TRY(g->ctx, hipEventRecord(g->download_done[frame], g->ctx->d2h_stream));
+  return VPCC_OK;
+}
+
+extern "C" int vpcc_gof_download_wait(vpcc_gof* g, uint32_t frame) {
+  if (!g || frame >= g->n_frames || g->download_done.empty()) return VPCC_ERR_INVALID_ARG;
+  // (no hipSetDevice and no use of the context: this may be called from another thread than the one that drives it)
+  return hipEventSynchronize(g->download_done[frame]) == hipSuccess ? VPCC_OK : VPCC_ERR_DEVICE;
 }
 
 extern "C" int vpcc_gof_kernel_times(vpcc_gof* g, const char** names_out, float* ms_out, int max) {
