@@ -269,6 +269,13 @@ int vpcc_gof_sync(vpcc_gof* gof);
 /* Per-frame point counts of the last reconstruct (synchronises). */
 int vpcc_gof_point_counts(vpcc_gof* gof, uint32_t* counts_out /* n_frames */);
 
+/* block_to_patch of frame `frame` as the gof holds it (src/codec.rs:205-250: 0 = unowned, else patch index + 1;
+ * (width / R) x (height / R) entries) and the number of work items the single-pass kernel has for the frame (0 for a gof
+ * of the general sequence, whose block_to_patch is valid after a reconstruct).  For the single-pass kernel both are
+ * built on the device when the gof is created (k_plan_cover / k_plan_items), from the occupancy plane where it lies.
+ * Synchronises; either out-pointer may be NULL. */
+int vpcc_gof_block_to_patch(vpcc_gof* gof, uint32_t frame, uint32_t* block_to_patch_out, uint32_t* work_items_out);
+
 /* Device pointers of frame `frame`'s outputs (vpcc_point3[capacity],
  * vpcc_color3[capacity], uint16_t[capacity] or NULL) and of its device-side
  * point counter (uint32_t).  Any of the out-pointers may be NULL. */

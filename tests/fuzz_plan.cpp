@@ -60,9 +60,14 @@ int main(int argc, char** argv) {
     if (plan.vblocks.size() != expect_vb) { std::fprintf(stderr, "vblock count\n"); return 1; }
     for (const vpcc::VBlock& b : plan.vblocks)
       if (b.canvas_block >= (uint64_t)plan.bw * plan.bh) { std::fprintf(stderr, "canvas block out of range\n"); return 1; }
-    for (const vpcc::TileItem& t : plan.tiles) {
-      if ((uint32_t)t.x0 + 16 > f.width || (uint32_t)t.y0 + 16 > f.height) { std::fprintf(stderr, "tile outside the canvas\n"); return 1; }
-      ++items;
+    // the tile kernel's items are completed on the device (k_plan_items) from one template per patch and the virtual
+    // blocks checked above: the host's part is the templates and the bound that sizes the device arrays
+    if (plan.tile_eligible) {
+      if (plan.patch_items.size() != patches.size()) { std::fprintf(stderr, "item templates\n"); return 1; }
+      if (plan.tile_bound > plan.vblocks.size() || plan.tile_bound > (uint64_t)plan.bw * plan.bh) { std::fprintf(stderr, "tile bound\n"); return 1; }
+      for (const vpcc::VBlock& b : plan.vblocks)
+        if ((b.canvas_block % plan.bw) * 16u + 16u > f.width || (b.canvas_block / plan.bw) * 16u + 16u > f.height) { std::fprintf(stderr, "tile outside the canvas\n"); return 1; }
+      items += plan.tile_bound;
     }
   }
   // Shares of the resident workgroups per frame (plan_tile_launch): every frame with tiles gets at least one

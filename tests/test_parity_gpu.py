@@ -275,6 +275,49 @@ def test_device_outputs_stay_valid(ctx):
     g.close()
 
 
+def test_work_lists_are_planned_on_the_device(ctx):
+    """generate_block_to_patch_from_occupancy_map_video (src/codec.rs:205-250) on the production path: the gof's
+    block_to_patch and the single-pass kernel's work list are built by k_plan_cover / k_plan_items when the gof is created,
+    from the occupancy plane where it lies — host planes and the caller's device planes alike.  Against the oracle's
+    block_to_patch; the work list holds exactly the owned blocks."""
+    import torch
+    frames = [synth.longdress_frame(3), cases.medium_frame(5, occupancy_values="random"), cases.precision_frame(2, 9),
+              cases.precision_frame(16, 4), synth.small_frame(1)]
+    refs = [ob.reconstruct(f)[1] for f in frames]
+    for f, ref in zip(frames, refs):
+        g = ctx.gof([f])
+        nb = (f["width"] // 16) * (f["height"] // 16)
+        b2p, items = g.block_to_patch(0, nb)                          # before any launch
+        assert np.array_equal(b2p.astype(np.uint64), ref["block_to_patch"].astype(np.uint64))
+        assert items == int(np.count_nonzero(ref["block_to_patch"])) > 0
+        g.reconstruct()
+        _check(g.download(0), ref)
+        g.close()
+    # the caller's device planes: the same list (round 3 kept every covered block there: the host could not see the occupancy)
+    f, ref = frames[0], refs[0]
+    dev = torch.device("cuda:0")
+    d, keep = _abi.host_frame_desc(f)
+    t = []
+
+    def up(a):
+        t.append(torch.from_numpy(np.ascontiguousarray(a).view(np.uint8).reshape(-1)).to(dev))
+        return t[-1].data_ptr()
+
+    d.occupancy.y = up(f["occupancy"])
+    d.occupancy.stride = d.occupancy.width
+    for m in range(2):
+        d.geometry[m].y = up(f["geometry"][m])
+        d.attribute[m].y, d.attribute[m].u, d.attribute[m].v = (up(p) for p in f["attribute"][m])
+    torch.cuda.synchronize()
+    g = ctx.gof(None, capacity=1_000_000, memory=_abi.VPCC_MEM_DEVICE, descs=[d])
+    b2p, items = g.block_to_patch(0, (f["width"] // 16) * (f["height"] // 16))
+    assert np.array_equal(b2p.astype(np.uint64), ref["block_to_patch"].astype(np.uint64))
+    assert items == int(np.count_nonzero(ref["block_to_patch"]))
+    g.reconstruct()
+    _check(g.download(0), ref)
+    g.close()
+
+
 def test_gof_is_deterministic_and_idempotent(ctx):
     frames = [synth.longdress_frame(i) for i in range(4)]
     g = ctx.gof(frames, capacity=1_000_000)

@@ -75,7 +75,8 @@ struct DevFrame {
   uint16_t* out_patch;        // optional (partition), may be null
   uint32_t* n_points;         // device counter of this frame
   // single-pass tile kernel (R == 16, Default/Swap patches, aligned planes)
-  const TileItem* tiles;      // owner-filtered items, emission order
+  TileItem* tiles;            // the frame's work items, emission order: written by k_plan_items when the gof is created
+  const TileItem* patch_items;   // one item template per patch (host)
   uint64_t* scan_state;       // one {status:2 | value:32} word per group of 16 items
   uint64_t* ticket;           // dynamic group counter {launch generation : 32 | groups drawn : 32} (deadlock-free ordering of
                               // the look-back chain; the generation makes a counter of an earlier launch read as fresh)
@@ -88,7 +89,7 @@ struct DevFrame {
   uint32_t n_patches, n_vblocks;
   uint32_t map_count, absolute_d1, has_attr;
   uint32_t capacity;
-  uint32_t n_tiles;           // number of tile items (the array is padded to a multiple of 16 readable items)
+  uint32_t n_tiles;           // number of work items, written by k_plan_items (the array is padded to a multiple of 16 readable items)
   uint32_t prec_shift;        // log2(prec) when prec is a power of two (tile kernel)
 };
 
@@ -166,6 +167,10 @@ void launch_smooth_mark(const DevFrame* d_frames, uint32_t first, uint32_t count
 void launch_smooth_clear(const DevFrame* d_frames, uint32_t first, uint32_t count, uint32_t max_points, SmoothGrid sg,
                          uint32_t w, bool both, void* stream);
 
+// Work lists of the tile kernel for frames [first, first + count): which virtual blocks own their canvas block and hold
+// occupancy (generate_block_to_patch_from_occupancy_map_video, src/codec.rs:205-250), in emission order.  Needs the frames'
+// occupancy planes in place and block_to_patch zeroed; writes block_to_patch, tiles and n_tiles.
+void launch_plan_tiles(DevFrame* d_frames, uint32_t first, uint32_t count, uint32_t max_vb, void* stream);
 // Kernel launchers (vpcc_kernels.hip).  All asynchronous on `stream`.
 void launch_block_owner(const DevFrame* d_frames, uint32_t first, uint32_t count, uint32_t max_vb,
                         void* stream);

@@ -99,7 +99,7 @@ int validate_frame(const vpcc_frame_desc* f) {
   return VPCC_OK;
 }
 
-void plan_frame(const vpcc_frame_desc& f, FramePlan* out, bool host_occupancy) {
+void plan_frame(const vpcc_frame_desc& f, FramePlan* out) {
   const int64_t R = f.occupancy_resolution;
   out->bw = f.width / f.occupancy_resolution;
   out->bh = f.height / f.occupancy_resolution;
@@ -135,41 +135,24 @@ void plan_frame(const vpcc_frame_desc& f, FramePlan* out, bool host_occupancy) {
       }
     vb_base += p.size_u0 * p.size_v0;
   }
-  // Ownership without looking at the occupancy (single-pass tile kernel).  For Default/Swap patches
-  // the pixels of a virtual block are exactly the pixels of its canvas block, so every covering
-  // patch sees the same occupancy and the reference's ascending overwrite (src/codec.rs:217,
-  // 242-244) leaves "highest covering patch, if any occupancy".  Blocks without occupancy emit
-  // nothing anyway, so the work list is simply the virtual blocks of the highest covering patch,
-  // in emission order, each carrying the patch fields its points need.
-  out->tiles.clear();
+  // Tile kernel (R = 16, Default/Swap patches): one item TEMPLATE per patch — the fields of a work item that the patch
+  // decides.  For such patches the pixels of a virtual block are exactly the pixels of its canvas block, so every covering
+  // patch sees the same occupancy and the reference's ascending overwrite (src/codec.rs:217, 242-244) leaves "highest
+  // covering patch, if any occupancy": the device finds those blocks (k_plan_cover, k_plan_items) and completes the items.
+  out->patch_items.clear();
   const uint32_t prec = f.occupancy_precision;
   out->tile_eligible = out->simple_orientations && f.occupancy_resolution == 16 && prec <= 16 && (prec & (prec - 1)) == 0;
+  out->tile_bound = 0;
   if (out->tile_eligible) {
-    std::vector<int32_t> cover((size_t)out->bw * out->bh, -1);
-    for (const VBlock& b : out->vblocks) cover[b.canvas_block] = std::max(cover[b.canvas_block], (int32_t)b.patch);
-    // occupancy samples of a 16x16 block: 16 / prec per side (at least one)
-    const uint32_t spb = prec >= 16 ? 1u : 16u / prec;
-    auto block_has_occupancy = [&](uint32_t cb) {
-      const uint32_t sx = (cb % out->bw) * 16u / prec, sy = (cb / out->bw) * 16u / prec;
-      for (uint32_t y = sy; y < sy + spb && y < f.occupancy.height; ++y) {
-        const uint8_t* row = f.occupancy.y + (size_t)y * f.occupancy.stride;
-        for (uint32_t x = sx; x < sx + spb && x < f.occupancy.width; ++x)
-          if (row[x]) return true;
-      }
-      return false;
-    };
-    for (const VBlock& b : out->vblocks) {
-      if (cover[b.canvas_block] != (int32_t)b.patch) continue;
-      if (host_occupancy && !block_has_occupancy(b.canvas_block)) continue;   // emits nothing (src/codec.rs:236-244, 393)
-      const vpcc_patch& p = f.patches[b.patch];
+    out->patch_items.resize(f.patch_count);
+    for (uint32_t i = 0; i < f.patch_count; ++i) {
+      const vpcc_patch& p = f.patches[i];
       TileItem t{};
-      t.x0 = (uint16_t)((b.canvas_block % out->bw) * 16u);
-      t.y0 = (uint16_t)((b.canvas_block / out->bw) * 16u);
-      t.patch = b.patch;
+      t.patch = (uint16_t)i;
       t.flags = (uint8_t)((p.orientation == VPCC_ORIENT_DEFAULT ? 0 : kTileSwap) | (p.projection_mode ? kTileMode1 : 0));
       t.axes = (uint8_t)(p.normal_axis | (p.tangent_axis << 2) | (p.bitangent_axis << 4));
-      t.tb = (uint32_t)b.u0 * 16u * p.lod_x + p.u1;
-      t.bb = (uint32_t)b.v0 * 16u * p.lod_y + p.v1;
+      t.tb = p.u1;                                     // + u0 * 16 * lod_x of the block   (src/decoder.rs:875-876)
+      t.bb = p.v1;                                     // + v0 * 16 * lod_y
       t.d1 = p.d1;
       t.lod_x = (uint16_t)p.lod_x;
       t.lod_y = (uint16_t)p.lod_y;
@@ -186,9 +169,10 @@ void plan_frame(const vpcc_frame_desc& f, FramePlan* out, bool host_occupancy) {
       t.sel_xy = sel[0] | (sel[1] << 16);
       t.sel_z = sel[2] | 0x0C0C0000u;
       if (p.lod_x > 65535u || p.lod_y > 65535u) out->tile_eligible = false;
-      out->tiles.push_back(t);
+      out->patch_items[i] = t;
     }
-    if (!out->tile_eligible) out->tiles.clear();
+    if (!out->tile_eligible) out->patch_items.clear();
+    else out->tile_bound = (uint32_t)std::min<uint64_t>(out->vblocks.size(), (uint64_t)out->bw * out->bh);
   }
   // B = Wo*Ho + M*W*H*2 + M*(W*H*2 + 2*(W/2)*(H/2)*2) + 9*N (N added at run time)
   uint64_t bytes = (uint64_t)f.occupancy.width * f.occupancy.height;

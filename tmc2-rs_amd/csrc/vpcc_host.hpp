@@ -23,7 +23,9 @@ Affine patch_affine(const vpcc_patch& p, int64_t res);
 struct FramePlan {
   std::vector<DevPatch> patches;
   std::vector<VBlock> vblocks;       // every (patch, v0, u0) in emission order
-  std::vector<TileItem> tiles;       // tile kernel work list: the vblocks that own their canvas block
+  std::vector<TileItem> patch_items; // tile kernel: per patch, the fields of a work item that do not depend on the block
+                                     //   (k_plan_items fills in x0, y0, tb, bb of every block the patch owns)
+  uint32_t tile_bound = 0;           // upper bound of the frame's work items: min(virtual blocks, canvas blocks)
   bool tile_eligible = false;        // R == 16, Default/Swap only, occupancy precision compatible
   uint32_t bw = 0, bh = 0;
   bool simple_orientations = true;   // only Default / Swap (/MRot270 == Swap) patches
@@ -36,11 +38,11 @@ struct FramePlan {
 // whether an occupied pixel would actually touch the missing part.
 int validate_frame(const vpcc_frame_desc* f);
 
-// Requires validate_frame(f) == VPCC_OK.  `host_occupancy`: the occupancy plane is readable by the host (VPCC_MEM_HOST) —
-// the tile work list then leaves out the blocks that hold no occupancy at all (they emit nothing; the reference skips
-// them the same way: block_to_patch stays 0, src/codec.rs:236-244); with device-resident planes every covered block
-// stays in the list and the kernel finds it empty.
-void plan_frame(const vpcc_frame_desc& f, FramePlan* out, bool host_occupancy = false);
+// Requires validate_frame(f) == VPCC_OK.  The host only translates the patch table (affine patches, the list of virtual
+// blocks in emission order, one item template per patch); WHICH virtual blocks own their canvas block and hold any
+// occupancy — generate_block_to_patch_from_occupancy_map_video, src/codec.rs:205-250 — is decided on the device
+// (k_plan_cover / k_plan_items), which reads the occupancy plane where it lies, whoever owns it.
+void plan_frame(const vpcc_frame_desc& f, FramePlan* out);
 
 // Elements of a chroma plane that the reference's flat index (v/2)*cstride + (u/2) can reach (src/decoder.rs:977):
 // what the runtime uploads of a U or V plane.

@@ -43,6 +43,74 @@ __global__ __launch_bounds__(256) void k_block_owner(const DevFrame* __restrict_
   if (__ballot(any) != 0ull && lane_id() == 0) atomicMax(f.block_to_patch + b.canvas_block, (uint32_t)b.patch + 1u);
 }
 
+// ------------------------------------------------------ k_plan_cover / k_plan_items
+// The tile kernel's work list, built where the occupancy plane lies.  For Default/Swap patches and 16x16 blocks the
+// reference's block_to_patch (src/codec.rs:205-250: ascending patches, each overwriting the blocks under its occupied
+// virtual blocks) is "the highest patch that covers the block, if the block holds any occupancy":
+//   k_plan_cover: a thread per virtual block: atomicMax(block_to_patch[canvas block], patch + 1) if the block is occupied;
+//   k_plan_items: a workgroup per frame walks the virtual blocks in emission order, keeps those that own their canvas
+//                 block (ordered compaction: ballot + wave scan + a running base), and completes each item from its
+//                 patch's template.
+__device__ __forceinline__ bool block_occupied(const DevFrame& f, uint32_t cb) {
+  const uint32_t spb = f.prec >= 16u ? 1u : 16u / f.prec;                // occupancy samples per block side
+  const uint32_t sx = (cb % f.bw) * 16u / f.prec, sy = (cb / f.bw) * 16u / f.prec;
+  uint32_t any = 0;
+  for (uint32_t y = sy; y < sy + spb && y < f.occ_h; ++y)
+    for (uint32_t x = sx; x < sx + spb && x < f.occ_w; ++x) any |= gl(f.occ)[y * f.occ_stride + x];
+  return any != 0;
+}
+__global__ __launch_bounds__(256) void k_plan_cover(const DevFrame* __restrict__ frames, uint32_t first) {
+  const DevFrame& f = frames[first + blockIdx.y];
+  const uint32_t vb = blockIdx.x * 256u + threadIdx.x;
+  if (!f.patch_items || vb >= f.n_vblocks) return;
+  const VBlock b = gload(f.vblocks + vb);
+  if (block_occupied(f, b.canvas_block)) atomicMax(f.block_to_patch + b.canvas_block, (uint32_t)b.patch + 1u);
+}
+__global__ __launch_bounds__(1024) void k_plan_items(DevFrame* __restrict__ frames, uint32_t first) {
+  DevFrame& f = frames[first + blockIdx.x];
+  if (!f.patch_items) return;                                              // (a frame of the general sequence)
+  __shared__ uint32_t wave_total[16];
+  __shared__ uint32_t base_s;
+  if (threadIdx.x == 0) base_s = 0;
+  __syncthreads();
+  const uint32_t n = f.n_vblocks, lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+  for (uint32_t v0 = 0; v0 < n; v0 += 1024u) {
+    const uint32_t vb = v0 + threadIdx.x;
+    VBlock b{};
+    bool own = false;
+    if (vb < n) {
+      b = gload(f.vblocks + vb);
+      own = gl(f.block_to_patch)[b.canvas_block] == (uint32_t)b.patch + 1u;
+    }
+    const uint64_t m = __ballot(own);
+    if (lane == 0) wave_total[wave] = (uint32_t)__builtin_popcountll(m);
+    __syncthreads();
+    uint32_t before = base_s;
+    for (uint32_t w = 0; w < wave; ++w) before += wave_total[w];
+    if (own) {
+      TileItem t = gload(f.patch_items + b.patch);
+      t.x0 = (uint16_t)((b.canvas_block % f.bw) * 16u);
+      t.y0 = (uint16_t)((b.canvas_block / f.bw) * 16u);
+      t.tb += (uint32_t)b.u0 * 16u * t.lod_x;
+      t.bb += (uint32_t)b.v0 * 16u * t.lod_y;
+      gstore(f.tiles + before + (uint32_t)__builtin_popcountll(m & ((1ull << lane) - 1ull)), t);
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      uint32_t tot = 0;
+      for (uint32_t w = 0; w < 16u; ++w) tot += wave_total[w];
+      base_s += tot;
+    }
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) f.n_tiles = base_s;
+}
+void launch_plan_tiles(DevFrame* d_frames, uint32_t first, uint32_t count, uint32_t max_vb, void* stream) {
+  if (!count || !max_vb) return;
+  hipLaunchKernelGGL(k_plan_cover, dim3((max_vb + 255u) / 256u, count), dim3(256), 0, (hipStream_t)stream, d_frames, first);
+  hipLaunchKernelGGL(k_plan_items, dim3(count), dim3(1024), 0, (hipStream_t)stream, d_frames, first);
+}
+
 // ------------------------------------------------------------------ k_count
 __global__ __launch_bounds__(256) void k_count(const DevFrame* __restrict__ frames, uint32_t first) {
   const DevFrame& f = frames[first + blockIdx.y];

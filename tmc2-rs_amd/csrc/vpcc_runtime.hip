@@ -612,7 +612,7 @@ int gof_create_impl(vpcc_ctx* ctx, const vpcc_frame_desc* frames, uint32_t n_fra
     // bottleneck of a run once the kernels take 0.5 % of it.
     const auto t_plan = std::chrono::steady_clock::now();
     const uint32_t team = n_frames >= 16 ? std::min<uint32_t>(8u, std::max(1u, std::thread::hardware_concurrency() / 2u)) : 1u;
-    auto work = [&](uint32_t t) { for (uint32_t i = t; i < n_frames; i += team) plan_frame(frames[i], &g->plans[i], kind == VPCC_MEM_HOST); };   // (the host can read the occupancy only there)
+    auto work = [&](uint32_t t) { for (uint32_t i = t; i < n_frames; i += team) plan_frame(frames[i], &g->plans[i]); };
     std::vector<std::thread> helpers;
     for (uint32_t t = 1; t < team; ++t) helpers.emplace_back(work, t);
     work(0);
@@ -636,13 +636,13 @@ int gof_create_impl(vpcc_ctx* ctx, const vpcc_frame_desc* frames, uint32_t n_fra
   const size_t off_frames = L.take(sizeof(DevFrame) * n_frames);
   const size_t off_counts = L.take(sizeof(uint32_t) * n_frames);
   struct Off {
-    size_t patches, vblocks, items, b2p, vb_count, vb_offset, xyz, rgb, pidx, occ, geo[2], ay[2], au[2], av[2];
+    size_t patches, vblocks, items, patch_items, b2p, vb_count, vb_offset, xyz, rgb, pidx, occ, geo[2], ay[2], au[2], av[2];
   };
   std::vector<Off> offs(n_frames);
   // control words of the single-pass path: one contiguous region, zeroed once at creation
   g->scan_off.assign(n_frames + 1, 0);
   for (uint32_t i = 0; i < n_frames; ++i)
-    g->scan_off[i + 1] = g->scan_off[i] + (g->plans[i].tiles.size() + kTileScanGranule - 1) / kTileScanGranule;
+    g->scan_off[i + 1] = g->scan_off[i] + (g->plans[i].tile_bound + kTileScanGranule - 1) / kTileScanGranule;
   const size_t ctrl_begin = L.total;
   const size_t off_tickets = L.total;
   L.total += 256 * (size_t)n_frames;              // one ticket per 256-B line: same-line atomics serialise
@@ -676,7 +676,8 @@ int gof_create_impl(vpcc_ctx* ctx, const vpcc_frame_desc* frames, uint32_t n_fra
     Off& o = offs[i];
     o.patches = L.take(sizeof(DevPatch) * std::max<size_t>(P.patches.size(), 1));
     o.vblocks = L.take(sizeof(VBlock) * std::max<size_t>(P.vblocks.size(), 1));
-    o.items = L.take(sizeof(TileItem) * (((P.tiles.size() + kTileItemsPerGroup - 1) / kTileItemsPerGroup) * kTileItemsPerGroup + kTileItemsPerGroup));
+    o.items = L.take(sizeof(TileItem) * (((P.tile_bound + kTileItemsPerGroup - 1) / kTileItemsPerGroup) * kTileItemsPerGroup + kTileItemsPerGroup));
+    o.patch_items = L.take(sizeof(TileItem) * std::max<size_t>(P.patch_items.size(), 1));
     o.vb_count = L.take(sizeof(uint32_t) * std::max<size_t>(P.vblocks.size(), 1));
     o.vb_offset = L.take(sizeof(uint32_t) * std::max<size_t>(P.vblocks.size(), 1));
     o.xyz = takek(i, 1, 0, sizeof(vpcc_point3) * cap);                    // (output block: positions, colours, partition in
@@ -747,8 +748,9 @@ int gof_create_impl(vpcc_ctx* ctx, const vpcc_frame_desc* frames, uint32_t n_fra
     D.out_rgb = F.attribute_count ? (vpcc_color3*)(kb(i, 1, 1) + o.rgb) : nullptr;
     D.out_patch = (gof_flags & VPCC_GOF_WANT_PATCH_INDEX) ? (uint16_t*)(kb(i, 1, 0) + o.pidx) : nullptr;
     D.n_points = g->d_counts + i;
-    D.tiles = (const TileItem*)(base + o.items);
-    D.n_tiles = (uint32_t)P.tiles.size();
+    D.tiles = (TileItem*)(base + o.items);
+    D.patch_items = P.tile_eligible ? (const TileItem*)(base + o.patch_items) : nullptr;
+    D.n_tiles = 0;                                              // written by k_plan_items
     D.scan_state = g->d_scan + g->scan_off[i];
     D.ticket = reinterpret_cast<uint64_t*>(g->d_tickets + 64 * (size_t)i);
     D.error_flag = g->d_errors + i;
@@ -826,8 +828,8 @@ int gof_create_impl(vpcc_ctx* ctx, const vpcc_frame_desc* frames, uint32_t n_fra
     if (!P.vblocks.empty())
       HIP_TRY(ctx, hipMemcpyAsync(base + o.vblocks, P.vblocks.data(), sizeof(VBlock) * P.vblocks.size(),
                                   hipMemcpyHostToDevice, sd));
-    if (!P.tiles.empty())
-      HIP_TRY(ctx, hipMemcpyAsync(base + o.items, P.tiles.data(), sizeof(TileItem) * P.tiles.size(),
+    if (!P.patch_items.empty())
+      HIP_TRY(ctx, hipMemcpyAsync(base + o.patch_items, P.patch_items.data(), sizeof(TileItem) * P.patch_items.size(),
                                   hipMemcpyHostToDevice, sd));
   }
   // the tile kernel needs every frame eligible and its vector loads aligned on the final pointers
@@ -837,6 +839,7 @@ int gof_create_impl(vpcc_ctx* ctx, const vpcc_frame_desc* frames, uint32_t n_fra
   HIP_TRY(ctx, hipMemcpyAsync(g->d_frames, g->h_frames.data(), sizeof(DevFrame) * n_frames, hipMemcpyHostToDevice, sd));
   HIP_TRY(ctx, hipMemsetAsync(g->d_counts, 0, sizeof(uint32_t) * n_frames, sd));
   HIP_TRY(ctx, hipMemsetAsync(base + ctrl_begin, 0, g->ctrl_bytes, sd));
+  if (g->b2p_words) HIP_TRY(ctx, hipMemsetAsync(g->d_b2p, 0, g->b2p_words * sizeof(uint32_t), sd));
   IngestPiece* d_pieces = (IngestPiece*)(base + off_ingest);
   if (!g->ingest.empty()) {
     if (g->ingest.size() > ingest_bound) return fail(ctx, VPCC_ERR_STATE, "ingest piece list overflow");
@@ -848,6 +851,11 @@ int gof_create_impl(vpcc_ctx* ctx, const vpcc_frame_desc* frames, uint32_t n_fra
   HIP_TRY(ctx, hipStreamWaitEvent(s, g->upload_done, 0));
   if (!g->ingest.empty()) {
     launch_ingest_planes(d_pieces, (uint32_t)g->ingest.size(), s);
+    HIP_TRY(ctx, hipGetLastError());
+  }
+  // the tile kernel's work lists, from the occupancy planes where they now lie (src/codec.rs:205-250 on the device)
+  if (!g->general) {
+    launch_plan_tiles(g->d_frames, 0, n_frames, g->max_vb, s);
     HIP_TRY(ctx, hipGetLastError());
   }
   HIP_TRY(ctx, hipEventRecord(g->upload_done, s));
@@ -944,13 +952,13 @@ extern "C" int vpcc_gof_reconstruct(vpcc_gof* g, uint32_t first, uint32_t count,
     // single-pass tile kernel: ONE kernel, nothing to prepare
     uint32_t max_groups = 0;
     for (uint32_t i = first; i < first + count; ++i)
-      max_groups = std::max(max_groups, (uint32_t)((g->plans[i].tiles.size() + kTileItemsPerGroup - 1) / kTileItemsPerGroup));
+      max_groups = std::max(max_groups, (uint32_t)((g->plans[i].tile_bound + kTileItemsPerGroup - 1) / kTileItemsPerGroup));
     // Nothing to clear: look-back words and ticket counters carry the launch generation (a counter of an earlier
     // launch is reset by the first workgroup that draws from it), and a frame's point count is rewritten by its last group
     // (a frame without tiles keeps the zero written at creation).
     if (!g->tile_map_valid || g->tile_map_first != first || g->tile_map_count != count) {
       std::vector<uint32_t> tiles(count);
-      for (uint32_t i = 0; i < count; ++i) tiles[i] = (uint32_t)g->plans[first + i].tiles.size();
+      for (uint32_t i = 0; i < count; ++i) tiles[i] = g->plans[first + i].tile_bound;   // (the exact counts are on the device: k_plan_items)
       plan_tile_launch(tiles.data(), count, ctx->resident_tile_wgs_per_xcd, 3, g->tile_map);
       g->tile_map_first = first; g->tile_map_count = count; g->tile_map_valid = true;
     }
@@ -1026,6 +1034,23 @@ extern "C" int vpcc_gof_point_counts(vpcc_gof* g, uint32_t* counts_out) {
   const int st = fetch_counts(g);
   if (st) return st;
   std::memcpy(counts_out, g->h_counts, sizeof(uint32_t) * g->n_frames);
+  return VPCC_OK;
+}
+
+extern "C" int vpcc_gof_block_to_patch(vpcc_gof* g, uint32_t frame, uint32_t* block_to_patch_out, uint32_t* work_items_out) {
+  if (!g || frame >= g->n_frames) return VPCC_ERR_INVALID_ARG;
+  vpcc_ctx* ctx = g->ctx;
+  HIP_TRY(ctx, hipSetDevice(ctx->device));
+  hipStream_t s = ctx->d2h_stream;
+  HIP_TRY(ctx, hipStreamWaitEvent(s, g->upload_done, 0));              // the planning kernels of vpcc_gof_create
+  if (g->launched) HIP_TRY(ctx, hipStreamWaitEvent(s, g->results_ready, 0));   // (general sequence: written by every launch)
+  const size_t n = (size_t)g->plans[frame].bw * g->plans[frame].bh;
+  if (block_to_patch_out && n)
+    HIP_TRY(ctx, hipMemcpyAsync(block_to_patch_out, g->h_frames[frame].block_to_patch, n * sizeof(uint32_t), hipMemcpyDeviceToHost, s));
+  DevFrame d{};
+  if (work_items_out) HIP_TRY(ctx, hipMemcpyAsync(&d, g->d_frames + frame, sizeof d, hipMemcpyDeviceToHost, s));
+  HIP_TRY(ctx, hipStreamSynchronize(s));
+  if (work_items_out) *work_items_out = g->general ? 0u : d.n_tiles;
   return VPCC_OK;
 }
 

@@ -225,6 +225,7 @@ def load_library():
     lib.vpcc_gof_point_counts.argtypes = [vp, vp]
     lib.vpcc_gof_device_outputs.argtypes = [vp, u32, C.POINTER(vp), C.POINTER(vp), C.POINTER(vp), C.POINTER(vp)]
     lib.vpcc_gof_download.argtypes = [vp, u32, vp, vp, vp, sz, C.POINTER(sz)]
+    lib.vpcc_gof_block_to_patch.argtypes = [vp, u32, vp, C.POINTER(u32)]
     lib.vpcc_gof_download_async.argtypes = [vp, u32, vp, vp, vp, sz, C.POINTER(sz)]
     lib.vpcc_gof_download_wait.argtypes = [vp, u32]
     lib.vpcc_gof_frame_status.argtypes = [vp, u32]

@@ -203,6 +203,13 @@ class Gof:
         self.ctx._check(self.lib.vpcc_gof_smooth(self.h, first, count, C.byref(p), C.c_void_p(stream) if stream else None),
                         "vpcc_gof_smooth")
 
+    def block_to_patch(self, frame, n_blocks):
+        """vpcc_gof_block_to_patch: (block_to_patch[n_blocks], work items of the single-pass kernel)."""
+        out = np.zeros(n_blocks, dtype=np.uint32)
+        items = C.c_uint32(0)
+        self.ctx._check(self.lib.vpcc_gof_block_to_patch(self.h, frame, out.ctypes.data, C.byref(items)), "vpcc_gof_block_to_patch")
+        return out, int(items.value)
+
     def device_outputs(self, frame):
         p = [C.c_void_p() for _ in range(4)]
         self.ctx._check(self.lib.vpcc_gof_device_outputs(self.h, frame, *[C.byref(x) for x in p]),
