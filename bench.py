@@ -105,7 +105,6 @@ def parse():
     ap.add_argument("--pool-gib", type=int, default=32,
                     help="vpcc_ctx_reserve: the context's pool (two homes in the two kinds of VRAM regions), as the streaming "
                          "Decoder's lanes take it (VPCC_DECODER_POOL_GIB, default 32).  0: every gof block is a hipMalloc of its own")
-    ap.add_argument("--no-tune-placement", action="store_true", help=argparse.SUPPRESS)   # accepted for old tool scripts
     ap.add_argument("--diag", action="store_true",
                     help="allow the diagnostic library (VPCC_DIAG_LIB=1, tools/ only): its timings are not the product's")
     ap.add_argument("--no-compare", action="store_true",

@@ -34,3 +34,8 @@ def test_random_sweep_oracle_equals_pyref():
 
 def test_full_size_longdress_frame_oracle_equals_pyref():
     assert _compare(synth.longdress_frame(5)) > 700_000
+
+
+def test_full_size_owlii_frame_oracle_equals_pyref():
+    """BASELINE config 5's shape (2048x2048, 11-bit coordinates, ~2 M points) through both restatements."""
+    assert _compare(synth.owlii_frame(2)) > 1_800_000

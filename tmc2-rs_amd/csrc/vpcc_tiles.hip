@@ -5,7 +5,7 @@
 // output byte written once.
 //
 // Work decomposition
-//   item   = one virtual block that owns its canvas block (host-filtered, see vpcc_host.cpp), in
+//   item   = one virtual block that owns its canvas block and holds occupancy (k_plan_items, vpcc_kernels.hip), in
 //            the reference's emission order (src/codec.rs:352-385);
 //   group  = 16 consecutive items = one ticket and one look-back word = the work of one 256-thread
 //            workgroup for one step;
@@ -197,7 +197,7 @@ struct Item {
   uint32_t x0, y0, patch, flags, axes, tb, bb, d1, lod_x, lod_y, sel_xy, sel_z;
 };
 
-// The item tables are written by the host before the launch and never by a kernel: with a
+// The item tables are written when the gof is created (k_plan_items) and never by this kernel: with a
 // wave-uniform address the constant address space makes this ONE s_load_dwordx8 — no vector load, no
 // readfirstlane, and (unlike a vector load) it does not queue behind the wave's outstanding stores.
 // (VPCC_CONSTANT: defined above.)

@@ -1,11 +1,17 @@
-// vpcc_tiles.hip — single-pass, wave-per-tile reconstruction kernel for gfx950 (CDNA4, wave64).
+// vpcc_tiles_lds_dma.hip — EXPERIMENTAL variant of vpcc_tiles.hip (round 4; `make lds-dma`, never the product): the attribute
+// samples of an item do not pass through registers but are staged in LDS by LDS-DMA (global_load_lds_dwordx4), a whole step
+// before the item is emitted.  Bit-exact (the GPU parity suite passes on it), 13 % fewer plane reads (1 250 vs 1 440 MB per
+// 128 S-longdress frames: at the floor of the raster layout in emission order) — and 7 % SLOWER (0.482 vs 0.451 ms) once the
+// memory system is balanced (vpcc_ctx_reserve): DESIGN.md 4.1.2, profiles/r04/ab_kernel.txt, ab_stage.txt.
+//
+// Single-pass, wave-per-tile reconstruction kernel for gfx950 (CDNA4, wave64).
 //
 // Production path for the common configuration (block size R = 16, Default/Swap patches, 8-byte
 // aligned luma rows).  One launch per batch of frames; every plane is read from HBM once, every
 // output byte written once.
 //
 // Work decomposition
-//   item   = one virtual block that owns its canvas block (host-filtered, see vpcc_host.cpp), in
+//   item   = one virtual block that owns its canvas block and holds occupancy (k_plan_items, vpcc_kernels.hip), in
 //            the reference's emission order (src/codec.rs:352-385);
 //   group  = 16 consecutive items = one ticket and one look-back word = the work of one 256-thread
 //            workgroup for one step;

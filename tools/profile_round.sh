@@ -1,7 +1,7 @@
 #!/bin/bash
 # Round evidence for one bench configuration (run on the GPU box through gpurun):
-#   stats/      rocprofv3 --kernel-trace --stats of the default-like bench command (kernel durations; the ~130 launches of the
-#               placement measurement are in the average: 1.5 s of timed launches dilute them to about 4 %)
+#   stats/      rocprofv3 --kernel-trace --stats of the default-like bench command (kernel durations; the ~100 launches of the
+#               pool's probe kernel, k_probe_outputs, are a kernel of their own in the table)
 #   pmc_*/      memory-side traffic of the dominant kernel, separate counter passes as MI355X_MICROARCH.md
 #               prescribes: FETCH_SIZE and WRITE_SIZE (the guide's counters; FETCH_SIZE x 2 on gfx950) and the
 #               exact request-size counters TCC_EA0_RDREQ_{32B,64B,128B}, TCC_EA0_WRREQ(_64B)
@@ -14,7 +14,7 @@ R=$GRAFT_REPO_ROOT
 cd /tmp; export TMPDIR=/tmp
 rocprofv3 --kernel-trace --stats --output-format csv -d "$out/stats" -- python3 $R/bench.py --min-seconds 1.5 --no-cpu-baseline --no-end-to-end --no-other-configs --no-gpu-state --no-compare "$@" > "$out/stats.log" 2>&1
 pass() { name=$1; shift
-  rocprofv3 --kernel-trace --pmc "$@" --output-format csv -d "$out/pmc_$name" -- python3 $R/bench.py --steps 3 --warmup 1 --ramp-ms 0 --min-seconds 0 --no-tune-placement --no-cpu-baseline --no-verify --no-end-to-end --no-other-configs --no-gpu-state --no-compare $BENCH_PMC_ARGS > "$out/pmc_$name.log" 2>&1 || echo "pass $name failed"; }
+  rocprofv3 --kernel-trace --pmc "$@" --output-format csv -d "$out/pmc_$name" -- python3 $R/bench.py --steps 3 --warmup 1 --ramp-ms 0 --min-seconds 0 --no-cpu-baseline --no-verify --no-end-to-end --no-other-configs --no-gpu-state --no-compare $BENCH_PMC_ARGS > "$out/pmc_$name.log" 2>&1 || echo "pass $name failed"; }
 BENCH_PMC_ARGS="$*"
 pass FETCH_SIZE FETCH_SIZE
 pass WRITE_SIZE WRITE_SIZE
