@@ -75,7 +75,7 @@ constexpr uint64_t kAggregate = 1ull << kStatusShift;
 constexpr uint64_t kPrefix = 2ull << kStatusShift;
 constexpr uint32_t kSpinLimit = 1u << 22;
 #ifndef VPCC_FRAMES_IN_FLIGHT
-#define VPCC_FRAMES_IN_FLIGHT 16
+#define VPCC_FRAMES_IN_FLIGHT 8
 #endif
 constexpr uint32_t kFramesInFlight = VPCC_FRAMES_IN_FLIGHT;    // frames of one XCD label worked on at a time (launches of more than 8 x this many frames run in rounds)
 
@@ -684,7 +684,9 @@ void k_recon_tiles(const DevFrame* __restrict__ frames, uint32_t first,
   // (lines shared between neighbouring blocks), but more workgroups per frame mean longer look-back chains and more
   // changes of frame.  Measured on 128-frame launches: raster planes as hipMalloc places them 4 / 8 / 16 frames in
   // flight 0.5195 / 0.5155 / 0.5016 ms; raster planes on placed blocks 0.459 / 0.4531 / 0.4537 (and 91 MB fewer
-  // reads with 8) (profiles/r03/ab_frames_in_flight*.txt); round 4, blocks in the pool's two homes: see profiles/r04/ab_kernel.txt.
+  // reads with 8) (profiles/r03/ab_frames_in_flight*.txt); round 4, every block in the pool's two homes (the product's
+  // allocation policy): 8 / 16 in flight 0.4500 / 0.4520 ms, S-owlii 1.0660 / 1.0775 (medians of four alternating runs,
+  // profiles/r04/ab_kernel.txt): 8.
   const uint32_t xcd = blockIdx.x & 7u, slot = blockIdx.x >> 3;
   const uint32_t frame_groups = (count + 7u) / 8u;
   const bool rounds = frame_groups > kFramesInFlight;
