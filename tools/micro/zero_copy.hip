@@ -7,6 +7,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <chrono>
+#include <sys/mman.h>
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 #define G __attribute__((address_space(1)))
 __global__ __launch_bounds__(256) void k_pull(const u32x4* __restrict__ src, u32x4* __restrict__ dst, size_t n16, int unroll) {
@@ -26,7 +27,10 @@ int main(int argc, char** argv) {
   const bool reg = argc > 1 && !strcmp(argv[1], "registered");
   void* h = nullptr; void* hd = nullptr; void* d = nullptr;
   if (reg) {
-    h = aligned_alloc(4096, bytes); memset(h, 1, bytes);
+    h = aligned_alloc(2 << 20, bytes);
+    if (argc > 2 && !strcmp(argv[2], "nohuge")) madvise(h, bytes, MADV_NOHUGEPAGE);      // 4-KB pages
+    if (argc > 2 && !strcmp(argv[2], "huge")) madvise(h, bytes, MADV_HUGEPAGE);
+    memset(h, 1, bytes);
     if (hipHostRegister(h, bytes, hipHostRegisterPortable | hipHostRegisterMapped) != hipSuccess) { printf("register failed\n"); return 1; }
   } else {
     if (hipHostMalloc(&h, bytes, hipHostMallocPortable | hipHostMallocMapped) != hipSuccess) { printf("hostmalloc failed\n"); return 1; }
