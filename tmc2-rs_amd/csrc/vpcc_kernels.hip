@@ -255,7 +255,10 @@ void launch_emit(const DevFrame* d_frames, uint32_t first, uint32_t count, uint3
 // workgroups and more — the rate of ONE big hipMemcpyAsync, where the 1 280 plane-sized copies (0.1-3.6 MB) of a
 // 128-frame unit reach 34 GB/s on the copy engines (tools/micro/zero_copy.hip, profiles/r04/zero_copy.txt).
 // A piece's source and destination are congruent modulo 16 (the runtime places the destination so); up to 15 bytes in
-// front of and behind the aligned body go byte by byte.
+// front of and behind the aligned body go byte by byte — single-byte reads over PCIe, which is why only a plane's first
+// and last piece have any (with eight in front of and behind EVERY piece: 2 060 instead of 2 190 frames/s end to end).
+// Measured and not kept: 256-KB pieces with eight loads in flight per lane 2 110; the next piece's descriptor fetched
+// beside the current piece's data 2 130-2 150.
 __global__ __launch_bounds__(256) void k_ingest_planes(const IngestPiece* __restrict__ pieces, uint32_t n) {
   typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
   for (uint32_t c = blockIdx.x; c < n; c += gridDim.x) {

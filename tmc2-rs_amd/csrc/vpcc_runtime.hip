@@ -783,8 +783,13 @@ int gof_create_impl(vpcc_ctx* ctx, const vpcc_frame_desc* frames, uint32_t n_fra
             hipHostGetDevicePointer(&dev_src, const_cast<void*>(src), 0) == hipSuccess && dev_src) {
           dst += (uintptr_t)src & 15u;
           const size_t bytes = (size_t)width * height * elem;
-          for (size_t at = 0; at < bytes; at += kIngestPieceBytes)
-            g->ingest.push_back(IngestPiece{(const char*)dev_src + at, dst + at, (uint32_t)std::min<size_t>(kIngestPieceBytes, bytes - at), 0u});
+          // (the first piece ends on a 16-byte boundary of the source: only a plane's first and last piece have bytes in front
+          // of / behind their aligned body — single-byte reads over PCIe)
+          for (size_t at = 0; at < bytes;) {
+            const size_t len = std::min<size_t>(kIngestPieceBytes - (at ? 0u : ((uintptr_t)dev_src & 15u)), bytes - at);
+            g->ingest.push_back(IngestPiece{(const char*)dev_src + at, dst + at, (uint32_t)len, 0u});
+            at += len;
+          }
           return dst;
         }
         (void)hipGetLastError();
