@@ -3,9 +3,12 @@
 
 A "step" is one pass of the hot path over one batch: ONE launch over four GOFs of 32 distinct synthetic
 S-longdress frames each (128 frames; 1280x1408 geometry+attribute, 320x352 occupancy, ~800 k points/frame —
-BASELINE.json configs[1]), all decoded planes and patch tables already resident in HBM when the
-timed region starts.  This is the launch the product issues: tmc2rs::Decoder reconstructs every run of up to four
-resident GOFs in one launch (`end_to_end.max_frames_per_launch`).  Frames are independent, so with N GPUs every
+BASELINE.json configs[1]), all decoded planes — in the RASTER layout a video decoder hands over — and
+patch tables already resident in HBM when the timed region starts; every kernel between those planes and the points is
+inside the region (`roofline.all_kernels_ms`: k_recon_tiles alone; nothing is re-arranged, the work lists are built when the
+gof is created, like the upload).  The gof's blocks are allocated by the policy the product uses: the context's pool
+(vpcc_ctx_reserve, `config.pool`; the streaming Decoder's lanes reserve the same).  This is the launch the product issues:
+tmc2rs::Decoder reconstructs every run of up to four resident GOFs in one launch (`end_to_end.max_frames_per_launch`).  Frames are independent, so with N GPUs every
 rank reconstructs its own batch (weak scaling, no data-path collective); `value` is the whole-job Mpoints/s.
 
   python bench.py --gpus 1 --steps 20 --warmup 3
@@ -431,7 +434,7 @@ def main():
             tr = measured_traffic("k_smooth", args.workload, n_batch)
         roofline = {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 1), "peak": HBM_PEAK_GBPS,
                     "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBPS, 4),
-                    "achieved_is": "algorithmic bytes (SURVEY 8d: whole planes once + 9 B/point) / kernel time — not a physical HBM rate (the kernel reads only the blocks that hold points: frac can exceed 1); that is frac_traffic",
+                    "achieved_is": "algorithmic bytes (SURVEY 8d: whole planes once + 9 B/point) / kernel time — a rate of the bytes the path stands for; the physical HBM rate is frac_traffic",
                     "traffic": tr["hbm_bytes_per_launch"] if tr else None,
                     "traffic_stale": stale(tr, "k_recon_tiles") if tr else None,
                     "traffic_measured_on": {"kernel_source_sha16": tr.get("kernel_source_sha16"), "library_sha16": (tr.get("library") or {}).get("sha16")} if tr else None,
