@@ -101,7 +101,56 @@ int main(int argc, char** argv) {
         if ((tiles[i] != 0) != (have[i / 8] != 0)) { std::fprintf(stderr, "frame %u tiles %u workgroups %u\n", i, tiles[i], have[i / 8]); return 1; }
     }
   }
-  std::printf("launch maps %ld, equal split %ld\n", maps, equal_split);
+  // The free space of a context's pool (vpcc::PoolExtents, behind vpcc_ctx_reserve): random runs of two kinds, random takes and
+  // returns.  Blocks never overlap, lie inside one run of the kind asked for, the byte accounts add up, and once everything is
+  // back every run is ONE free extent again (coalescing never crosses a run).
+  long pool_ops = 0;
+  for (long it = 0; it < iterations / 8 + 4; ++it) {
+    vpcc::PoolExtents E;
+    static char arena[1];                                     // addresses only: nothing is dereferenced
+    char* base = arena;
+    const size_t G = 1u << 20;
+    size_t at = 0, total[2] = {0, 0};
+    const uint32_t n_runs = 1 + below(6);
+    for (uint32_t r = 0; r < n_runs; ++r) {
+      const size_t len = (1 + below(48)) * G;
+      const int kind = (int)below(2);
+      E.add_run(base + at, len, kind);
+      total[kind] += len;
+      at += len + (below(3) == 0 ? (1 + below(4)) * G : 0);    // sometimes a gap: another slab
+    }
+    if (E.in_use[0] != 0 || E.in_use[1] != 0) { std::fprintf(stderr, "pool: fresh runs in use\n"); return 1; }
+    struct Held { char* p; size_t bytes; uint32_t run; };
+    std::vector<Held> held;
+    for (int op = 0; op < 200; ++op, ++pool_ops) {
+      if (held.empty() || below(3) != 0) {
+        const int kind = (int)below(2);
+        const size_t bytes = (1 + below(below(4) == 0 ? 40 * 1024 : 4096)) * 1024;
+        char* p = nullptr; uint32_t run = 0;
+        if (!E.take(kind, bytes, &p, &run)) continue;
+        const vpcc::PoolExtents::Run& R = E.runs[run];
+        if (R.kind != kind || p < R.ptr || p + bytes > R.ptr + R.bytes) { std::fprintf(stderr, "pool: block outside a run of its kind\n"); return 1; }
+        for (const Held& h : held)
+          if (p < h.p + h.bytes && h.p < p + bytes) { std::fprintf(stderr, "pool: blocks overlap\n"); return 1; }
+        held.push_back(Held{p, bytes, run});
+      } else {
+        const size_t k = below((uint32_t)held.size());
+        E.give_back(held[k].run, held[k].p, held[k].bytes);
+        held.erase(held.begin() + k);
+      }
+      size_t used[2] = {0, 0}, freeb[2] = {0, 0};
+      for (const Held& h : held) used[E.runs[h.run].kind] += h.bytes;
+      for (int kd = 0; kd < 2; ++kd) {
+        for (const auto& x : E.free_[kd]) freeb[kd] += x.bytes;
+        if (used[kd] != E.in_use[kd] || used[kd] + freeb[kd] != total[kd]) { std::fprintf(stderr, "pool: byte accounts\n"); return 1; }
+      }
+    }
+    for (const Held& h : held) E.give_back(h.run, h.p, h.bytes);
+    size_t extents = 0;
+    for (int kd = 0; kd < 2; ++kd) extents += E.free_[kd].size();
+    if (extents != E.runs.size() || E.in_use[0] || E.in_use[1]) { std::fprintf(stderr, "pool: not whole again (%zu extents, %zu runs)\n", extents, E.runs.size()); return 1; }
+  }
+  std::printf("launch maps %ld, equal split %ld, pool operations %ld\n", maps, equal_split, pool_ops);
   std::printf("iterations %ld accepted %ld rejected %ld tile items %ld\n", iterations, accepted, rejected, items);
   return accepted > 0 && rejected > 0 ? 0 : 1;
 }

@@ -1,6 +1,7 @@
 """Host-side frame validation + planning (tmc2-rs_amd/csrc/vpcc_host.cpp) under AddressSanitizer + UBSan with random
 and adversarial patch tables: rejected, or planned into work lists that stay inside the canvas; and the shares of the
-resident workgroups per frame of a launch (plan_tile_launch) keep their invariants for random frame sizes."""
+resident workgroups per frame of a launch (plan_tile_launch) keep their invariants for random frame sizes; and the free-space
+book-keeping of a context's pool (PoolExtents, behind vpcc_ctx_reserve) under random takes and returns."""
 import os
 import subprocess
 

@@ -185,6 +185,40 @@ void plan_frame(const vpcc_frame_desc& f, FramePlan* out) {
   out->plane_bytes = bytes;
 }
 
+uint32_t PoolExtents::add_run(char* ptr, size_t bytes, int kind) {
+  runs.push_back(Run{ptr, bytes, kind});
+  const uint32_t run = (uint32_t)runs.size() - 1;
+  in_use[kind] += bytes;                                           // (give_back takes it off again)
+  give_back(run, ptr, bytes);
+  return run;
+}
+
+bool PoolExtents::take(int kind, size_t bytes, char** ptr_out, uint32_t* run_out) {
+  auto& F = free_[kind];
+  for (size_t k = 0; k < F.size(); ++k)
+    if (F[k].bytes >= bytes) {
+      *ptr_out = F[k].ptr;
+      *run_out = F[k].run;
+      F[k].ptr += bytes;
+      F[k].bytes -= bytes;
+      if (!F[k].bytes) F.erase(F.begin() + k);
+      in_use[kind] += bytes;
+      return true;
+    }
+  return false;
+}
+
+void PoolExtents::give_back(uint32_t run, char* ptr, size_t bytes) {
+  const int kind = runs[run].kind;
+  in_use[kind] -= bytes;
+  auto& F = free_[kind];
+  size_t k = 0;
+  while (k < F.size() && F[k].ptr < ptr) ++k;
+  F.insert(F.begin() + k, Extent{ptr, bytes, run});
+  if (k + 1 < F.size() && F[k + 1].run == run && F[k].ptr + F[k].bytes == F[k + 1].ptr) { F[k].bytes += F[k + 1].bytes; F.erase(F.begin() + k + 1); }
+  if (k > 0 && F[k - 1].run == run && F[k - 1].ptr + F[k - 1].bytes == F[k].ptr) { F[k - 1].bytes += F[k].bytes; F.erase(F.begin() + k); }
+}
+
 bool tile_planes_aligned(const DevFrame& d) {
   auto al = [](const void* p, uintptr_t a) { return ((uintptr_t)p % a) == 0; };
   // the lane's occupancy bytes (4 / 2 / 1 for precision 1 / 2 / >= 4) must lie inside one aligned dword

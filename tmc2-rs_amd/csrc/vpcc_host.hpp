@@ -51,6 +51,20 @@ inline size_t chroma_elems(const vpcc_image_u16& a) {
   return (size_t)((a.height - 1) / 2) * a.cstride + (a.width - 1) / 2 + 1;
 }
 
+// Free space of a context's pool (vpcc_ctx_reserve): the classified slabs as RUNS — maximal stretches of granules of one
+// kind of VRAM region — and per kind a list of free extents, sorted by address, coalesced within a run (never across a
+// change of kind or of slab).  Pure host logic, no HIP: fuzzed under ASan/UBSan by tests/fuzz_plan.cpp.
+struct PoolExtents {
+  struct Run { char* ptr; size_t bytes; int kind; };
+  struct Extent { char* ptr; size_t bytes; uint32_t run; };
+  std::vector<Run> runs;
+  std::vector<Extent> free_[2];
+  size_t in_use[2] = {0, 0};
+  uint32_t add_run(char* ptr, size_t bytes, int kind);            // a new run, all of it free; returns its index
+  bool take(int kind, size_t bytes, char** ptr_out, uint32_t* run_out);   // first fit; false: no extent of that kind is big enough
+  void give_back(uint32_t run, char* ptr, size_t bytes);          // exactly what take() handed out
+};
+
 // Alignment preconditions of the tile kernel's vector loads for the planes as the kernels will see
 // them (device pointers and strides): 8-B aligned luma rows, 4-B aligned chroma pairs.
 bool tile_planes_aligned(const DevFrame& d);

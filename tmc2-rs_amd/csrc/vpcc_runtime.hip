@@ -51,10 +51,7 @@ struct vpcc_ctx {
   struct Pool {
     static constexpr size_t kGranule = size_t(1) << 30;
     std::vector<void*> slabs;                            // the allocations (one; two when the first lay in one kind only)
-    struct Run { char* ptr; size_t bytes; int kind; };   // maximal stretches of granules of one kind inside a slab
-    std::vector<Run> runs;
-    struct Extent { char* ptr; size_t bytes; uint32_t run; };
-    std::vector<Extent> free_[2];                        // by kind, sorted by address, coalesced within a run
+    PoolExtents space;                                   // runs of one kind inside the slabs and the free extents (vpcc_host.cpp)
     vpcc_pool_info info{};
     bool reserved() const { return !slabs.empty(); }
   } pool;
@@ -303,7 +300,7 @@ void retire_pool(vpcc_ctx* ctx) {
   std::lock_guard<std::mutex> lock(ctx->pool_mutex);
   vpcc_ctx::Pool& P = ctx->pool;
   if (!P.reserved()) return;
-  if (P.info.in_use[0] == 0 && P.info.in_use[1] == 0) {          // every gof of the context is gone: the pool is whole
+  if (P.space.in_use[0] == 0 && P.space.in_use[1] == 0) {          // every gof of the context is gone: the pool is whole
     std::lock_guard<std::mutex> keep(g_kept_pools_mutex);
     g_kept_pools.emplace_back(ctx->device, std::move(P));
   } else {
@@ -316,29 +313,6 @@ void retire_pool(vpcc_ctx* ctx) {
 // hipFree cost milliseconds and hipFree synchronises the whole device, which would stall a GOF pipeline.
 constexpr size_t kBlockCacheEntries = 8;
 
-void pool_insert_free(vpcc_ctx::Pool& P, uint32_t run, char* ptr, size_t bytes) {
-  auto& F = P.free_[P.runs[run].kind];
-  size_t k = 0;
-  while (k < F.size() && F[k].ptr < ptr) ++k;
-  F.insert(F.begin() + k, vpcc_ctx::Pool::Extent{ptr, bytes, run});
-  if (k + 1 < F.size() && F[k + 1].run == run && F[k].ptr + F[k].bytes == F[k + 1].ptr) { F[k].bytes += F[k + 1].bytes; F.erase(F.begin() + k + 1); }
-  if (k > 0 && F[k - 1].run == run && F[k - 1].ptr + F[k - 1].bytes == F[k].ptr) { F[k - 1].bytes += F[k].bytes; F.erase(F.begin() + k); }
-}
-
-bool pool_take(vpcc_ctx::Pool& P, int kind, size_t bytes, vpcc_ctx::Block* out) {
-  auto& F = P.free_[kind];
-  for (size_t k = 0; k < F.size(); ++k)
-    if (F[k].bytes >= bytes) {
-      *out = vpcc_ctx::Block{F[k].ptr, bytes, true, F[k].run};
-      F[k].ptr += bytes;
-      F[k].bytes -= bytes;
-      if (!F[k].bytes) F.erase(F.begin() + k);
-      P.info.in_use[kind] += bytes;
-      return true;
-    }
-  return false;
-}
-
 // A block of `bytes` for part `part` of a gof: from the pool's home `part` (then from the other home), else an
 // allocation of its own (from the context's cache of such blocks when one fits).
 int acquire_block(vpcc_ctx* ctx, int part, size_t bytes, vpcc_ctx::Block* out) {
@@ -346,11 +320,15 @@ int acquire_block(vpcc_ctx* ctx, int part, size_t bytes, vpcc_ctx::Block* out) {
   std::lock_guard<std::mutex> lock(ctx->pool_mutex);
   if (ctx->pool.reserved()) {
     const int want = ctx->pool.info.kinds > 1 ? part % 2 : 0;
-    for (int t = 0; t < 2; ++t)
-      if (pool_take(ctx->pool, (want + t) % 2, bytes, out)) {
+    for (int t = 0; t < 2; ++t) {
+      char* p = nullptr;
+      uint32_t run = 0;
+      if (ctx->pool.space.take((want + t) % 2, bytes, &p, &run)) {
+        *out = vpcc_ctx::Block{p, bytes, true, run};
         if (t) ctx->pool.info.other_home++;
         return VPCC_OK;
       }
+    }
     ctx->pool.info.fallbacks++;
   }
   auto& cache = ctx->block_cache;
@@ -375,8 +353,7 @@ void release_block(vpcc_ctx* ctx, vpcc_ctx::Block& B) {      // all work on the 
   if (!B.ptr) return;
   std::lock_guard<std::mutex> lock(ctx->pool_mutex);
   if (B.pooled) {
-    ctx->pool.info.in_use[ctx->pool.runs[B.run].kind] -= B.bytes;
-    pool_insert_free(ctx->pool, B.run, (char*)B.ptr, B.bytes);
+    ctx->pool.space.give_back(B.run, (char*)B.ptr, B.bytes);
   } else if (ctx->block_cache.size() < kBlockCacheEntries) {
     ctx->block_cache.push_back(B);
   } else {
@@ -473,8 +450,7 @@ extern "C" int vpcc_ctx_reserve(vpcc_ctx* ctx, uint64_t bytes, vpcc_pool_info* o
     for (size_t j = 0; j < kind.size();) {                    // runs of one kind -> free extents
       size_t e = j;
       while (e < kind.size() && kind[e] == kind[j]) ++e;
-      P.runs.push_back(vpcc_ctx::Pool::Run{(char*)slab + j * G, (e - j) * G, (int)kind[j]});
-      pool_insert_free(P, (uint32_t)P.runs.size() - 1, (char*)slab + j * G, (e - j) * G);
+      P.space.add_run((char*)slab + j * G, (e - j) * G, (int)kind[j]);
       P.info.bytes_of_kind[kind[j]] += (e - j) * G;
       j = e;
     }
@@ -541,6 +517,8 @@ extern "C" int vpcc_ctx_pool_info(vpcc_ctx* ctx, vpcc_pool_info* out) {
   if (!ctx || !out) return VPCC_ERR_INVALID_ARG;
   std::lock_guard<std::mutex> lock(ctx->pool_mutex);
   *out = ctx->pool.info;
+  out->in_use[0] = ctx->pool.space.in_use[0];
+  out->in_use[1] = ctx->pool.space.in_use[1];
   return VPCC_OK;
 }
 
