@@ -100,7 +100,7 @@ struct DevFrame {
 // min patch index != max patch index) is count * sp2 != sp * sp — equality in Cauchy-Schwarz holds exactly when all
 // patch indices are equal; count < 2^22, index < 2^16: both sides stay below 2^60.
 struct SmoothCell {
-  uint32_t count;
+  uint32_t count;       // ... with kSmoothCountMixed above it once k_smooth_mark has seen the cell: the filters read the first 16 bytes only
   uint32_t s[3];        // coordinate sums (geometry) or R,G,B sums (colour)
   uint64_t sp2;         // sum of squared patch indices
   uint32_t sp;          // sum of patch indices
@@ -108,7 +108,8 @@ struct SmoothCell {
                         // (k_smooth_mark, k_smooth_moved_mark; the statistics kernel adds 0 here)
 };
 static_assert(sizeof(SmoothCell) == 32, "SmoothCell is 32 B");
-constexpr uint32_t kSmoothMixed = 1u, kSmoothPainted = 2u;
+constexpr uint32_t kSmoothMixed = 1u, kSmoothPainted = 2u, kSmoothMovedHere = 4u;   // (a moved point left or entered the cell: k_smooth_moved_mark)
+constexpr uint32_t kSmoothCountMixed = 1u << 31;
 // 65 537 x 65 535 < 2^32: up to this many points in a cell no sum of 16-bit values (coordinates, patch indices) leaves its 32 bits
 constexpr uint32_t kSmoothCellMaxPoints = 65537u;
 // DevFrame::error_flag bits
@@ -126,30 +127,41 @@ static_assert(sizeof(SmoothColorCell) == 16, "SmoothColorCell is 16 B");
 #define VPCC_HD
 #endif
 // Scratch of the smoothing filters for a chunk of frames: per frame a dense grid of w^3 cells (all-zero between
-// launches) and the cell index of every point as the statistics kernel saw it (the geometry filter moves
-// points in place, so the cells to clear afterwards cannot be recomputed from the positions).
-constexpr uint32_t kSmoothListLen = 16, kSmoothNoCell = 0xFFFFFFFFu, kSmoothListOverflow = 0xFFFFFFFEu;
+// launches), the neighbourhood flags, and the list of the cells every chunk of 256 consecutive points touched (the
+// geometry filter moves points in place, so the cells to clear afterwards cannot be recomputed from the positions).
+constexpr uint32_t kSmoothListSpan = 1024;        // consecutive points (four chunks of 256: one wave of the statistics kernel) per cell list
+constexpr uint32_t kSmoothListLen = 1024;         // entries reserved per list: one per point at worst; a few dozen are used
 struct SmoothGrid {
-  unsigned char* base;        // frame slot j at base + j * slot_bytes: [w^3 cells | w^3 flag bytes], all-zero between launches
-  size_t slot_bytes;
-  size_t flags_offset;        // bytes from the slot's start to its flags
-  uint32_t* key_base;         // cell indices of frame slot j at key_base + j * key_stride (their own allocation: no zero invariant);
-  size_t key_stride;          //   written only for the waves (64 consecutive points) whose cells do not fit their list
-  uint32_t* list_base;        // cell lists of frame slot j at list_base + j * list_stride: kSmoothListLen entries per wave of 64
-  size_t list_stride;         //   points — the distinct cells the wave's points fall into, kSmoothNoCell where unused; or
-                              //   kSmoothListOverflow in entry 0: the cells of these 64 points are in the key array instead
+  unsigned char* base;        // frame slot j at base + j * slot_bytes: [w^3 cells | (w + 1)^3 + w^3 flag bytes | w^3 colour cells],
+  size_t slot_bytes;          //   all-zero between launches
+  size_t flags_offset;        // bytes from the slot's start to its flags: one per 2x2x2 neighbourhood, named by its lower
+                              //   corner + 1 in [0, w]^3 — "one of these eight cells mixes patches"
+  size_t near_offset;         //   ... and to w^3 more, one per cell: "one of the 27 cells around this one mixes patches"
+  uint32_t* list_base;        // cell lists of frame slot j at list_base + j * list_stride: kSmoothListLen entries per span of points —
+  size_t list_stride;         //   the cells the span's points fall into (their own allocation: no zero invariant)
+  uint32_t* count_base;       //   ... and how many entries each list holds (frame slot j at count_base + j * count_stride)
+  size_t count_stride;
+  uint32_t* flag_base;        //   ... and whether any of its cells has a mixed cell next to it (k_smooth_spans; same stride)
+  uint64_t* painted_base;     //   ... and which of its entries k_smooth_mark painted flags for: a bit per entry (frame slot j at
+  size_t painted_stride;      //   painted_base + j * painted_stride)
   size_t color_offset;        // both filters in one pass: bytes from the slot's start to its w^3 colour cells (else 0)
-  uint64_t* moved_base;       //   ... which points the geometry filter moved: one bit per point, a 64-bit word per wave of 64
+  uint64_t* moved_base;       //   ... which points the geometry filter moved: one bit per point, a 64-bit word per 64
   size_t moved_stride;        //   points (frame slot j at + j * moved_stride; zeroed by vpcc_gof_smooth before every pass),
-  uint32_t* oldkey_base;      //   and the cell a moved point LEFT if it changed cell (frame slot j at + j * key_stride; written
-                              //   for those points only)
+  uint32_t* oldkey_base;      //   and the cell a moved point was counted in (frame slot j at + j * oldkey_stride; written
+  size_t oldkey_stride;       //   for those points only)
+  uint64_t* moved_painted_base;   // ... and which moved points k_smooth_moved_mark painted flags for, around the cell they left /
+                              //   entered: two words per word of moved bits (frame slot j at + j * 2 * moved_stride)
   VPCC_HD SmoothCell* cells(uint32_t j) const { return reinterpret_cast<SmoothCell*>(base + j * slot_bytes); }
   VPCC_HD SmoothColorCell* color_cells(uint32_t j) const { return reinterpret_cast<SmoothColorCell*>(base + j * slot_bytes + color_offset); }
   VPCC_HD uint64_t* moved(uint32_t j) const { return moved_base + j * moved_stride; }
-  VPCC_HD uint32_t* old_keys(uint32_t j) const { return oldkey_base + j * key_stride; }
+  VPCC_HD uint32_t* old_keys(uint32_t j) const { return oldkey_base + j * oldkey_stride; }
   VPCC_HD unsigned char* flags(uint32_t j) const { return base + j * slot_bytes + flags_offset; }
-  VPCC_HD uint32_t* keys(uint32_t j) const { return key_base + j * key_stride; }
+  VPCC_HD unsigned char* near(uint32_t j) const { return base + j * slot_bytes + near_offset; }
   VPCC_HD uint32_t* lists(uint32_t j) const { return list_base + j * list_stride; }
+  VPCC_HD uint32_t* list_counts(uint32_t j) const { return count_base + j * count_stride; }
+  VPCC_HD uint32_t* span_flags(uint32_t j) const { return flag_base + j * count_stride; }
+  VPCC_HD uint64_t* painted(uint32_t j) const { return painted_base + j * painted_stride; }
+  VPCC_HD uint64_t* moved_painted(uint32_t j) const { return moved_painted_base + j * 2 * moved_stride; }
 };
 
 void launch_smooth_stats(const DevFrame* d_frames, uint32_t first, uint32_t count, uint32_t max_points, SmoothGrid sg,
@@ -162,10 +174,11 @@ void launch_smooth_apply_color(const DevFrame* d_frames, uint32_t first, uint32_
                                SmoothGrid sg, uint32_t w, uint32_t G, uint32_t Ts, uint32_t Td, bool both, void* stream);
 void launch_smooth_moved(const DevFrame* d_frames, uint32_t first, uint32_t count, uint32_t max_points, SmoothGrid sg,
                          uint32_t w, uint32_t G, void* stream);
+void launch_smooth_spans(const DevFrame* d_frames, uint32_t first, uint32_t count, uint32_t max_points, SmoothGrid sg, void* stream);
 void launch_smooth_mark(const DevFrame* d_frames, uint32_t first, uint32_t count, uint32_t max_points, SmoothGrid sg,
                         uint32_t w, void* stream);
 void launch_smooth_clear(const DevFrame* d_frames, uint32_t first, uint32_t count, uint32_t max_points, SmoothGrid sg,
-                         uint32_t w, bool both, void* stream);
+                         uint32_t w, uint32_t G, bool both, void* stream);
 
 // Work lists of the tile kernel for frames [first, first + count): which virtual blocks own their canvas block and hold
 // occupancy (generate_block_to_patch_from_occupancy_map_video, src/codec.rs:205-250), in emission order.  Needs the frames'

@@ -115,8 +115,8 @@ struct vpcc_gof {
   void* smooth_grid = nullptr;         // smoothing scratch (on demand): dense cell grids + touched lists + list lengths
   size_t smooth_bytes = 0;
   bool smooth_clean = false;           // the scratch is all-zero (the invariant between launches)
-  void* smooth_keys = nullptr;         // cell index of every point of every frame (capacity words per frame), then the cell lists
-  void* smooth_moved = nullptr;        // both filters in one pass: which points moved (a bit each), and the cell each left
+  void* smooth_keys = nullptr;         // the cell lists of every chunk of 256 points of every frame, then their lengths
+  void* smooth_moved = nullptr;        // both filters in one pass: which points moved (a bit each), and the cell each was counted in
 };
 
 namespace {
@@ -658,9 +658,9 @@ int gof_create_impl(vpcc_ctx* ctx, const vpcc_frame_desc* frames, uint32_t n_fra
     o.patch_items = L.take(sizeof(TileItem) * std::max<size_t>(P.patch_items.size(), 1));
     o.vb_count = L.take(sizeof(uint32_t) * std::max<size_t>(P.vblocks.size(), 1));
     o.vb_offset = L.take(sizeof(uint32_t) * std::max<size_t>(P.vblocks.size(), 1));
-    o.xyz = takek(i, 1, 0, sizeof(vpcc_point3) * cap);                    // (output block: positions, colours, partition in
-    o.rgb = F.attribute_count ? takek(i, 1, 1, sizeof(vpcc_color3) * cap) : 0;   //  this order — the smoothing kernels' 8-byte loads
-    o.pidx = (gof_flags & VPCC_GOF_WANT_PATCH_INDEX) ? takek(i, 1, 0, sizeof(uint16_t) * cap) : 0;   // read a few bytes past an element)
+    o.xyz = takek(i, 1, 0, sizeof(vpcc_point3) * (cap + 4));                    // (output block: positions, colours, partition; + 4:
+    o.rgb = F.attribute_count ? takek(i, 1, 1, sizeof(vpcc_color3) * (cap + 4)) : 0;   //  the smoothing kernels read whole quads of points,
+    o.pidx = (gof_flags & VPCC_GOF_WANT_PATCH_INDEX) ? takek(i, 1, 0, sizeof(uint16_t) * (cap + 4)) : 0;   // so a quad that begins inside an array must end in memory)
     if (own_planes) {
       // (+ 16: a plane pulled by the ingest kernel starts 0 or 8 bytes behind its 256-byte boundary — where its source does modulo 16)
       auto plane = [&](int sub, size_t bytes) { ingest_bound += bytes / kIngestPieceBytes + 1; return takek(i, 0, sub, bytes + 16); };
@@ -1230,20 +1230,30 @@ extern "C" int vpcc_gof_smooth(vpcc_gof* g, uint32_t first, uint32_t count, cons
     // between launches (k_smooth_clear restores what a launch touched), so it is cleared only when it is
     // (re)allocated or after a failed launch.
     SmoothGrid sg{};
+    const size_t corners = (size_t)(w + 1) * (w + 1) * (w + 1);
     sg.flags_offset = align_up(cells * sizeof(SmoothCell), 256);
-    sg.color_offset = both ? align_up(sg.flags_offset + cells, 256) : 0;
-    sg.slot_bytes = align_up(both ? sg.color_offset + cells * sizeof(SmoothColorCell) : sg.flags_offset + cells, 256);
-    sg.key_stride = align_up(g->capacity, 4);                // 16-byte loads of four cell indices
-    sg.list_stride = align_up((g->capacity + 63) / 64 * kSmoothListLen, 64);
-    if (!g->smooth_keys) HIP_TRY(ctx, hipMalloc(&g->smooth_keys, sizeof(uint32_t) * (sg.key_stride + sg.list_stride) * g->n_frames));
-    sg.key_base = (uint32_t*)g->smooth_keys;
-    sg.list_base = sg.key_base + sg.key_stride * g->n_frames;
+    sg.near_offset = align_up(sg.flags_offset + corners, 256);
+    sg.color_offset = both ? align_up(sg.near_offset + cells, 256) : 0;
+    sg.slot_bytes = align_up(both ? sg.color_offset + cells * sizeof(SmoothColorCell) : sg.near_offset + cells, 256);
+    // per span of 1 024 points: a cell list (as many entries reserved, a few dozen used) and its length
+    const size_t chunks = (g->capacity + kSmoothListSpan - 1) / kSmoothListSpan + 1;
+    sg.list_stride = chunks * kSmoothListLen;
+    sg.count_stride = align_up(chunks, 64);
+    sg.painted_stride = chunks * (kSmoothListLen / 64);
+    if (!g->smooth_keys)
+      HIP_TRY(ctx, hipMalloc(&g->smooth_keys, (sizeof(uint32_t) * (sg.list_stride + 2 * sg.count_stride) + sizeof(uint64_t) * sg.painted_stride) * g->n_frames));
+    sg.painted_base = (uint64_t*)g->smooth_keys;
+    sg.list_base = (uint32_t*)(sg.painted_base + sg.painted_stride * g->n_frames);
+    sg.count_base = sg.list_base + sg.list_stride * g->n_frames;
+    sg.flag_base = sg.count_base + sg.count_stride * g->n_frames;
     if (both) {
-      sg.moved_stride = align_up((g->capacity + 63) / 64, 32);
+      sg.moved_stride = align_up((g->capacity + 63) / 64 + 4, 32);
+      sg.oldkey_stride = align_up(g->capacity, 4);
       if (!g->smooth_moved)
-        HIP_TRY(ctx, hipMalloc(&g->smooth_moved, (sizeof(uint64_t) * sg.moved_stride + sizeof(uint32_t) * sg.key_stride) * g->n_frames));
+        HIP_TRY(ctx, hipMalloc(&g->smooth_moved, (sizeof(uint64_t) * 3 * sg.moved_stride + sizeof(uint32_t) * sg.oldkey_stride) * g->n_frames));
       sg.moved_base = (uint64_t*)g->smooth_moved;
-      sg.oldkey_base = (uint32_t*)(sg.moved_base + sg.moved_stride * g->n_frames);
+      sg.moved_painted_base = sg.moved_base + sg.moved_stride * g->n_frames;
+      sg.oldkey_base = (uint32_t*)(sg.moved_painted_base + 2 * sg.moved_stride * g->n_frames);
     }
     // (VPCC_SMOOTH_SCRATCH_LIMIT_MB: the limit in MB, for tests that want several chunks out of a small gof)
     const char* limit_env = getenv("VPCC_SMOOTH_SCRATCH_LIMIT_MB");
@@ -1279,6 +1289,7 @@ extern "C" int vpcc_gof_smooth(vpcc_gof* g, uint32_t first, uint32_t count, cons
       T.end();
       T.begin(kNames[1][tag]);
       launch_smooth_mark(g->d_frames, c0, c, max_points, sg, w, s);
+      launch_smooth_spans(g->d_frames, c0, c, max_points, sg, s);     // (timed with the marking: which spans of points have anything to do)
       T.end();
       if (geo) {
         T.begin("k_smooth_apply_geometry");
@@ -1288,6 +1299,7 @@ extern "C" int vpcc_gof_smooth(vpcc_gof* g, uint32_t first, uint32_t count, cons
       if (both) {
         T.begin("k_smooth_moved");
         launch_smooth_moved(g->d_frames, c0, c, max_points, sg, w, G, s);
+        launch_smooth_spans(g->d_frames, c0, c, max_points, sg, s);   // (cells may have become mixed)
         T.end();
       }
       if (!geo || both) {
@@ -1297,7 +1309,7 @@ extern "C" int vpcc_gof_smooth(vpcc_gof* g, uint32_t first, uint32_t count, cons
         T.end();
       }
       T.begin(kNames[2][tag]);
-      launch_smooth_clear(g->d_frames, c0, c, max_points, sg, w, both, s);
+      launch_smooth_clear(g->d_frames, c0, c, max_points, sg, w, G, both, s);
       T.end();
       HIP_TRY(ctx, hipGetLastError());
       g->smooth_clean = true;
