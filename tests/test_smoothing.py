@@ -103,6 +103,113 @@ def test_hip_smoothing_matches_spec(frames, params):
     ctx.close()
 
 
+def _check_against_spec(g, before, bitdepth, params):
+    for i, b in enumerate(before):
+        after = g.download(i)
+        exp_xyz = b["xyz"]
+        if params.get("grid_size"):
+            exp_xyz = ob.spec_smooth_geometry(b["xyz"], b["patch_index"], bitdepth, params["grid_size"], params["threshold"])
+        assert np.array_equal(after["xyz"], exp_xyz), i
+        exp_rgb = b["rgb"]
+        if params.get("color_grid_size"):
+            exp_rgb = ob.spec_smooth_color(exp_xyz, b["rgb"], b["patch_index"], bitdepth, params["color_grid_size"],
+                                           params["color_threshold_smoothing"], params["color_threshold_difference"])
+        assert np.array_equal(after["rgb"], exp_rgb), i
+    return exp_xyz, exp_rgb
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("bitdepth,params", [
+    # grid sizes that are no power of two: the cell coordinate by the float reciprocal (G < 128) ...
+    (10, dict(grid_size=6, threshold=1, color_grid_size=10, color_threshold_smoothing=4, color_threshold_difference=90)),
+    (10, dict(grid_size=12, threshold=2, color_grid_size=12, color_threshold_smoothing=6, color_threshold_difference=120)),   # one pass for both
+    # ... and by the integer division (G >= 128): seven cells per axis, thousands of points per cell
+    (10, dict(grid_size=160, threshold=0, color_grid_size=160, color_threshold_smoothing=0, color_threshold_difference=765)),
+    # one filter at a time
+    (10, dict(grid_size=8, threshold=2)),
+    (10, dict(color_grid_size=8, color_threshold_smoothing=3, color_threshold_difference=150)),
+    (10, dict(color_grid_size=5, color_threshold_smoothing=3, color_threshold_difference=150)),
+    # a finer grid than the content needs (11 bits: 256 cells per axis, 0.8 GB of cells per frame)
+    (11, dict(grid_size=8, threshold=1, color_grid_size=8, color_threshold_smoothing=5, color_threshold_difference=100)),
+])
+def test_hip_smoothing_grids_and_modes(bitdepth, params):
+    from tmc2rs import recon
+    fr = [cases.overlapping_3d_frame(i) for i in range(2)]
+    ctx = recon.Context(0)
+    g = ctx.gof(fr, flags=_abi.VPCC_GOF_WANT_PATCH_INDEX)
+    g.reconstruct()
+    before = [g.download(i, want_patch_index=True) for i in range(len(fr))]
+    g.smooth(bitdepth, **params)
+    xyz, rgb = _check_against_spec(g, before, bitdepth, params)
+    assert np.any(xyz != before[-1]["xyz"]) or np.any(rgb != before[-1]["rgb"])          # the case exercises a filter
+    g.close()
+    ctx.close()
+
+
+def _frame_of_k_points(k):
+    """k points in one grid cell: occupancy precision 1, the first ceil(k / 2) pixels of the collapsed frame's blocks
+    occupied (two points per pixel; an odd k: the last pixel's two layers are equal, and the second is dropped as a
+    duplicate, codec.rs:432-440)."""
+    f = _collapsed_frame(4, prec=1)
+    occ = np.zeros_like(f["occupancy"])
+    g0, g1 = f["geometry"][0].copy(), f["geometry"][1].copy()
+    bw = 320 // 16
+    for t in range((k + 1) // 2):
+        blk, within = divmod(t, 256)
+        y, x = (blk // bw) * 16 + within // 16, (blk % bw) * 16 + within % 16
+        occ[y, x] = 1
+        if k % 2 and t == (k + 1) // 2 - 1:
+            g1[y, x] = g0[y, x]
+    f["occupancy"], f["geometry"] = occ, [g0, g1]
+    return f
+
+
+@pytest.mark.gpu
+def test_hip_smoothing_frames_of_a_few_points():
+    """The kernels read four points per lane: frames of 0 ... 9 points, and of 255 ... 257, 511 ... 513 (a wave's chunk of
+    256 points, a filter wave's 512) and 1 023 ... 1 025 points (a cell list's span); beyond 512 points a second patch
+    shares the cell."""
+    from tmc2rs import recon
+    ctx = recon.Context(0)
+    params = dict(grid_size=8, threshold=0, color_grid_size=8, color_threshold_smoothing=0, color_threshold_difference=765)
+    wanted = [0, 1, 2, 3, 4, 5, 7, 9, 255, 256, 257, 511, 512, 513, 1023, 1024, 1025]
+    fr = [_frame_of_k_points(k) for k in wanted]
+    g = ctx.gof(fr, flags=_abi.VPCC_GOF_WANT_PATCH_INDEX)
+    g.reconstruct()
+    before = [g.download(i, want_patch_index=True) for i in range(len(fr))]
+    assert [b["n"] for b in before] == wanted
+    g.smooth(10, **params)
+    xyz, _ = _check_against_spec(g, before, 10, params)
+    assert np.any(xyz != before[-1]["xyz"])
+    g.close()
+    ctx.close()
+
+
+@pytest.mark.gpu
+def test_hip_smoothing_many_patches_in_a_wave():
+    """Patches of one block with a few points each: a wave's 256 points hold dozens of patches (the statistics kernel works
+    on a chunk patch by patch), all in the same handful of cells (every cell mixes patches)."""
+    from tmc2rs import recon
+    f = _collapsed_frame(120)
+    occ = np.zeros_like(f["occupancy"])
+    occ[::4, ::4] = 1                                  # one occupancy sample (32 points) per block
+    f["occupancy"] = occ
+    p = f["patches"].copy()
+    p["u1"] = 101 + (np.arange(len(p)) % 3) * 5        # two neighbouring cells, shared by dozens of patches each
+    f["patches"] = p
+    ctx = recon.Context(0)
+    params = dict(grid_size=8, threshold=0, color_grid_size=8, color_threshold_smoothing=0, color_threshold_difference=765)
+    g = ctx.gof([f], flags=_abi.VPCC_GOF_WANT_PATCH_INDEX)
+    g.reconstruct()
+    before = [g.download(0, want_patch_index=True)]
+    assert before[0]["n"] == 120 * 32 and len(np.unique(before[0]["patch_index"][:256])) == 8
+    g.smooth(10, **params)
+    xyz, _ = _check_against_spec(g, before, 10, params)
+    assert np.any(xyz != before[0]["xyz"])
+    g.close()
+    ctx.close()
+
+
 @pytest.mark.gpu
 def test_smoothing_in_chunks_of_frames(monkeypatch):
     """A gof whose grids exceed the scratch limit (16 GiB; 11-bit content with grid 8 needs 0.8 GB per frame) is smoothed
@@ -135,10 +242,10 @@ def test_smoothing_in_chunks_of_frames(monkeypatch):
     ctx.close()
 
 
-def _collapsed_frame(n_blocks):
+def _collapsed_frame(n_blocks, prec=4):
     """Every patch is one fully occupied block whose 512 points (lod 0: all pixels share the tangent and bitangent
     coordinate; two depths) fall into ONE grid cell."""
-    f = synth.make_frame(320, 256, 4, 16, seed=5, max_side=2, cover_target=0.5)
+    f = synth.make_frame(320, 256, prec, 16, seed=5, max_side=2, cover_target=0.5)
     bw = 320 // 16
     p = np.zeros(n_blocks, dtype=_abi.PATCH_DTYPE)
     p["u0"] = np.arange(n_blocks) % bw

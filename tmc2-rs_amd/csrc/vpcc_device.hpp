@@ -160,6 +160,8 @@ struct SmoothGrid {
   VPCC_HD uint32_t* lists(uint32_t j) const { return list_base + j * list_stride; }
   VPCC_HD uint32_t* list_counts(uint32_t j) const { return count_base + j * count_stride; }
   VPCC_HD uint32_t* span_flags(uint32_t j) const { return flag_base + j * count_stride; }
+  // "a cell has become mixed behind the geometry filter": the stride's last word (the lists need one word less at least)
+  VPCC_HD uint32_t* frame_dirty(uint32_t j) const { return flag_base + j * count_stride + (count_stride - 1); }
   VPCC_HD uint64_t* painted(uint32_t j) const { return painted_base + j * painted_stride; }
   VPCC_HD uint64_t* moved_painted(uint32_t j) const { return moved_painted_base + j * 2 * moved_stride; }
 };
@@ -174,7 +176,8 @@ void launch_smooth_apply_color(const DevFrame* d_frames, uint32_t first, uint32_
                                SmoothGrid sg, uint32_t w, uint32_t G, uint32_t Ts, uint32_t Td, bool both, void* stream);
 void launch_smooth_moved(const DevFrame* d_frames, uint32_t first, uint32_t count, uint32_t max_points, SmoothGrid sg,
                          uint32_t w, uint32_t G, void* stream);
-void launch_smooth_spans(const DevFrame* d_frames, uint32_t first, uint32_t count, uint32_t max_points, SmoothGrid sg, void* stream);
+void launch_smooth_spans(const DevFrame* d_frames, uint32_t first, uint32_t count, uint32_t max_points, SmoothGrid sg, bool again,
+                         void* stream);
 void launch_smooth_mark(const DevFrame* d_frames, uint32_t first, uint32_t count, uint32_t max_points, SmoothGrid sg,
                         uint32_t w, void* stream);
 void launch_smooth_clear(const DevFrame* d_frames, uint32_t first, uint32_t count, uint32_t max_points, SmoothGrid sg,

@@ -89,6 +89,12 @@ __device__ __forceinline__ void unpack_rgb(const uint32_t (&c)[3], uint32_t (&rg
   rgb[3] = c[2] >> 8;
 }
 
+// value of the lane's partner inside its quad of four lanes (DPP quad_perm)
+template <int kCtrl>
+__device__ __forceinline__ uint32_t qperm(uint32_t v) {
+  return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, kCtrl, 0xF, 0xF, false);
+}
+
 // ---- statistics ----------------------------------------------------------------------------------------------------
 // mode 0: sums of coordinates (geometry); mode 1: sums of R,G,B (colour); mode 2: both (colour sums into the colour cells).
 // Points arrive in emission order, so the 1 024 points of a wave's kStatChunks consecutive chunks fall into a few dozen
@@ -97,9 +103,9 @@ __device__ __forceinline__ void unpack_rgb(const uint32_t (&c)[3], uint32_t (&rg
 // multiple of four cells apart in every axis); the table holds cells of one patch at a time and lives as long as it can:
 //   1. a lane adds up, in registers, those of its four points that share a cell — pairwise (1 into 0, 3 into 2), then
 //      2 into 0: A A A A becomes one LEADER, A A B B two, the rest stay on their own (a cell may have several leaders);
-//   2. every leader looks at its slot: if it is free the leader writes its cell there, and all read again (of the leaders
-//      that write at the same time one wins): a leader whose cell the slot holds now has it, the others stay PENDING;
-//   3. the leaders that have their slot add their sums to it with LDS atomics (seven words: x, y, z, count, R, G, B);
+//   2. every leader swaps its cell into its slot if the slot is free (LDS compare-and-swap), and all look at what the slot
+//      holds now: a leader whose cell it is has the slot, the others stay PENDING;
+//   3. the leaders that have their slot add their sums to it with LDS atomics (six words: x, y, z, count + R << 16, G, B);
 //   4. while leaders are pending, the table is flushed — which frees every slot — and they try again (at least one per
 //      contended slot succeeds each time); it is flushed for good after the wave's last chunk, and before points of
 //      another patch (a chunk that holds several patches is worked on patch by patch);
@@ -117,13 +123,14 @@ __device__ __forceinline__ void unpack_rgb(const uint32_t (&c)[3], uint32_t (&rg
 // wave-wide reductions for waves with a collision, 0.15-0.17 (it is the number of atomic REQUESTS that counts: the
 // elected lanes issuing four 8-byte atomics each was 3 x slower).
 struct StatTable {
-  uint32_t key[64];            // cell index of the slot's cell; all-ones: free
-  uint32_t acc[7][64];         // x, y, z, count, R, G, B
+  uint32_t key[128];           // [0, 64): cell index of the slot's cell, all-ones: free; [64, 128): a DUMP slot per lane —
+  uint32_t acc[5][128];        //   what a lane without a leader reads and "adds" to, so that nothing here needs a branch
+  uint64_t cnt_r[128];         // x, y, z, G, B | count + (R << 16): the red sum grows into the upper half
   uint32_t order[64];          // the occupied slots, lined up
 };
 constexpr uint32_t kFreeSlot = 0xFFFFFFFFu;                  // (cells < 2^32 - 1: vpcc_gof_smooth)
-// which of the seven words a mode keeps
-template <uint32_t kMode> constexpr uint32_t stat_words() { return kMode == 0 ? 0x0Fu : kMode == 1 ? 0x78u : 0x7Fu; }
+// which of the six words a mode keeps: x, y, z, G, B (bits 0-4), count + R (always)
+template <uint32_t kMode> constexpr uint32_t stat_words() { return kMode == 0 ? 0x07u : kMode == 1 ? 0x18u : 0x1Fu; }
 
 struct StatDst {
   SmoothCell* grid;
@@ -147,14 +154,15 @@ __device__ __forceinline__ void stats_flush(StatTable& T, const StatDst& dst, ui
     dst.list[m + rank] = own;
   }
   __builtin_amdgcn_wave_barrier();                           // (LDS operations of one wave execute in order)
-#ifndef VPCC_AB_NOFLUSH
   for (uint32_t base = 0; base < ncell; base += 16u) {
     const uint32_t j = base + (lane >> 2), t = lane & 3u;
     if (j < ncell) {
       const uint32_t sl = T.order[j];
       const uint32_t k = T.key[sl];
-      const uint32_t cnt = T.acc[3][sl];
-      const uint32_t s0 = T.acc[kMode == 1u ? 4 : 0][sl], s1 = T.acc[kMode == 1u ? 5 : 1][sl], s2 = T.acc[kMode == 1u ? 6 : 2][sl];
+      const uint64_t cr = T.cnt_r[sl];
+      const uint32_t cnt = (uint32_t)cr & 0xFFFFu;
+      const uint32_t s0 = kMode == 1u ? (uint32_t)(cr >> 16) : T.acc[0][sl];
+      const uint32_t s1 = T.acc[kMode == 1u ? 3 : 1][sl], s2 = T.acc[kMode == 1u ? 4 : 2][sl];
       const uint32_t sp = cnt * pl;
       const uint64_t val = t == 0 ? (uint64_t)cnt | ((uint64_t)s0 << 32)
                          : t == 1 ? (uint64_t)s1 | ((uint64_t)s2 << 32)
@@ -167,17 +175,18 @@ __device__ __forceinline__ void stats_flush(StatTable& T, const StatDst& dst, ui
       const uint32_t j = base + (lane >> 1), t = lane & 1u;
       if (j < ncell) {
         const uint32_t sl = T.order[j];
-        const uint64_t val = t == 0 ? (uint64_t)T.acc[3][sl] | ((uint64_t)T.acc[4][sl] << 32)        // {count, R}
-                                    : (uint64_t)T.acc[5][sl] | ((uint64_t)T.acc[6][sl] << 32);       // {G, B}
+        const uint64_t cr = T.cnt_r[sl];
+        const uint64_t val = t == 0 ? (cr & 0xFFFFull) | ((cr >> 16) << 32)                          // {count, R}
+                                    : (uint64_t)T.acc[3][sl] | ((uint64_t)T.acc[4][sl] << 32);       // {G, B}
         atomicAdd(reinterpret_cast<unsigned long long*>(dst.cgrid + T.key[sl]) + t, (unsigned long long)val);
       }
     }
-#endif
   __builtin_amdgcn_wave_barrier();
   if (occupied) {
     T.key[lane] = kFreeSlot;
+    T.cnt_r[lane] = 0ull;
 #pragma unroll
-    for (int q = 0; q < 7; ++q) if ((kWords >> q) & 1u) T.acc[q][lane] = 0u;
+    for (int q = 0; q < 5; ++q) if ((kWords >> q) & 1u) T.acc[q][lane] = 0u;
   }
   __builtin_amdgcn_wave_barrier();
   m += ncell;
@@ -189,6 +198,7 @@ __device__ __forceinline__ void stats_chunk(const QuadIn& in, uint32_t nvalid, c
                                             uint32_t& tpatch, uint32_t& m) {
   constexpr uint32_t kWords = stat_words<kMode>();
   constexpr uint32_t kLaneWords = kMode == 0 ? 0xFu : kMode == 1 ? 0x18u : 0x1Fu;     // in registers: x, y, z, count | R << 16, G | B << 16
+  static_assert(kSmoothListSpan <= 1024u, "count < 2^16 below the red sum; sums of 1 024 bytes in 32 bits");
   const uint32_t lane = threadIdx.x & 63u;
   uint32_t x[4], y[4], z[4];
   unpack_xyz(in.p, x, y, z);
@@ -239,27 +249,56 @@ __device__ __forceinline__ void stats_chunk(const QuadIn& in, uint32_t nvalid, c
     VPCC_JOIN(s32, 2, 3)
     VPCC_JOIN(s20, 0, 2)
 #undef VPCC_JOIN
+    // ... and neighbouring lanes whose first leaders share a cell: lane pairs, then pairs of pairs (the LDS serves the lanes of
+    // one slot one after the other; a CU has ONE LDS, and it is this kernel's busiest unit)
+    {
+      // (the neighbour's cell is fetched by every lane, before any condition: a DPP read under `pend[0] && ...` runs with the
+      // lanes without a leader switched off, and reads 0 from them — the index of a cell)
+      const uint32_t key1 = qperm<0xB1>(key[0]);                                // lane ^ 1
+      const bool same1 = pend[0] && key1 == key[0];
+#pragma unroll
+      for (int q = 0; q < 5; ++q) if ((kLaneWords >> q) & 1u) { const uint32_t o = qperm<0xB1>(W[0][q]); W[0][q] += (same1 && !(lane & 1u)) ? o : 0u; }
+      if (same1 && (lane & 1u)) pend[0] = false;
+      const uint32_t key2 = pend[0] ? key[0] : kFreeSlot;
+      const uint32_t key3 = qperm<0x4E>(key2);                                  // lane ^ 2 (lanes 0 and 2 of a quad: never given away above)
+      const bool same2 = pend[0] && key3 == key[0];
+#pragma unroll
+      for (int q = 0; q < 5; ++q) if ((kLaneWords >> q) & 1u) { const uint32_t o = qperm<0x4E>(W[0][q]); W[0][q] += (same2 && !(lane & 2u)) ? o : 0u; }
+      if (same2 && (lane & 2u)) pend[0] = false;
+    }
     for (;;) {
-      // 2. a slot each
+      // 2. a slot each: compare-and-swap "free -> my cell" (a lane without a leader does it to its dump slot), in the
+      // order of the points; then everybody looks at what the slot holds now
+      uint32_t at[4];
 #pragma unroll
-      for (int j = 0; j < 4; ++j)
-        if (pend[j] && T.key[slot[j]] == kFreeSlot) T.key[slot[j]] = key[j];
+      for (int j = 0; j < 4; ++j) {
+        at[j] = pend[j] ? slot[j] : 64u + lane;
+        if (j == 0) atomicCAS(&T.key[at[j]], kFreeSlot, key[j]);
+        else if (pend[j]) atomicCAS(&T.key[at[j]], kFreeSlot, key[j]);
+      }
       __builtin_amdgcn_wave_barrier();
-      // 3. add
+      // 3. add (a leader that did not get its slot: to the dump)
 #pragma unroll
-      for (int j = 0; j < 4; ++j)
-        if (pend[j] && T.key[slot[j]] == key[j]) {
-#ifndef VPCC_AB_NOADD
-          if (kWords & 1u) atomicAdd(&T.acc[0][slot[j]], W[j][0]);
-          if (kWords & 2u) atomicAdd(&T.acc[1][slot[j]], W[j][1]);
-          if (kWords & 4u) atomicAdd(&T.acc[2][slot[j]], W[j][2]);
-          atomicAdd(&T.acc[3][slot[j]], W[j][3] & 0xFFFFu);
-          if (kWords & 16u) atomicAdd(&T.acc[4][slot[j]], W[j][3] >> 16);
-          if (kWords & 32u) atomicAdd(&T.acc[5][slot[j]], W[j][4] & 0xFFFFu);
-          if (kWords & 64u) atomicAdd(&T.acc[6][slot[j]], W[j][4] >> 16);
-#endif
-          pend[j] = false;
+      for (int j = 0; j < 4; ++j) {
+        auto add = [&](uint32_t to) {
+          if (kWords & 1u) atomicAdd(&T.acc[0][to], W[j][0]);
+          if (kWords & 2u) atomicAdd(&T.acc[1][to], W[j][1]);
+          if (kWords & 4u) atomicAdd(&T.acc[2][to], W[j][2]);
+          atomicAdd(reinterpret_cast<unsigned long long*>(&T.cnt_r[to]), (unsigned long long)W[j][3]);
+          if (kWords & 8u) atomicAdd(&T.acc[3][to], W[j][4] & 0xFFFFu);
+          if (kWords & 16u) atomicAdd(&T.acc[4][to], W[j][4] >> 16);
+        };
+        if (j == 0) {                                         // every lane that kept its first leader: no branch
+          const bool hit = pend[j] && T.key[at[j]] == key[j];
+          add(hit ? at[j] : 64u + lane);
+          pend[j] = pend[j] && !hit;
+        } else if (pend[j]) {                                 // few lanes have one here
+          if (T.key[at[j]] == key[j]) {
+            add(at[j]);
+            pend[j] = false;
+          }
         }
+      }
       __builtin_amdgcn_wave_barrier();
       if (__ballot(pend[0] || pend[1] || pend[2] || pend[3]) == 0) break;
       // 4. somebody's slot is taken by another cell: deliver what the table holds, and again
@@ -281,8 +320,7 @@ __device__ __forceinline__ QuadIn load_stat_input(const DevFrame& f, uint32_t q,
 
 }  // namespace
 
-// A wave handles kStatChunks consecutive chunks — kSmoothListSpan points — with one table and one cell list, the next
-// chunk's quads fetched while the current one is worked on.
+// A wave handles kStatChunks consecutive chunks — kSmoothListSpan points — with one table and one cell list.
 constexpr uint32_t kStatChunks = kSmoothListSpan / 256u;
 template <uint32_t kMode, bool kPow2>
 __global__ __launch_bounds__(256) void k_smooth_stats(const DevFrame* __restrict__ frames, uint32_t first,
@@ -294,24 +332,28 @@ __global__ __launch_bounds__(256) void k_smooth_stats(const DevFrame* __restrict
   const uint32_t span = blockIdx.x * 4u + wave;                          // the wave's kSmoothListSpan points
   if (span * kSmoothListSpan >= n) return;
   StatTable& T = s_tab[wave];
-  T.key[lane] = kFreeSlot;
+  T.key[lane] = kFreeSlot; T.key[64u + lane] = 0u;
+  T.cnt_r[lane] = 0ull;
 #pragma unroll
-  for (int q = 0; q < 7; ++q) T.acc[q][lane] = 0u;
+  for (int q = 0; q < 5; ++q) T.acc[q][lane] = 0u;
   StatDst dst;
   dst.grid = sg.cells(blockIdx.y);
   dst.cgrid = sg.color_cells(blockIdx.y);
   dst.list = sg.lists(blockIdx.y) + (size_t)span * kSmoothListLen;
   uint32_t m = 0, tpatch = 0;
-  QuadIn cur = load_stat_input<kMode>(f, span * (kSmoothListSpan / 4u) + lane, n);
+  // All of the wave's points are fetched before the first is looked at: gfx9 counts loads and stores with ONE in-order
+  // counter, so a wait for a load issued while the table's atomics are in flight is a wait for those atomics (with the
+  // next chunk fetched during the current one, the kernel spent 37 % of its time in such waits).
+  QuadIn in[kStatChunks];
+#pragma unroll
+  for (uint32_t c = 0; c < kStatChunks; ++c) in[c] = load_stat_input<kMode>(f, (span * kStatChunks + c) * 64u + lane, n);
 #pragma unroll
   for (uint32_t c = 0; c < kStatChunks; ++c) {
     const uint32_t chunk = span * kStatChunks + c;
     if (chunk * 256u >= n) break;
-    const QuadIn nxt = c + 1u < kStatChunks ? load_stat_input<kMode>(f, (chunk + 1u) * 64u + lane, n) : QuadIn{};
     const uint32_t i0 = chunk * 256u + 4u * lane;
     const uint32_t nvalid = i0 >= n ? 0u : min(n - i0, 4u);
-    stats_chunk<kMode, kPow2>(cur, nvalid, gd, dst, T, tpatch, m);
-    cur = nxt;
+    stats_chunk<kMode, kPow2>(in[c], nvalid, gd, dst, T, tpatch, m);
   }
   stats_flush<kMode>(T, dst, tpatch, m, lane);
   if (lane == 0) sg.list_counts(blockIdx.y)[span] = m;
@@ -585,6 +627,7 @@ __global__ __launch_bounds__(256) void k_smooth_moved_mark(const DevFrame* __res
       if (mixed && !(c.mixed & kSmoothPainted)) {
         paint_flags(sg, blockIdx.y, key, gd.w, 1);
         painted[side] |= 1ull << b;
+        *sg.frame_dirty(blockIdx.y) = 1u;                       // the spans with something to do have to be found again
       }
       const uint32_t bits = (mixed ? kSmoothMixed : 0u) | ((mixed || (c.mixed & kSmoothPainted)) ? kSmoothPainted : 0u);
       if (bits != c.mixed) cell->mixed = bits;
@@ -654,7 +697,15 @@ __device__ __forceinline__ void smooth_apply_color_point(const DevFrame& f, uint
 
 // Which spans of kSmoothListSpan points have anything to do: those whose list holds a cell with a mixed cell among the
 // 27 around it — one span in six.  A wave sees to four lists, their loads issued together.
-__global__ __launch_bounds__(256) void k_smooth_spans(const DevFrame* __restrict__ frames, uint32_t first, SmoothGrid sg) {
+__global__ __launch_bounds__(256) void k_smooth_spans(const DevFrame* __restrict__ frames, uint32_t first, SmoothGrid sg,
+                                                      bool again) {
+  // again: the pass behind the geometry filter — nothing to do unless a cell has become mixed since (k_smooth_moved_mark)
+  uint32_t* dirty = sg.frame_dirty(blockIdx.y);
+  if (again) {
+    if (*gl(dirty) == 0u) return;
+  } else if (blockIdx.x == 0 && threadIdx.x == 0) {
+    *dirty = 0u;
+  }
   const DevFrame& f = frames[first + blockIdx.y];
   const uint32_t n = min(*gl(f.n_points), f.capacity);
   const uint32_t lane = threadIdx.x & 63u;
@@ -783,11 +834,12 @@ void launch_smooth_moved(const DevFrame* d_frames, uint32_t first, uint32_t coun
   if (pow2(G)) hipLaunchKernelGGL(k_smooth_moved_mark<true>, grid, block, 0, (hipStream_t)stream, d_frames, first, sg, gd);
   else hipLaunchKernelGGL(k_smooth_moved_mark<false>, grid, block, 0, (hipStream_t)stream, d_frames, first, sg, gd);
 }
-void launch_smooth_spans(const DevFrame* d_frames, uint32_t first, uint32_t count, uint32_t max_points, SmoothGrid sg, void* stream) {
+void launch_smooth_spans(const DevFrame* d_frames, uint32_t first, uint32_t count, uint32_t max_points, SmoothGrid sg, bool again,
+                         void* stream) {
   if (!count || !max_points) return;
   const uint32_t per_block = 16u * kSmoothListSpan;
   hipLaunchKernelGGL(k_smooth_spans, dim3((max_points + per_block - 1) / per_block, count), dim3(256), 0, (hipStream_t)stream, d_frames,
-                     first, sg);
+                     first, sg, again);
 }
 void launch_smooth_mark(const DevFrame* d_frames, uint32_t first, uint32_t count, uint32_t max_points, SmoothGrid sg,
                         uint32_t w, void* stream) {
