@@ -115,7 +115,7 @@ def parse():
                          "launches of the same kernel would blur a rocprofv3 average of the run")
     ap.add_argument("--no-verify", action="store_true", help="skip the oracle check of the timed GOF's output (tools/ only)")
     ap.add_argument("--no-end-to-end", action="store_true", help="skip the PCIe-inclusive Decoder run")
-    ap.add_argument("--e2e-gofs", type=int, default=9, help="GOFs in the end-to-end container (launches of 1 + 4 + 4 GOFs)")
+    ap.add_argument("--e2e-gofs", type=int, default=17, help="GOFs in the end-to-end container (launches of 1 + 4 + 4 + 4 + 2 + 1 + 1 GOFs: the stream's last unit is dealt out in halves)")
     ap.add_argument("--profile-every", type=int, default=16,
                     help="an event pair around every n-th launch of the timed region (each costs a few us of stream time)")
     ap.add_argument("--profile-steps", type=int, default=0, help=argparse.SUPPRESS)   # accepted for old tool scripts
@@ -583,7 +583,8 @@ def main():
                    "host_plan_and_enqueue_us_per_frame": round(dstats["launch_seconds"] / max(nf, 1) * 1e6, 1),
                    "lane_numa_nodes": dstats["numa_node"],
                    "sample": f"{args.e2e_gofs} GOFs x {args.frames} frames through tmc2rs::Decoder (pinned container -> "
-                             f"H2D -> kernels -> D2H -> consumer)"}
+                             f"H2D -> kernels -> D2H -> consumer); the rate after the first frame still contains the stream's end, "
+                             f"where the last GOF's results travel back alone"}
         finally:
             if os.path.exists(path):
                 os.remove(path)

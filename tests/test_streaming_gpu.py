@@ -91,6 +91,20 @@ def test_decoder_launch_covers_several_gofs_small_frames():
     assert st["lanes"] == 1 and len(st["numa_node"]) == 1
 
 
+@pytest.mark.parametrize("switch", ["VPCC_NO_EXTENT_INGEST", "VPCC_NO_STAGED_DESCRIPTORS", "VPCC_NO_PULL_INGEST"])
+def test_decoder_ingest_paths(monkeypatch, longdress32, switch):
+    """The Decoder's planes reach the device as whole stretches of its page-locked container by default (one copy per
+    eight frames; descriptors through a page-locked staging buffer).  The paths behind it — planes pulled by kernel,
+    descriptors from pageable memory on a set-up stream, plane-by-plane copies — serve callers whose planes are not
+    laid out like that: each must give the same frames."""
+    frames, ref = longdress32
+    if switch == "VPCC_NO_PULL_INGEST":
+        monkeypatch.setenv("VPCC_NO_EXTENT_INGEST", "1")            # neither stretches nor the kernel: the copy engine, plane by plane
+    monkeypatch.setenv(switch, "1")
+    got, err = _stream([frames[:16], frames[16:], frames[:8]], devices=(0,))
+    assert err == "" and got == ref[:16] + ref[16:] + ref[:8]
+
+
 def test_config3_three_sequences_sharded_over_two_contexts(longdress32):
     import torch
     devices = (0, 1) if torch.cuda.device_count() >= 2 else (0, 0)
@@ -109,8 +123,9 @@ def test_config3_three_sequences_sharded_over_two_contexts(longdress32):
     got, err = _stream(gofs, devices=devices)
     assert err == ""
     assert len(got) == 288 and got == expect
-    st = _stream.last_stats                                        # 9 GOFs: [0], [1..4], [5..8], each dealt over two lanes
-    assert st["lanes"] == 2 and st["launches"] == 6 and st["max_frames_per_launch"] == 64
+    # 9 GOFs: [0], [1..4], and the stream's last unit in halves — [5, 6], [7], [8] — each dealt over two lanes
+    st = _stream.last_stats
+    assert st["lanes"] == 2 and st["launches"] == 10 and st["max_frames_per_launch"] == 64
 
 
 def test_decoder_to_ply_matches_oracle_bytes(tmp_path):

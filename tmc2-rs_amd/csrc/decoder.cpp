@@ -183,8 +183,9 @@ void Decoder::worker() {
   const bool trace_steps = std::getenv("VPCC_DECODER_TRACE") != nullptr && std::getenv("VPCC_DECODER_TRACE")[0] == '2';
   auto step = [&](const char* what) {                   // VPCC_DECODER_TRACE=2: the start-up, step by step
     if (trace_steps)
-      std::fprintf(stderr, "[vpcc decoder] +%.1f ms %s\n",
-                   std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_worker).count(), what);
+      std::fprintf(stderr, "[vpcc decoder] +%.1f ms %s   (@%.1f)\n",
+                   std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_worker).count(), what,
+                   std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count());
   };
   std::vector<std::unique_ptr<Lane>> lanes;
   for (size_t d = 0; d < G; ++d) lanes.push_back(std::make_unique<Lane>(params_.devices.empty() ? 0 : params_.devices[d]));
@@ -347,6 +348,20 @@ void Decoder::worker() {
     }
     units.emplace_back(k, end);
     k = end;
+  }
+  // The results of the stream's LAST unit travel back with nothing left to overlap them with (20 ms for 128 frames): it is
+  // dealt out in halves — 4 GOFs as 2 + 1 + 1 — so that only a GOF's worth of downloads is left at the end (units of fewer than
+  // 64 frames are left alone: nothing to gain).
+  auto frames_of = [&](const std::pair<size_t, size_t>& u) {
+    size_t n = 0;
+    for (size_t q = u.first; q < u.second; ++q) n += gofs_[q].frames.size();
+    return n;
+  };
+  while (units.size() > 1 && units.back().second - units.back().first > 1 && frames_of(units.back()) >= 64 &&
+         !std::getenv("VPCC_DECODER_NO_TAIL_SPLIT")) {
+    const size_t a = units.back().first, b = units.back().second, mid = a + (b - a + 1) / 2;
+    units.back().second = mid;
+    units.emplace_back(mid, b);
   }
 
   // Two units are kept queued behind the one being drained: the copy engines then always have the next

@@ -39,6 +39,7 @@ struct vpcc_ctx {
   // Arenas of destroyed GOFs are kept for the next GOF of the same shape: hipMalloc/hipFree cost
   // milliseconds and hipFree synchronises the whole device, which would stall a GOF pipeline.
   std::vector<std::pair<void*, size_t>> arena_cache;
+  std::vector<std::pair<void*, size_t>> stage_cache;   // ... and their page-locked descriptor staging buffers
   // The big blocks of a gof — the video planes it ingested and its output arrays — are kept in kParts parts by frame
   // (eight frames, one per XCD label, to part 0, the next eight to part 1, ...), and with a reserved pool
   // (vpcc_ctx_reserve) part p lies in home p: VRAM consists of KINDS of regions, 32 GB each, and a launch whose
@@ -99,6 +100,9 @@ struct vpcc_gof {
   bool counts_valid = false;
   bool launched = false;
   std::vector<IngestPiece> ingest;     // plane ingest by kernel: the pieces (alive while their upload may read them)
+  uint32_t ingest_extents = 0;         // plane ingest by extent: copies issued
+  void* stage = nullptr;               // page-locked staging of the descriptors (returned to the context's cache)
+  size_t stage_bytes = 0;
   std::vector<hipEvent_t> download_done;   // vpcc_gof_download_async: one per frame
   hipEvent_t upload_done = nullptr;
   hipEvent_t results_ready = nullptr;   // recorded behind the last kernel launched on this gof
@@ -193,6 +197,7 @@ extern "C" void vpcc_ctx_destroy(vpcc_ctx* ctx) {
   if (!ctx) return;
   (void)hipSetDevice(ctx->device);
   for (auto& a : ctx->arena_cache) (void)hipFree(a.first);
+  for (auto& a : ctx->stage_cache) (void)hipHostFree(a.first);
   retire_pool(ctx);
   for (auto& b : ctx->block_cache) (void)hipFree(b.ptr);
   if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
@@ -249,17 +254,52 @@ extern "C" int vpcc_ctx_bind_thread(vpcc_ctx* ctx, int* node_out) {
   return VPCC_OK;
 }
 
+namespace {
+// The page-locked regions this library made (vpcc_host_pin, vpcc_host_alloc), for the whole process: a stretch of planes
+// that lies inside one of them may be copied in one piece, what lies between the planes included (extent ingest).
+std::mutex g_pinned_mutex;
+std::vector<std::pair<const char*, size_t>> g_pinned;
+void note_pinned(const void* p, size_t bytes) {
+  std::lock_guard<std::mutex> lock(g_pinned_mutex);
+  g_pinned.emplace_back((const char*)p, bytes);
+}
+void forget_pinned(const void* p) {
+  std::lock_guard<std::mutex> lock(g_pinned_mutex);
+  for (size_t k = 0; k < g_pinned.size(); ++k)
+    if (g_pinned[k].first == (const char*)p) { g_pinned.erase(g_pinned.begin() + k); return; }
+}
+bool inside_one_pinned_region(const char* lo, size_t bytes) {
+  {
+    std::lock_guard<std::mutex> lock(g_pinned_mutex);
+    for (const auto& r : g_pinned)
+      if (lo >= r.first && lo + bytes <= r.first + r.second) return true;
+  }
+  // page-locked by the caller's own means: both ends map to the device, linearly, as parts of an allocation of one size
+  void *d0 = nullptr, *d1 = nullptr, *b0 = nullptr, *b1 = nullptr;
+  size_t s0 = 0, s1 = 0;
+  const bool ok = hipHostGetDevicePointer(&d0, const_cast<char*>(lo), 0) == hipSuccess && d0 &&
+                  hipHostGetDevicePointer(&d1, const_cast<char*>(lo + bytes - 1), 0) == hipSuccess && d1 &&
+                  (char*)d1 - (char*)d0 == (ptrdiff_t)(bytes - 1) &&
+                  hipMemGetAddressRange(reinterpret_cast<hipDeviceptr_t*>(&b0), &s0, (hipDeviceptr_t)d0) == hipSuccess &&
+                  hipMemGetAddressRange(reinterpret_cast<hipDeviceptr_t*>(&b1), &s1, (hipDeviceptr_t)d1) == hipSuccess && s0 == s1 && s0 >= bytes;
+  (void)hipGetLastError();
+  return ok;
+}
+}  // namespace
+
 extern "C" int vpcc_host_pin(vpcc_ctx* ctx, const void* ptr, size_t bytes) {
   if (!ctx || !ptr || !bytes) return VPCC_ERR_INVALID_ARG;
   HIP_TRY(ctx, hipSetDevice(ctx->device));
   // Portable: every device (every vpcc_ctx of the process) may DMA from it, not only ctx's
   HIP_TRY(ctx, hipHostRegister(const_cast<void*>(ptr), bytes, hipHostRegisterPortable | hipHostRegisterMapped));   // mapped: the ingest kernel reads it in place
+  note_pinned(ptr, bytes);
   return VPCC_OK;
 }
 
 extern "C" int vpcc_host_unpin(vpcc_ctx* ctx, const void* ptr) {
   if (!ctx || !ptr) return VPCC_ERR_INVALID_ARG;
   HIP_TRY(ctx, hipSetDevice(ctx->device));
+  forget_pinned(ptr);
   HIP_TRY(ctx, hipHostUnregister(const_cast<void*>(ptr)));
   return VPCC_OK;
 }
@@ -268,6 +308,7 @@ extern "C" int vpcc_host_alloc(vpcc_ctx* ctx, size_t bytes, void** out) {
   if (!ctx || !out || !bytes) return VPCC_ERR_INVALID_ARG;
   HIP_TRY(ctx, hipSetDevice(ctx->device));
   HIP_TRY(ctx, hipHostMalloc(out, bytes, hipHostMallocPortable));     // usable as a DMA target by every device
+  note_pinned(*out, bytes);
   return VPCC_OK;
 }
 
@@ -276,6 +317,7 @@ extern "C" int vpcc_host_free(vpcc_ctx* ctx, void* ptr) {     // ctx may be NULL
   if (!ptr) return VPCC_ERR_INVALID_ARG;
   // no hipSetDevice: page-locked host memory is freed from any thread with any current device, and this is
   // called from a consumer's thread when it drops a frame — it must not change that thread's device
+  forget_pinned(ptr);
   return hipHostFree(ptr) == hipSuccess ? VPCC_OK : VPCC_ERR_DEVICE;
 }
 
@@ -526,11 +568,13 @@ extern "C" int vpcc_ctx_pool_info(vpcc_ctx* ctx, vpcc_pool_info* out) {
 extern "C" void vpcc_gof_destroy(vpcc_gof* gof) {
   if (!gof) return;
   (void)hipSetDevice(gof->ctx->device);
-  if (gof->last_stream) (void)hipStreamSynchronize(gof->last_stream);
-  (void)hipStreamSynchronize(gof->ctx->stream);
-  (void)hipStreamSynchronize(gof->ctx->copy_stream);
-  (void)hipStreamSynchronize(gof->ctx->setup_stream);
-  (void)hipStreamSynchronize(gof->ctx->d2h_stream);
+  // Everything enqueued on THIS gof has to be over — its ingest and planning (upload_done), the last kernel launched on it
+  // (results_ready), its asynchronous downloads — and nothing else: the context's streams carry the next units' ingest, and
+  // a lane that waited here for the copy stream to drain (round 3 and the first half of round 4) left the link idle until it
+  // had posted the unit after those (a 128-frame unit every 55 ms instead of every 41).
+  if (gof->upload_done) (void)hipEventSynchronize(gof->upload_done);
+  if (gof->launched && gof->results_ready) (void)hipEventSynchronize(gof->results_ready);
+  for (hipEvent_t e : gof->download_done) if (e) (void)hipEventSynchronize(e);
   for (auto& l : gof->history)
     for (auto& t : l.k) {
       (void)hipEventDestroy(t.start);
@@ -546,6 +590,11 @@ extern "C" void vpcc_gof_destroy(vpcc_gof* gof) {
     auto& cache = gof->ctx->arena_cache;
     if (cache.size() < 4) cache.emplace_back(gof->arena, gof->arena_bytes);
     else (void)hipFree(gof->arena);
+  }
+  if (gof->stage) {
+    auto& cache = gof->ctx->stage_cache;
+    if (cache.size() < 4) cache.emplace_back(gof->stage, gof->stage_bytes);
+    else (void)hipHostFree(gof->stage);
   }
   for (vpcc_ctx::Block& B : gof->block) release_block(gof->ctx, B);
   if (gof->h_counts) (void)hipHostFree(gof->h_counts);
@@ -612,6 +661,18 @@ int gof_create_impl(vpcc_ctx* ctx, const vpcc_frame_desc* frames, uint32_t n_fra
   // 2. arena layout
   ArenaLayout L;
   const size_t off_frames = L.take(sizeof(DevFrame) * n_frames);
+  // what the HOST writes — frame descriptors, patches, virtual blocks, item templates — lies together at the arena's start:
+  // with page-locked planes (VPCC_GOF_ASYNC_UPLOAD) it is put together in a page-locked staging buffer and arrives as ONE copy
+  // at the head of the gof's ingest (below)
+  struct HostOff { size_t patches, vblocks, patch_items; };
+  std::vector<HostOff> hoffs(n_frames);
+  for (uint32_t i = 0; i < n_frames; ++i) {
+    const FramePlan& P = g->plans[i];
+    hoffs[i].patches = L.take(sizeof(DevPatch) * std::max<size_t>(P.patches.size(), 1));
+    hoffs[i].vblocks = L.take(sizeof(VBlock) * std::max<size_t>(P.vblocks.size(), 1));
+    hoffs[i].patch_items = L.take(sizeof(TileItem) * std::max<size_t>(P.patch_items.size(), 1));
+  }
+  const size_t host_end = L.total;
   const size_t off_counts = L.take(sizeof(uint32_t) * n_frames);
   struct Off {
     size_t patches, vblocks, items, patch_items, b2p, vb_count, vb_offset, xyz, rgb, pidx, occ, geo[2], ay[2], au[2], av[2];
@@ -648,20 +709,88 @@ int gof_create_impl(vpcc_ctx* ctx, const vpcc_frame_desc* frames, uint32_t n_fra
   // kind 0 planes / 1 outputs
   auto takek = [&](uint32_t i, int kind, int, size_t bytes) { return LB[2 * part_of(i) + kind].take(bytes); };
   size_t ingest_bound = 0;
+  // Plane ingest (page-locked host planes, VPCC_GOF_ASYNC_UPLOAD):
+  //   * planes that lie next to each other in the caller's memory — the output of a decoder that allocates from one pool, a
+  //     decoded-GOF container — keep that arrangement on the device and arrive as ONE copy per stretch (an EXTENT): with the
+  //     copy engine moving 146-MB stretches the link runs at 57 GB/s host -> device AND 53 GB/s device -> host at the same
+  //     time (tools/micro/zero_copy); a kernel that pulls the same bytes (zero-copy reads) gets 46 GB/s beside pushed
+  //     results, and 1 280 copies of single planes 34 GB/s;
+  //   * other tight planes are pulled by kernel (k_ingest_planes), strided ones go through the copy engine one by one.
+  const bool pinned = kind == VPCC_MEM_HOST && (gof_flags & VPCC_GOF_ASYNC_UPLOAD);
+  struct PlaneRef { const char* src; size_t bytes; size_t* slot; int part; };
+  struct Extent { const char* lo; size_t bytes; size_t dev; int part; };
+  std::vector<Extent> extents;
+  bool by_extent = false;
+  if (own_planes && pinned && !getenv("VPCC_NO_EXTENT_INGEST")) {
+    std::vector<PlaneRef> refs;
+    bool tight = true;
+    for (uint32_t i = 0; i < n_frames && tight; ++i) {
+      const vpcc_frame_desc& F = frames[i];
+      Off& o = offs[i];
+      auto add = [&](const void* src, size_t bytes, size_t* slot) { refs.push_back(PlaneRef{(const char*)src, bytes, slot, part_of(i)}); };
+      tight = F.occupancy.stride == F.occupancy.width;
+      add(F.occupancy.y, (size_t)F.occupancy.width * F.occupancy.height, &o.occ);
+      for (uint32_t m = 0; m < F.map_count; ++m) {
+        tight = tight && F.geometry[m].stride == F.geometry[m].width;
+        add(F.geometry[m].y, (size_t)F.geometry[m].width * F.geometry[m].height * 2, &o.geo[m]);
+        if (F.attribute_count) {
+          tight = tight && F.attribute[m].stride == F.attribute[m].width;
+          add(F.attribute[m].y, (size_t)F.attribute[m].width * F.attribute[m].height * 2, &o.ay[m]);
+          add(F.attribute[m].u, chroma_elems(F.attribute[m]) * 2, &o.au[m]);
+          add(F.attribute[m].v, chroma_elems(F.attribute[m]) * 2, &o.av[m]);
+        }
+      }
+    }
+    if (tight && !refs.empty()) {
+      std::stable_sort(refs.begin(), refs.end(), [](const PlaneRef& a, const PlaneRef& b) { return a.part != b.part ? a.part < b.part : a.src < b.src; });
+      const size_t kGap = 256u << 10;                         // what may lie between two planes of an extent (patch tables, headers)
+      std::vector<std::pair<size_t, size_t>> span;             // [first, last] plane of every extent
+      for (size_t k = 0; k < refs.size(); ++k) {
+        const char* end = extents.empty() ? nullptr : extents.back().lo + extents.back().bytes;
+        if (!extents.empty() && extents.back().part == refs[k].part && refs[k].src <= end + kGap) {
+          extents.back().bytes = std::max<size_t>(extents.back().bytes, (size_t)(refs[k].src + refs[k].bytes - extents.back().lo));
+          span.back().second = k;
+        } else {
+          extents.push_back(Extent{refs[k].src, refs[k].bytes, 0, refs[k].part});
+          span.emplace_back(k, k);
+        }
+      }
+      // worth it when stretches are long, and every stretch must lie inside ONE page-locked region (what lies between its
+      // planes is copied along)
+      by_extent = extents.size() * 4 <= refs.size();
+      if (getenv("VPCC_RUNTIME_TRACE")) fprintf(stderr, "[vpcc] ingest: %zu planes in %zu stretches\n", refs.size(), extents.size());
+      for (size_t e = 0; e < extents.size() && by_extent; ++e) {
+        by_extent = inside_one_pinned_region(extents[e].lo, extents[e].bytes);
+        if (!by_extent && getenv("VPCC_RUNTIME_TRACE"))
+          fprintf(stderr, "[vpcc] ingest: stretch %zu (%zu bytes at %p) is not inside one page-locked region\n", e, extents[e].bytes,
+                  (const void*)extents[e].lo);
+      }
+      (void)hipGetLastError();
+      if (by_extent)
+        for (size_t e = 0; e < extents.size(); ++e) {
+          // the device copy lies where the host stretch lies modulo 256: every plane keeps its alignment
+          const size_t shift = (uintptr_t)extents[e].lo & 255u;
+          extents[e].dev = LB[2 * extents[e].part + 0].take(extents[e].bytes + 256) + shift;
+          for (size_t k = span[e].first; k <= span[e].second; ++k) *refs[k].slot = extents[e].dev + (size_t)(refs[k].src - extents[e].lo);
+        }
+      else
+        extents.clear();
+    }
+  }
   for (uint32_t i = 0; i < n_frames; ++i) {
     const vpcc_frame_desc& F = frames[i];
     const FramePlan& P = g->plans[i];
     Off& o = offs[i];
-    o.patches = L.take(sizeof(DevPatch) * std::max<size_t>(P.patches.size(), 1));
-    o.vblocks = L.take(sizeof(VBlock) * std::max<size_t>(P.vblocks.size(), 1));
+    o.patches = hoffs[i].patches;
+    o.vblocks = hoffs[i].vblocks;
     o.items = L.take(sizeof(TileItem) * (((P.tile_bound + kTileItemsPerGroup - 1) / kTileItemsPerGroup) * kTileItemsPerGroup + kTileItemsPerGroup));
-    o.patch_items = L.take(sizeof(TileItem) * std::max<size_t>(P.patch_items.size(), 1));
+    o.patch_items = hoffs[i].patch_items;
     o.vb_count = L.take(sizeof(uint32_t) * std::max<size_t>(P.vblocks.size(), 1));
     o.vb_offset = L.take(sizeof(uint32_t) * std::max<size_t>(P.vblocks.size(), 1));
     o.xyz = takek(i, 1, 0, sizeof(vpcc_point3) * (cap + 4));                    // (output block: positions, colours, partition; + 4:
     o.rgb = F.attribute_count ? takek(i, 1, 1, sizeof(vpcc_color3) * (cap + 4)) : 0;   //  the smoothing kernels read whole quads of points,
     o.pidx = (gof_flags & VPCC_GOF_WANT_PATCH_INDEX) ? takek(i, 1, 0, sizeof(uint16_t) * (cap + 4)) : 0;   // so a quad that begins inside an array must end in memory)
-    if (own_planes) {
+    if (own_planes && !by_extent) {
       // (+ 16: a plane pulled by the ingest kernel starts 0 or 8 bytes behind its 256-byte boundary — where its source does modulo 16)
       auto plane = [&](int sub, size_t bytes) { ingest_bound += bytes / kIngestPieceBytes + 1; return takek(i, 0, sub, bytes + 16); };
       o.occ = plane(0, (size_t)F.occupancy.width * F.occupancy.height);
@@ -677,7 +806,7 @@ int gof_create_impl(vpcc_ctx* ctx, const vpcc_frame_desc* frames, uint32_t n_fra
   }
   // Plane ingest by kernel (k_ingest_planes) for page-locked host planes (VPCC_GOF_ASYNC_UPLOAD says they are; vpcc_host_pin
   // maps them for the device): one launch instead of ten hipMemcpyAsync per frame.  VPCC_NO_PULL_INGEST=1: the copy engines.
-  const bool pull = kind == VPCC_MEM_HOST && (gof_flags & VPCC_GOF_ASYNC_UPLOAD) && !getenv("VPCC_NO_PULL_INGEST");
+  const bool pull = pinned && !by_extent && !getenv("VPCC_NO_PULL_INGEST");
   const size_t off_ingest = pull ? L.take(sizeof(IngestPiece) * ingest_bound) : 0;
   g->arena_bytes = L.total;
   for (size_t k = 0; k < ctx->arena_cache.size(); ++k) {          // smallest cached arena that fits
@@ -697,6 +826,22 @@ int gof_create_impl(vpcc_ctx* ctx, const vpcc_frame_desc* frames, uint32_t n_fra
       if (st) return st;
     }
   char* base = (char*)g->arena;
+  // descriptor staging: a page-locked buffer of the context's (kept for the next gof)
+  const bool staged = pinned && !getenv("VPCC_NO_STAGED_DESCRIPTORS");
+  if (staged) {
+    for (size_t k = 0; k < ctx->stage_cache.size(); ++k)
+      if (ctx->stage_cache[k].second >= host_end) {
+        g->stage = ctx->stage_cache[k].first;
+        g->stage_bytes = ctx->stage_cache[k].second;
+        ctx->stage_cache.erase(ctx->stage_cache.begin() + k);
+        break;
+      }
+    if (!g->stage) {
+      g->stage_bytes = host_end + host_end / 4;
+      HIP_TRY(ctx, hipHostMalloc(&g->stage, g->stage_bytes, hipHostMallocDefault));
+    }
+  }
+  char* const stage = (char*)g->stage;
   auto kb = [&](uint32_t i, int kind, int) { return (char*)g->block[2 * part_of(i) + kind].ptr; };
   g->d_frames = (DevFrame*)(base + off_frames);
   g->d_counts = (uint32_t*)(base + off_counts);
@@ -756,6 +901,7 @@ int gof_create_impl(vpcc_ctx* ctx, const vpcc_frame_desc* frames, uint32_t n_fra
       // src mod 16, so that 16-byte pieces line up on both sides); everything else goes through the copy engines.
       int st = VPCC_OK;
       auto ingest_plane = [&](char* dst, const void* src, size_t elem, uint32_t width, uint32_t height, uint32_t stride) -> const void* {
+        if (by_extent) return dst;                              // arrives with its extent (below)
         void* dev_src = nullptr;
         if (pull && stride == width && ((uintptr_t)src & 7u) == 0 &&
             hipHostGetDevicePointer(&dev_src, const_cast<void*>(src), 0) == hipSuccess && dev_src) {
@@ -805,6 +951,12 @@ int gof_create_impl(vpcc_ctx* ctx, const vpcc_frame_desc* frames, uint32_t n_fra
         D.attr_y[m] = D.attr_u[m] = D.attr_v[m] = D.geo[m];
         D.attr_stride[m] = D.attr_cstride[m] = D.geo_stride[m];
       }
+    if (staged) {
+      if (!P.patches.empty()) std::memcpy(stage + o.patches, P.patches.data(), sizeof(DevPatch) * P.patches.size());
+      if (!P.vblocks.empty()) std::memcpy(stage + o.vblocks, P.vblocks.data(), sizeof(VBlock) * P.vblocks.size());
+      if (!P.patch_items.empty()) std::memcpy(stage + o.patch_items, P.patch_items.data(), sizeof(TileItem) * P.patch_items.size());
+      continue;
+    }
     if (!P.patches.empty())
       HIP_TRY(ctx, hipMemcpyAsync(base + o.patches, P.patches.data(), sizeof(DevPatch) * P.patches.size(),
                                   hipMemcpyHostToDevice, sd));
@@ -819,23 +971,37 @@ int gof_create_impl(vpcc_ctx* ctx, const vpcc_frame_desc* frames, uint32_t n_fra
   bool tiles_ok = all_simple && !(gof_flags & VPCC_GOF_FORCE_GENERAL);
   for (uint32_t i = 0; i < n_frames && tiles_ok; ++i) tiles_ok = tile_planes_aligned(g->h_frames[i]);
   g->general = !tiles_ok;
-  HIP_TRY(ctx, hipMemcpyAsync(g->d_frames, g->h_frames.data(), sizeof(DevFrame) * n_frames, hipMemcpyHostToDevice, sd));
-  HIP_TRY(ctx, hipMemsetAsync(g->d_counts, 0, sizeof(uint32_t) * n_frames, sd));
-  HIP_TRY(ctx, hipMemsetAsync(base + ctrl_begin, 0, g->ctrl_bytes, sd));
-  if (g->b2p_words) HIP_TRY(ctx, hipMemsetAsync(g->d_b2p, 0, g->b2p_words * sizeof(uint32_t), sd));
+  // Staged: everything of this gof goes onto the copy stream, in the order it is needed — nothing waits for another stream
+  // (HIP maps streams onto a few hardware queues: the small copies of a set-up stream sat behind the 40 ms of the previous
+  // unit's planes although they were enqueued long before, and the copy engine then idled 10 ms between two units' planes).
+  hipStream_t const sm = staged ? s : sd;
+  if (staged) {
+    std::memcpy(stage + off_frames, g->h_frames.data(), sizeof(DevFrame) * n_frames);
+    HIP_TRY(ctx, hipMemcpyAsync(base, stage, host_end, hipMemcpyHostToDevice, s));
+  } else {
+    HIP_TRY(ctx, hipMemcpyAsync(g->d_frames, g->h_frames.data(), sizeof(DevFrame) * n_frames, hipMemcpyHostToDevice, sd));
+  }
+  HIP_TRY(ctx, hipMemsetAsync(g->d_counts, 0, sizeof(uint32_t) * n_frames, sm));
+  HIP_TRY(ctx, hipMemsetAsync(base + ctrl_begin, 0, g->ctrl_bytes, sm));
+  if (g->b2p_words) HIP_TRY(ctx, hipMemsetAsync(g->d_b2p, 0, g->b2p_words * sizeof(uint32_t), sm));
   IngestPiece* d_pieces = (IngestPiece*)(base + off_ingest);
   if (!g->ingest.empty()) {
     if (g->ingest.size() > ingest_bound) return fail(ctx, VPCC_ERR_STATE, "ingest piece list overflow");
-    HIP_TRY(ctx, hipMemcpyAsync(d_pieces, g->ingest.data(), sizeof(IngestPiece) * g->ingest.size(), hipMemcpyHostToDevice, sd));
+    HIP_TRY(ctx, hipMemcpyAsync(d_pieces, g->ingest.data(), sizeof(IngestPiece) * g->ingest.size(), hipMemcpyHostToDevice, sm));
   }
   // the planes follow on the copy stream (plane copies of the fallback path are queued there already; nothing of them
   // depends on the descriptors), behind the set-up: upload_done then stands for both
-  HIP_TRY(ctx, hipEventRecord(g->upload_done, sd));
-  HIP_TRY(ctx, hipStreamWaitEvent(s, g->upload_done, 0));
+  if (!staged) {
+    HIP_TRY(ctx, hipEventRecord(g->upload_done, sd));
+    HIP_TRY(ctx, hipStreamWaitEvent(s, g->upload_done, 0));
+  }
   if (!g->ingest.empty()) {
     launch_ingest_planes(d_pieces, (uint32_t)g->ingest.size(), s);
     HIP_TRY(ctx, hipGetLastError());
   }
+  for (const Extent& e : extents)
+    HIP_TRY(ctx, hipMemcpyAsync((char*)g->block[2 * e.part + 0].ptr + e.dev, e.lo, e.bytes, hipMemcpyHostToDevice, s));
+  g->ingest_extents = (uint32_t)extents.size();
   // the tile kernel's work lists, from the occupancy planes where they now lie (src/codec.rs:205-250 on the device)
   if (!g->general) {
     launch_plan_tiles(g->d_frames, 0, n_frames, g->max_vb, s);
@@ -844,9 +1010,10 @@ int gof_create_impl(vpcc_ctx* ctx, const vpcc_frame_desc* frames, uint32_t n_fra
   HIP_TRY(ctx, hipEventRecord(g->upload_done, s));
   if (getenv("VPCC_RUNTIME_TRACE")) {
     const auto t_end = std::chrono::steady_clock::now();
-    fprintf(stderr, "[vpcc] gof of %u frames: allocations %.1f ms, descriptors + %s of the planes %.1f ms\n", n_frames,
+    fprintf(stderr, "[vpcc] gof of %u frames: allocations %.1f ms, descriptors + %s of the planes %.1f ms (%u extents, %zu pieces by kernel)   (@%.1f - %.1f)\n", n_frames,
             std::chrono::duration<double, std::milli>(t_fill - t_alloc).count(), kind == VPCC_MEM_HOST ? "upload enqueue" : "binding",
-            std::chrono::duration<double, std::milli>(t_end - t_fill).count());
+            std::chrono::duration<double, std::milli>(t_end - t_fill).count(), g->ingest_extents, g->ingest.size(),
+            std::chrono::duration<double, std::milli>(t_alloc.time_since_epoch()).count(), std::chrono::duration<double, std::milli>(t_end.time_since_epoch()).count());
     for (int k = 0; k < 2 * vpcc_ctx::kParts; ++k)
       if (g->block[k].ptr)
         fprintf(stderr, "[vpcc]   %s block of part %d: %p + %.2f GB%s\n", (k & 1) ? "output" : "planes", k / 2, g->block[k].ptr,

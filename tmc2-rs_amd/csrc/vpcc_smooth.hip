@@ -542,6 +542,26 @@ __device__ __forceinline__ void move_sums(const SmoothGrid& sg, uint32_t frame, 
   }
 }
 
+// Quotients of the filters without the 64-bit integer division (some 150 instructions each): for 0 <= a < 2^52 and
+// 0 < b < 2^52 the product a * fl(1 / b) is within one of a / b, so its integer part is the quotient or a neighbour,
+// and the remainder says which.  Anything else (weights of a point outside the grid can be negative) divides in integers.
+__device__ __forceinline__ bool small_operands(int64_t a, int64_t b) {
+  return (uint64_t)a < (1ull << 52) && (uint64_t)b < (1ull << 52);       // (b > 0 is the caller's)
+}
+__device__ __forceinline__ int64_t div_small(int64_t a, int64_t b, double inv_b) {
+  int64_t q = (int64_t)((double)a * inv_b);
+  const int64_t r = a - q * b;
+  q += r < 0 ? -1 : r >= b ? 1 : 0;
+  return q;
+}
+// floor(a / b) for a < 2^24 and a / b < 2^8 (a sum of up to 65 537 bytes over their number)
+__device__ __forceinline__ uint32_t mean_small(uint32_t a, uint32_t b, float inv_b) {
+  uint32_t q = (uint32_t)((float)a * inv_b);
+  const int32_t r = (int32_t)(a - q * b);
+  q += r < 0 ? -1 : (uint32_t)r >= b ? 1 : 0;
+  return q;
+}
+
 template <bool kPow2>
 __device__ __forceinline__ void smooth_apply_geometry_point(const DevFrame& f, uint32_t frame, uint32_t i, const SmoothGrid& sg,
                                                             const GridDims& gd, uint32_t T, bool both, const uint32_t (&p)[3]) {
@@ -563,9 +583,17 @@ __device__ __forceinline__ void smooth_apply_geometry_point(const DevFrame& f, u
   }
   if (den <= 0) return;
   int64_t C[3], d2 = 0;
+  const int64_t A[3] = {16 * num[0] + den / 2, 16 * num[1] + den / 2, 16 * num[2] + den / 2};
+  if (small_operands(A[0] | A[1] | A[2], den)) {
+    const double inv = 1.0 / (double)den;
+#pragma unroll
+    for (int a = 0; a < 3; ++a) C[a] = div_small(A[a], den, inv);
+  } else {
+#pragma unroll
+    for (int a = 0; a < 3; ++a) C[a] = A[a] / den;
+  }
 #pragma unroll
   for (int a = 0; a < 3; ++a) {
-    C[a] = (16 * num[a] + den / 2) / den;
     const int64_t d = 16 * (int64_t)p[a] - C[a];
     d2 += d * d;
   }
@@ -660,8 +688,12 @@ __device__ __forceinline__ void smooth_apply_color_point(const DevFrame& f, uint
   u32x4 cc = h.c[0];
 #pragma unroll
   for (int d = 1; d < 8; ++d) if (d == own) cc = h.c[d];
+  // the cells' means, floor(sum / count) per channel (oracle/vpcc_smoothing_spec.h): sums of bytes, below 2^24 as long as a
+  // cell holds no more than 65 537 points (beyond: VPCC_ERR_UNSUPPORTED, k_smooth_mark)
   const uint32_t own_count = cc.x & kCountMask;
-  const int32_t mc[3] = {(int32_t)(cc.y / own_count), (int32_t)(cc.z / own_count), (int32_t)(cc.w / own_count)};
+  const float own_inv = 1.0f / (float)own_count;
+  const int32_t mc[3] = {(int32_t)mean_small(cc.y, own_count, own_inv), (int32_t)mean_small(cc.z, own_count, own_inv),
+                         (int32_t)mean_small(cc.w, own_count, own_inv)};
   int64_t num[3] = {0, 0, 0}, den = 0;
   bool mixed = false;
 #pragma unroll
@@ -670,7 +702,9 @@ __device__ __forceinline__ void smooth_apply_color_point(const DevFrame& f, uint
     const uint32_t count = c.x & kCountMask;
     if (!count) continue;
     if (d != own) {
-      const int32_t m0 = (int32_t)(c.y / count) - mc[0], m1 = (int32_t)(c.z / count) - mc[1], m2 = (int32_t)(c.w / count) - mc[2];
+      const float inv = 1.0f / (float)count;
+      const int32_t m0 = (int32_t)mean_small(c.y, count, inv) - mc[0], m1 = (int32_t)mean_small(c.z, count, inv) - mc[1],
+                    m2 = (int32_t)mean_small(c.w, count, inv) - mc[2];
       const uint32_t diff = (uint32_t)((m0 < 0 ? -m0 : m0) + (m1 < 0 ? -m1 : m1) + (m2 < 0 ? -m2 : m2));
       if (diff > Td) continue;
     }
@@ -681,9 +715,17 @@ __device__ __forceinline__ void smooth_apply_color_point(const DevFrame& f, uint
   }
   if (!mixed || den <= 0) return;
   int64_t m[3], dist = 0;
+  const int64_t A[3] = {2 * num[0] + den, 2 * num[1] + den, 2 * num[2] + den}, den2 = 2 * den;
+  if (small_operands(A[0] | A[1] | A[2], den2)) {
+    const double inv = 1.0 / (double)den2;
+#pragma unroll
+    for (int a = 0; a < 3; ++a) m[a] = div_small(A[a], den2, inv);
+  } else {
+#pragma unroll
+    for (int a = 0; a < 3; ++a) m[a] = A[a] / den2;
+  }
 #pragma unroll
   for (int a = 0; a < 3; ++a) {
-    m[a] = (2 * num[a] + den) / (2 * den);
     const int64_t d = cl[a] - m[a];
     dist += d < 0 ? -d : d;
   }

@@ -78,5 +78,33 @@ int main(int argc, char** argv) {
                mode ? "16-workgroup push kernels" : "hipMemcpyAsync D2H      ", 2 * bytes / m1 / 1e6, m1, 2 * back * piece / m2 / 1e6, m2);
       }
   }
+  // duplex with the COPY ENGINE pulling: 2 x 7 copies of 146 MB (the planes of eight frames, contiguous in the container) host -> device
+  // while 0.8 GiB of results go back in 7-MB copies (copy engine) or by push kernels
+  {
+    void* h2 = nullptr; void* d2 = nullptr; void* h2d = nullptr;
+    hipHostMalloc(&h2, bytes, hipHostMallocPortable | hipHostMallocMapped); hipMalloc(&d2, bytes); hipHostGetDevicePointer(&h2d, h2, 0);
+    hipStream_t s1, s2; hipStreamCreateWithFlags(&s1, hipStreamNonBlocking); hipStreamCreateWithFlags(&s2, hipStreamNonBlocking);
+    hipEvent_t a2, b2; hipEventCreate(&a2); hipEventCreate(&b2);
+    const size_t piece = 7ull << 20, back = 58, big = 146ull << 20, nbig = bytes / big;
+    for (int mode = 0; mode < 3; ++mode) {
+      hipDeviceSynchronize();
+      hipEventRecord(a, s1);
+      for (int r = 0; r < 2; ++r) for (size_t k = 0; k < nbig; ++k) hipMemcpyAsync((char*)d + k * big, (char*)h + k * big, big, hipMemcpyHostToDevice, s1);
+      hipEventRecord(b, s1);
+      hipEventRecord(a2, s2);
+      if (mode < 2)
+        for (int r = 0; r < 4; ++r)
+          for (size_t k = 0; k < back; ++k) {
+            if (mode == 0) hipMemcpyAsync((char*)h2 + k * piece, (char*)d2 + k * piece, piece, hipMemcpyDeviceToHost, s2);
+            else hipLaunchKernelGGL(k_pull, dim3(16), dim3(256), 0, s2, (const u32x4*)((char*)d2 + k * piece), (u32x4*)((char*)h2d + k * piece), piece / 16, 4);
+          }
+      hipEventRecord(b2, s2);
+      hipEventSynchronize(b); hipEventSynchronize(b2);
+      float m1, m2; hipEventElapsedTime(&m1, a, b); hipEventElapsedTime(&m2, a2, b2);
+      printf("duplex, %zu copies of 146 MB host -> device + %s back: H2D %.1f GB/s (%.1f ms), D2H %.1f GB/s (%.1f ms)\n", 2 * nbig,
+             mode == 0 ? "hipMemcpyAsync D2H (7 MB)" : mode == 1 ? "16-workgroup push kernels" : "nothing", 2 * nbig * big / m1 / 1e6, m1,
+             mode < 2 ? 4 * back * piece / m2 / 1e6 : 0.0, m2);
+    }
+  }
   return 0;
 }
