@@ -425,8 +425,9 @@ def main():
         dom = max(kernels, key=kernels.get)
         dom_ms = kernels[dom]
         dom_bytes = alg_bytes
-        if args.smooth and dom.startswith(("k_smooth", "smooth_")):
-            dom_bytes = smooth_bytes           # a smoothing kernel dominates: its own algorithmic bytes (whole pass pair)
+        if args.smooth:                        # --smooth: the line is about the filters — all their launches, their algorithmic bytes
+            dom = "k_smooth_*"
+            dom_bytes = smooth_bytes
             dom_ms = sum(v for k, v in kernels.items() if k.startswith(("k_smooth", "smooth_")))
         achieved = dom_bytes / (dom_ms * 1e-3) / 1e9
         tr = measured_traffic(dom, args.workload, n_batch) if not args.smooth else None
@@ -436,7 +437,7 @@ def main():
                     "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBPS, 4),
                     "achieved_is": "algorithmic bytes (SURVEY 8d: whole planes once + 9 B/point) / kernel time — a rate of the bytes the path stands for; the physical HBM rate is frac_traffic",
                     "traffic": tr["hbm_bytes_per_launch"] if tr else None,
-                    "traffic_stale": stale(tr, "k_recon_tiles") if tr else None,
+                    "traffic_stale": stale(tr, "k_smooth" if args.smooth else "k_recon_tiles") if tr else None,
                     "traffic_measured_on": {"kernel_source_sha16": tr.get("kernel_source_sha16"), "library_sha16": (tr.get("library") or {}).get("sha16")} if tr else None,
                     "algorithmic_bytes_per_launch": dom_bytes, "kernel_ms": round(dom_ms, 4),
                     "kernel_ms_launches_averaged": launches_averaged,

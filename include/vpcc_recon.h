@@ -189,7 +189,13 @@ int  vpcc_ctx_reserve(vpcc_ctx* ctx, uint64_t bytes, vpcc_pool_info* out /* may 
 int  vpcc_ctx_pool_info(vpcc_ctx* ctx, vpcc_pool_info* out);
 
 /* Plane ingest (stand-in for LibavcodecDecoder::decode, src/decoder.rs:1089-1156, whose Vec<u8> planes
- * are the H2D source): page-locks a host range so that uploads from it are true asynchronous DMA. */
+ * are the H2D source): page-locks a host range so that uploads from it are true asynchronous DMA.
+ * Planes of a VPCC_GOF_ASYNC_UPLOAD gof that lie next to each other (up to 256 KB apart) inside ONE region page-locked
+ * here — a decoder's frame pool, a decoded-GOF container — are copied as whole stretches, whatever lies between them
+ * included, and keep their arrangement on the device: one copy per eight frames runs the link at its full rate in both
+ * directions at once (57 + 53 GB/s on an MI355X), which neither a copy per plane (34 GB/s) nor a kernel reading the host
+ * memory in place (46 GB/s beside the results going back) does.  Page-locked planes that do not lie like that are pulled
+ * by kernel, planes with padded rows are copied one by one. */
 int  vpcc_host_pin(vpcc_ctx* ctx, const void* ptr, size_t bytes);
 int  vpcc_host_unpin(vpcc_ctx* ctx, const void* ptr);
 /* Page-locked host buffers for results (D2H straight into the memory the consumer keeps). */
@@ -342,11 +348,11 @@ typedef struct vpcc_smoothing_params {
 /* Smooths frames [first, first+count) of the last reconstruct.  The gof must have been created with
  * VPCC_GOF_WANT_PATCH_INDEX (the filters need each point's patch).  Geometry first, then colour.
  * Device memory: on first use the gof allocates, and keeps until vpcc_gof_destroy, a scratch of dense grids —
- * 33 bytes per cell, ceil(2^bitdepth / grid_size)^3 cells per frame slot (66 MB at 10 bits and grid 8, 553 MB at
- * 11 bits), one slot per frame of the range up to ~16 GiB in all (larger ranges are smoothed in chunks of
- * frames) — plus 5 bytes per point of capacity and frame for the cell indices and the cell lists.  It is zeroed once,
- * when allocated.  When both filters are asked for with the same grid size, one pass over the points serves both
- * (49 bytes per cell, 4.2 more bytes per point); grids of 2^32 cells and more are not supported.
+ * 34 bytes per cell, w = ceil(2^bitdepth / grid_size), w^3 cells (+ (w + 1)^3 bytes) per frame slot: 71 MB at 10 bits and
+ * grid 8, 570 MB at 11 bits; one slot per frame of the range up to ~16 GiB in all (larger ranges are smoothed in chunks
+ * of frames) — plus 4.3 bytes per point of capacity and frame for the cell lists (reserved; a few per cent of it are
+ * touched).  It is zeroed once, when allocated.  When both filters are asked for with the same grid size, one pass over
+ * the points serves both (50 bytes per cell, 4.4 more bytes per point); grids of 2^32 cells and more are not supported.
  * Bound of the all-sum cells, CHECKED on the device: at most 65 537 points of a frame in one grid cell (65 537 x 65 535
  * < 2^32: no 32-bit sum of coordinates, colours or patch indices can overflow; the specification's u32 sums would wrap
  * where the kernels' packed 64-bit adds would carry).  A frame that exceeds it — hundreds of points per position —

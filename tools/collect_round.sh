@@ -6,7 +6,7 @@ r=$1; ld=$2; ow=$3; sm=$4; drv=$5
 out=profiles/r$(printf %02d $r); mkdir -p $out
 python3 tools/traffic_json.py $ld $r k_recon_tiles "S-longdress, 128 frames per launch (4 GOFs of 32)" > $out/traffic.json
 python3 tools/traffic_json.py $ow $r k_recon_tiles "S-owlii, 128 frames per launch (8 distinct frames x 16)" > $out/traffic_owlii.json
-python3 tools/traffic_json.py $sm $r k_smooth "S-longdress, 128 frames per launch (4 GOFs of 32), geometry + colour smoothing: all eight k_smooth_* launches of a step" > $out/traffic_smooth.json
+python3 tools/traffic_json.py $sm $r k_smooth "S-longdress, 128 frames per launch (4 GOFs of 32), geometry + colour smoothing: every k_smooth_* launch of a step" > $out/traffic_smooth.json
 cp "$(ls -t $ld/stats/*/*_kernel_stats.csv | head -1)" $out/longdress_kernel_stats.csv
 cp "$(ls -t $ow/stats/*/*_kernel_stats.csv | head -1)" $out/owlii_kernel_stats.csv
 cp "$(ls -t $sm/stats/*/*_kernel_stats.csv | head -1)" $out/smooth_kernel_stats.csv
