@@ -105,6 +105,21 @@ def test_decoder_ingest_paths(monkeypatch, longdress32, switch):
     assert err == "" and got == ref[:16] + ref[16:] + ref[:8]
 
 
+@pytest.mark.parametrize("switch", [None, "VPCC_NO_EXTENT_INGEST", "VPCC_NO_PULL_INGEST"])
+def test_decoder_input_page_locked_in_chunks(monkeypatch, longdress32, switch):
+    """An input that is page-locked in several adjacent regions (here: 48-MB chunks; a frame's planes are 18 MB): a stretch
+    of planes, or a single plane, that crosses from one region into the next is copied piece by piece — the runtime refuses
+    a copy whose source does."""
+    frames, ref = longdress32
+    monkeypatch.setenv("VPCC_DECODER_PIN_CHUNK_MB", "48")
+    if switch == "VPCC_NO_PULL_INGEST":
+        monkeypatch.setenv("VPCC_NO_EXTENT_INGEST", "1")
+    if switch:
+        monkeypatch.setenv(switch, "1")
+    got, err = _stream([frames[:12], frames[12:]], devices=(0,))
+    assert err == "" and got == ref
+
+
 def test_config3_three_sequences_sharded_over_two_contexts(longdress32):
     import torch
     devices = (0, 1) if torch.cuda.device_count() >= 2 else (0, 0)

@@ -223,18 +223,40 @@ void Decoder::worker() {
   stats_.lanes = (uint32_t)G;
   for (size_t d = 0; d < G && d < 8; ++d) stats_.numa_node[d] = lanes[d]->numa_node();
 
-  // the input registration is portable (every device may DMA from it); it is made on lane 0's context
+  // The input is page-locked (portable: every device may DMA from it) before the first unit is launched: 50-130 ms for 10 GB.
+  // (Page-locking it chunk by chunk on a thread of its own, ahead of the launches, was tried: the first unit's kernels were done
+  // after 58 ms instead of 110 — but page-locking holds a lock of the runtime's that every allocation and enqueue waits for, the
+  // first FRAME came no sooner and the stream ran at 1 800 frames/s instead of 2 450.)  VPCC_DECODER_PIN_CHUNK_MB page-locks it in
+  // chunks of that size instead of in one piece — stretches of planes and planes that cross from one page-locked region into the
+  // next are copied piece by piece (vpcc_gof_create) —, for tests.
+  struct InputPins {
+    vpcc_ctx* ctx = nullptr;
+    std::vector<const void*> locked;
+    bool lock(const unsigned char* p, size_t bytes, size_t chunk) {
+      const uintptr_t lo = (uintptr_t)p & ~uintptr_t(4095), hi = ((uintptr_t)p + bytes + 4095) & ~uintptr_t(4095);   // whole pages
+      if (!chunk) chunk = hi - lo;
+      for (uintptr_t at = lo; at < hi; at += chunk) {
+        if (vpcc_host_pin(ctx, (const void*)at, (size_t)(std::min<uintptr_t>(at + chunk, hi) - at)) != VPCC_OK) {
+          for (const void* q : locked) (void)vpcc_host_unpin(ctx, q);      // all or nothing: a half page-locked input is of no use
+          locked.clear();
+          return false;
+        }
+        locked.push_back((const void*)at);
+      }
+      return true;
+    }
+    ~InputPins() { for (const void* q : locked) (void)vpcc_host_unpin(ctx, q); }
+  } pins;
+  lanes[0]->post([&pins](vpcc_ctx* c) { pins.ctx = c; return 0; }).get();
   bool pinned = false;
-  if (!file_.empty())
-    pinned = lanes[0]->post([&](vpcc_ctx* c) { return vpcc_host_pin(c, file_.data(), file_.size()); }).get() == VPCC_OK;
+  if (!file_.empty()) {
+    const char* e = std::getenv("VPCC_DECODER_PIN_CHUNK_MB");
+    const size_t chunk = e ? (size_t)std::strtoull(e, nullptr, 10) << 20 : 0;
+    pinned = lanes[0]->post([&](vpcc_ctx*) { return pins.lock(file_.data(), file_.size(), chunk) ? 0 : 1; }).get() == 0;
+  }
   step("input page-locked");
   for (auto& x : reservers.t) if (x.joinable()) x.join();
   step("pools reserved");
-  struct Unpin {
-    Lane* l; const void* p; bool on;
-    ~Unpin() { if (on) l->post([this](vpcc_ctx* c) { return vpcc_host_unpin(c, p); }).get(); }
-  } unpin{lanes[0].get(), file_.data(), pinned};
-
   struct Part {                                       // one device's share of one unit
     std::vector<vpcc_frame_desc> frames;
     vpcc_gof* g = nullptr;

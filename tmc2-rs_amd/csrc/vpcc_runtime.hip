@@ -268,11 +268,25 @@ void forget_pinned(const void* p) {
   for (size_t k = 0; k < g_pinned.size(); ++k)
     if (g_pinned[k].first == (const char*)p) { g_pinned.erase(g_pinned.begin() + k); return; }
 }
-bool inside_one_pinned_region(const char* lo, size_t bytes) {
+// [lo, lo + bytes) as pieces that each lie inside one page-locked region (an input page-locked chunk by chunk: a stretch of
+// planes may cross from one chunk into the next); false if some byte of it is in none.
+bool pinned_pieces(const char* lo, size_t bytes, std::vector<std::pair<const char*, size_t>>* pieces) {
+  pieces->clear();
   {
     std::lock_guard<std::mutex> lock(g_pinned_mutex);
-    for (const auto& r : g_pinned)
-      if (lo >= r.first && lo + bytes <= r.first + r.second) return true;
+    const char* cur = lo;
+    const char* const hi = lo + bytes;
+    while (cur < hi) {
+      const std::pair<const char*, size_t>* in = nullptr;
+      for (const auto& r : g_pinned)
+        if (cur >= r.first && cur < r.first + r.second) { in = &r; break; }
+      if (!in) break;
+      const char* end = std::min(hi, in->first + in->second);
+      pieces->emplace_back(cur, (size_t)(end - cur));
+      cur = end;
+    }
+    if (cur == hi) return true;
+    pieces->clear();
   }
   // page-locked by the caller's own means: both ends map to the device, linearly, as parts of an allocation of one size
   void *d0 = nullptr, *d1 = nullptr, *b0 = nullptr, *b1 = nullptr;
@@ -283,6 +297,7 @@ bool inside_one_pinned_region(const char* lo, size_t bytes) {
                   hipMemGetAddressRange(reinterpret_cast<hipDeviceptr_t*>(&b0), &s0, (hipDeviceptr_t)d0) == hipSuccess &&
                   hipMemGetAddressRange(reinterpret_cast<hipDeviceptr_t*>(&b1), &s1, (hipDeviceptr_t)d1) == hipSuccess && s0 == s1 && s0 >= bytes;
   (void)hipGetLastError();
+  if (ok) pieces->emplace_back(lo, bytes);
   return ok;
 }
 }  // namespace
@@ -607,7 +622,22 @@ namespace {
 // tight device plane.
 int copy_plane(vpcc_ctx* ctx, void* dst, const void* src, size_t elem, uint32_t width, uint32_t height,
                uint32_t stride, hipStream_t s, hipMemcpyKind dir = hipMemcpyHostToDevice) {
-  if (stride == width) {
+  // A host plane may cross from one page-locked region into the next (an input page-locked chunk by chunk): a copy whose
+  // source does is refused by the runtime (invalid argument), so it goes piece by piece.
+  std::vector<std::pair<const char*, size_t>> pieces;
+  const size_t span = height ? ((size_t)stride * (height - 1) + width) * elem : 0;
+  const bool split = dir == hipMemcpyHostToDevice && span && pinned_pieces((const char*)src, span, &pieces) && pieces.size() > 1;
+  if (split && stride == width) {
+    for (const auto& pc : pieces)
+      HIP_TRY(ctx, hipMemcpyAsync((char*)dst + (size_t)(pc.first - (const char*)src), pc.first, pc.second, dir, s));
+  } else if (split) {                                       // padded rows across a boundary: row by row, each row piece by piece
+    for (uint32_t r = 0; r < height; ++r) {
+      const char* row = (const char*)src + (size_t)r * stride * elem;
+      if (!pinned_pieces(row, (size_t)width * elem, &pieces)) pieces.assign(1, {row, (size_t)width * elem});
+      for (const auto& pc : pieces)
+        HIP_TRY(ctx, hipMemcpyAsync((char*)dst + (size_t)r * width * elem + (size_t)(pc.first - row), pc.first, pc.second, dir, s));
+    }
+  } else if (stride == width) {
     HIP_TRY(ctx, hipMemcpyAsync(dst, src, (size_t)width * height * elem, dir, s));
   } else {
     HIP_TRY(ctx, hipMemcpy2DAsync(dst, (size_t)width * elem, src, (size_t)stride * elem, (size_t)width * elem, height, dir, s));
@@ -718,7 +748,7 @@ int gof_create_impl(vpcc_ctx* ctx, const vpcc_frame_desc* frames, uint32_t n_fra
   //   * other tight planes are pulled by kernel (k_ingest_planes), strided ones go through the copy engine one by one.
   const bool pinned = kind == VPCC_MEM_HOST && (gof_flags & VPCC_GOF_ASYNC_UPLOAD);
   struct PlaneRef { const char* src; size_t bytes; size_t* slot; int part; };
-  struct Extent { const char* lo; size_t bytes; size_t dev; int part; };
+  struct Extent { const char* lo; size_t bytes; size_t dev; int part; std::vector<std::pair<const char*, size_t>> pieces; };
   std::vector<Extent> extents;
   bool by_extent = false;
   if (own_planes && pinned && !getenv("VPCC_NO_EXTENT_INGEST")) {
@@ -751,18 +781,18 @@ int gof_create_impl(vpcc_ctx* ctx, const vpcc_frame_desc* frames, uint32_t n_fra
           extents.back().bytes = std::max<size_t>(extents.back().bytes, (size_t)(refs[k].src + refs[k].bytes - extents.back().lo));
           span.back().second = k;
         } else {
-          extents.push_back(Extent{refs[k].src, refs[k].bytes, 0, refs[k].part});
+          extents.push_back(Extent{refs[k].src, refs[k].bytes, 0, refs[k].part, {}});
           span.emplace_back(k, k);
         }
       }
-      // worth it when stretches are long, and every stretch must lie inside ONE page-locked region (what lies between its
+      // worth it when stretches are long, and every stretch must be page-locked memory from end to end (what lies between its
       // planes is copied along)
       by_extent = extents.size() * 4 <= refs.size();
       if (getenv("VPCC_RUNTIME_TRACE")) fprintf(stderr, "[vpcc] ingest: %zu planes in %zu stretches\n", refs.size(), extents.size());
       for (size_t e = 0; e < extents.size() && by_extent; ++e) {
-        by_extent = inside_one_pinned_region(extents[e].lo, extents[e].bytes);
+        by_extent = pinned_pieces(extents[e].lo, extents[e].bytes, &extents[e].pieces);
         if (!by_extent && getenv("VPCC_RUNTIME_TRACE"))
-          fprintf(stderr, "[vpcc] ingest: stretch %zu (%zu bytes at %p) is not inside one page-locked region\n", e, extents[e].bytes,
+          fprintf(stderr, "[vpcc] ingest: stretch %zu (%zu bytes at %p) is not page-locked memory from end to end\n", e, extents[e].bytes,
                   (const void*)extents[e].lo);
       }
       (void)hipGetLastError();
@@ -999,9 +1029,13 @@ int gof_create_impl(vpcc_ctx* ctx, const vpcc_frame_desc* frames, uint32_t n_fra
     launch_ingest_planes(d_pieces, (uint32_t)g->ingest.size(), s);
     HIP_TRY(ctx, hipGetLastError());
   }
+  g->ingest_extents = 0;
   for (const Extent& e : extents)
-    HIP_TRY(ctx, hipMemcpyAsync((char*)g->block[2 * e.part + 0].ptr + e.dev, e.lo, e.bytes, hipMemcpyHostToDevice, s));
-  g->ingest_extents = (uint32_t)extents.size();
+    for (const auto& pc : e.pieces) {                          // (one piece, unless the stretch crosses from one page-locked region into the next)
+      HIP_TRY(ctx, hipMemcpyAsync((char*)g->block[2 * e.part + 0].ptr + e.dev + (size_t)(pc.first - e.lo), pc.first, pc.second,
+                                  hipMemcpyHostToDevice, s));
+      ++g->ingest_extents;
+    }
   // the tile kernel's work lists, from the occupancy planes where they now lie (src/codec.rs:205-250 on the device)
   if (!g->general) {
     launch_plan_tiles(g->d_frames, 0, n_frames, g->max_vb, s);
