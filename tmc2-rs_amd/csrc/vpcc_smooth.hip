@@ -219,12 +219,15 @@ __device__ __forceinline__ void stats_chunk(const QuadIn& in, uint32_t nvalid, c
     cell[j] = (cz * gd.w + cy) * gd.w + cx;
     slot[j] = (cx & 3u) | ((cy & 3u) << 2) | ((cz & 3u) << 4);
   }
-  bool rem[4] = {nvalid > 0u, nvalid > 1u, nvalid > 2u, nvalid > 3u};
+  // (per-lane flags are single variables, not arrays: as arrays that live across the loops below the compiler packs them into
+  // bytes of one register and spends a fifth of the kernel's vector instructions packing and unpacking them)
+  bool rem0 = nvalid > 0u, rem1 = nvalid > 1u, rem2 = nvalid > 2u, rem3 = nvalid > 3u;
+  auto rem = [&](int j) -> bool& { return j == 0 ? rem0 : j == 1 ? rem1 : j == 2 ? rem2 : rem3; };
   do {
     // the patch of the first point that is left (the chunk's first pass: of its first point), and the points of that patch
     uint32_t P = 0;
     {
-      const uint64_t r0 = __ballot(rem[0]), r1 = __ballot(rem[1]), r2 = __ballot(rem[2]), r3 = __ballot(rem[3]);
+      const uint64_t r0 = __ballot(rem0), r1 = __ballot(rem1), r2 = __ballot(rem2), r3 = __ballot(rem3);
       if (r0) P = (uint32_t)__builtin_amdgcn_readlane((int)patch[0], (int)__builtin_ctzll(r0));
       else if (r1) P = (uint32_t)__builtin_amdgcn_readlane((int)patch[1], (int)__builtin_ctzll(r1));
       else if (r2) P = (uint32_t)__builtin_amdgcn_readlane((int)patch[2], (int)__builtin_ctzll(r2));
@@ -237,8 +240,8 @@ __device__ __forceinline__ void stats_chunk(const QuadIn& in, uint32_t nvalid, c
     uint32_t key[4], W[4][5];
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
-      const bool sel = rem[j] && patch[j] == P;
-      rem[j] = rem[j] && !sel;
+      const bool sel = rem(j) && patch[j] == P;
+      rem(j) = rem(j) && !sel;
       key[j] = sel ? cell[j] : kFreeSlot;                     // (a point that is not taken joins nobody and leads nothing)
       W[j][0] = x[j]; W[j][1] = y[j]; W[j][2] = z[j];
       W[j][3] = __builtin_amdgcn_perm(rgb[j], 1u, 0x0C040C00u);          // 1 | R << 16
@@ -246,7 +249,8 @@ __device__ __forceinline__ void stats_chunk(const QuadIn& in, uint32_t nvalid, c
     }
     // 1. points of the lane that share a cell
     const bool s10 = key[1] == key[0], s32 = key[3] == key[2], s20 = key[2] == key[0];
-    bool pend[4] = {key[0] != kFreeSlot, key[1] != kFreeSlot && !s10, key[2] != kFreeSlot && !s20, key[3] != kFreeSlot && !s32};
+    bool pend0 = key[0] != kFreeSlot, pend1 = key[1] != kFreeSlot && !s10, pend2 = key[2] != kFreeSlot && !s20, pend3 = key[3] != kFreeSlot && !s32;
+    auto pend = [&](int j) -> bool& { return j == 0 ? pend0 : j == 1 ? pend1 : j == 2 ? pend2 : pend3; };
 #define VPCC_JOIN(cond, to, from)                                                         \
     {                                                                                     \
       _Pragma("unroll") for (int q = 0; q < 5; ++q) if ((kLaneWords >> q) & 1u) W[to][q] += (cond) ? W[from][q] : 0u; \
@@ -258,19 +262,19 @@ __device__ __forceinline__ void stats_chunk(const QuadIn& in, uint32_t nvalid, c
     // ... and neighbouring lanes whose first leaders share a cell: lane pairs, then pairs of pairs (the LDS serves the lanes of
     // one slot one after the other; a CU has ONE LDS, and it is this kernel's busiest unit)
     {
-      // (the neighbour's cell is fetched by every lane, before any condition: a DPP read under `pend[0] && ...` runs with the
+      // (the neighbour's cell is fetched by every lane, before any condition: a DPP read under `pend0 && ...` runs with the
       // lanes without a leader switched off, and reads 0 from them — the index of a cell)
       const uint32_t key1 = qperm<0xB1>(key[0]);                                // lane ^ 1
-      const bool same1 = pend[0] && key1 == key[0];
+      const bool same1 = pend0 && key1 == key[0];
 #pragma unroll
       for (int q = 0; q < 5; ++q) if ((kLaneWords >> q) & 1u) { const uint32_t o = qperm<0xB1>(W[0][q]); W[0][q] += (same1 && !(lane & 1u)) ? o : 0u; }
-      if (same1 && (lane & 1u)) pend[0] = false;
-      const uint32_t key2 = pend[0] ? key[0] : kFreeSlot;
+      if (same1 && (lane & 1u)) pend0 = false;
+      const uint32_t key2 = pend0 ? key[0] : kFreeSlot;
       const uint32_t key3 = qperm<0x4E>(key2);                                  // lane ^ 2 (lanes 0 and 2 of a quad: never given away above)
-      const bool same2 = pend[0] && key3 == key[0];
+      const bool same2 = pend0 && key3 == key[0];
 #pragma unroll
       for (int q = 0; q < 5; ++q) if ((kLaneWords >> q) & 1u) { const uint32_t o = qperm<0x4E>(W[0][q]); W[0][q] += (same2 && !(lane & 2u)) ? o : 0u; }
-      if (same2 && (lane & 2u)) pend[0] = false;
+      if (same2 && (lane & 2u)) pend0 = false;
     }
     for (;;) {
       // 2. a slot each: compare-and-swap "free -> my cell" (a lane without a leader does it to its dump slot), in the
@@ -278,9 +282,9 @@ __device__ __forceinline__ void stats_chunk(const QuadIn& in, uint32_t nvalid, c
       uint32_t at[4];
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
-        at[j] = pend[j] ? slot[j] : 64u + lane;
+        at[j] = pend(j) ? slot[j] : 64u + lane;
         if (j == 0) atomicCAS(&T.key[at[j]], kFreeSlot, key[j]);
-        else if (pend[j]) atomicCAS(&T.key[at[j]], kFreeSlot, key[j]);
+        else if (pend(j)) atomicCAS(&T.key[at[j]], kFreeSlot, key[j]);
       }
       __builtin_amdgcn_wave_barrier();
       // 3. add (a leader that did not get its slot: to the dump)
@@ -295,22 +299,22 @@ __device__ __forceinline__ void stats_chunk(const QuadIn& in, uint32_t nvalid, c
           if (kWords & 16u) atomicAdd(&T.acc[4][to], W[j][4] >> 16);
         };
         if (j == 0) {                                         // every lane that kept its first leader: no branch
-          const bool hit = pend[j] && T.key[at[j]] == key[j];
+          const bool hit = pend(j) && T.key[at[j]] == key[j];
           add(hit ? at[j] : 64u + lane);
-          pend[j] = pend[j] && !hit;
-        } else if (pend[j]) {                                 // few lanes have one here
+          pend(j) = pend(j) && !hit;
+        } else if (pend(j)) {                                 // few lanes have one here
           if (T.key[at[j]] == key[j]) {
             add(at[j]);
-            pend[j] = false;
+            pend(j) = false;
           }
         }
       }
       __builtin_amdgcn_wave_barrier();
-      if (__ballot(pend[0] || pend[1] || pend[2] || pend[3]) == 0) break;
+      if (__ballot(pend0 || pend1 || pend2 || pend3) == 0) break;
       // 4. somebody's slot is taken by another cell: deliver what the table holds, and again
       stats_flush<kMode>(T, dst, tpatch, m, lane);
     }
-  } while (__ballot(rem[0] || rem[1] || rem[2] || rem[3]) != 0);
+  } while (__ballot(rem0 || rem1 || rem2 || rem3) != 0);
 }
 
 template <uint32_t kMode>
@@ -347,9 +351,9 @@ __global__ __launch_bounds__(256) void k_smooth_stats(const DevFrame* __restrict
   dst.cgrid = sg.color_cells(blockIdx.y);
   dst.list = sg.lists(blockIdx.y) + (size_t)span * kSmoothListLen;
   uint32_t m = 0, tpatch = 0;
-  // All of the wave's points are fetched before the first is looked at: gfx9 counts loads and stores with ONE in-order
-  // counter, so a wait for a load issued while the table's atomics are in flight is a wait for those atomics (with the
-  // next chunk fetched during the current one, the kernel spent 37 % of its time in such waits).
+  // All of the wave's points are fetched before the first is looked at (fetching the next chunk during the current one is
+  // no faster and no slower; gfx9 counts loads and stores with ONE in-order counter, so a wait for a load issued while the
+  // table's atomics are in flight would be a wait for those atomics).
   QuadIn in[kStatChunks];
 #pragma unroll
   for (uint32_t c = 0; c < kStatChunks; ++c) in[c] = load_stat_input<kMode>(f, (span * kStatChunks + c) * 64u + lane, n);
