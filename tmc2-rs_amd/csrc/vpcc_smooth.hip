@@ -98,7 +98,7 @@ __device__ __forceinline__ void unpack_rgb(const uint32_t (&c)[3], uint32_t (&rg
 // value of the lane's partner inside its quad of four lanes (DPP quad_perm)
 template <int kCtrl>
 __device__ __forceinline__ uint32_t qperm(uint32_t v) {
-  return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, kCtrl, 0xF, 0xF, false);
+  return (uint32_t)__builtin_amdgcn_mov_dpp((int)v, kCtrl, 0xF, 0xF, true);     // (every lane of a quad has its partner: nothing to preset)
 }
 
 // ---- statistics ----------------------------------------------------------------------------------------------------
