@@ -572,6 +572,19 @@ __device__ __forceinline__ uint32_t mean_small(uint32_t a, uint32_t b, float inv
   return q;
 }
 
+// The weights of a point inside the grid are 1 .. 2 G - 1 per axis: for grids up to 512 their products stay below 2^30 and a
+// weighted sum is one 32 x 32 + 64-bit multiply-add per cell and value.  (Weights of a point outside the grid can be negative
+// or large: 64-bit arithmetic as the specification writes it.)
+__device__ __forceinline__ bool small_weights(const int64_t (&wt)[3][2]) {
+  return (uint64_t)(wt[0][0] | wt[0][1] | wt[1][0] | wt[1][1] | wt[2][0] | wt[2][1]) < 1024u;
+}
+__device__ __forceinline__ void hood_weights32(const int64_t (&wt)[3][2], uint32_t (&W)[8]) {
+  const uint32_t xy[4] = {(uint32_t)wt[0][0] * (uint32_t)wt[1][0], (uint32_t)wt[0][1] * (uint32_t)wt[1][0],
+                          (uint32_t)wt[0][0] * (uint32_t)wt[1][1], (uint32_t)wt[0][1] * (uint32_t)wt[1][1]};
+#pragma unroll
+  for (int d = 0; d < 8; ++d) W[d] = xy[d & 3] * (uint32_t)wt[2][d >> 2];
+}
+
 template <bool kPow2>
 __device__ __forceinline__ void smooth_apply_geometry_point(const DevFrame& f, uint32_t frame, uint32_t i, const SmoothGrid& sg,
                                                             const GridDims& gd, uint32_t T, bool both, const uint32_t (&p)[3]) {
@@ -582,14 +595,27 @@ __device__ __forceinline__ void smooth_apply_geometry_point(const DevFrame& f, u
 #pragma unroll
   for (int a = 0; a < 3; ++a) axis_weights(p[a], S[a], gd.G, wt[a]);
   int64_t num[3] = {0, 0, 0}, den = 0;
+  if (small_weights(wt)) {
+    uint32_t W[8];
+    hood_weights32(wt, W);
+    uint64_t n0 = 0, n1 = 0, n2 = 0, dn = 0;
 #pragma unroll
-  for (int d = 0; d < 8; ++d) {
-    const u32x4 c = h.c[d];
-    const uint32_t count = c.x & kCountMask;
-    if (!count) continue;
-    const int64_t W = wt[0][d & 1] * wt[1][(d >> 1) & 1] * wt[2][d >> 2];
-    num[0] += W * c.y; num[1] += W * c.z; num[2] += W * c.w;
-    den += W * count;
+    for (int d = 0; d < 8; ++d) {                           // (an empty or absent cell adds nothing: its sums are zero)
+      const u32x4 c = h.c[d];
+      n0 += (uint64_t)W[d] * c.y; n1 += (uint64_t)W[d] * c.z; n2 += (uint64_t)W[d] * c.w;
+      dn += (uint64_t)W[d] * (c.x & kCountMask);
+    }
+    num[0] = (int64_t)n0; num[1] = (int64_t)n1; num[2] = (int64_t)n2; den = (int64_t)dn;
+  } else {
+#pragma unroll
+    for (int d = 0; d < 8; ++d) {
+      const u32x4 c = h.c[d];
+      const uint32_t count = c.x & kCountMask;
+      if (!count) continue;
+      const int64_t W = wt[0][d & 1] * wt[1][(d >> 1) & 1] * wt[2][d >> 2];
+      num[0] += W * c.y; num[1] += W * c.z; num[2] += W * c.w;
+      den += W * count;
+    }
   }
   if (den <= 0) return;
   int64_t C[3], d2 = 0;
@@ -706,22 +732,49 @@ __device__ __forceinline__ void smooth_apply_color_point(const DevFrame& f, uint
                          (int32_t)mean_small(cc.w, own_count, own_inv)};
   int64_t num[3] = {0, 0, 0}, den = 0;
   bool mixed = false;
+  if (small_weights(wt)) {
+    // (32-bit weights, one multiply-add per cell and value, see the geometry filter; no branches: a cell that does not take part —
+    // empty, or its mean too far from the own cell's — has the weight 0)
+    uint32_t W32[8];
+    hood_weights32(wt, W32);
+    uint64_t un[4] = {0, 0, 0, 0};
 #pragma unroll
-  for (int d = 0; d < 8; ++d) {
-    const u32x4 c = h.c[d];
-    const uint32_t count = c.x & kCountMask;
-    if (!count) continue;
-    if (d != own) {
-      const float inv = 1.0f / (float)count;
-      const int32_t m0 = (int32_t)mean_small(c.y, count, inv) - mc[0], m1 = (int32_t)mean_small(c.z, count, inv) - mc[1],
-                    m2 = (int32_t)mean_small(c.w, count, inv) - mc[2];
-      const uint32_t diff = (uint32_t)((m0 < 0 ? -m0 : m0) + (m1 < 0 ? -m1 : m1) + (m2 < 0 ? -m2 : m2));
-      if (diff > Td) continue;
+    for (int d = 0; d < 8; ++d) {
+      const u32x4 c = h.c[d];
+      const uint32_t count = c.x & kCountMask;
+      bool use = count != 0u;
+      if (d != own) {
+        const uint32_t cnt1 = count ? count : 1u;
+        const float inv = 1.0f / (float)cnt1;
+        const int32_t m0 = (int32_t)mean_small(c.y, cnt1, inv) - mc[0], m1 = (int32_t)mean_small(c.z, cnt1, inv) - mc[1],
+                      m2 = (int32_t)mean_small(c.w, cnt1, inv) - mc[2];
+        const uint32_t diff = (uint32_t)((m0 < 0 ? -m0 : m0) + (m1 < 0 ? -m1 : m1) + (m2 < 0 ? -m2 : m2));
+        use = use && diff <= Td;
+      }
+      const uint32_t W = use ? W32[d] : 0u;
+      un[0] += (uint64_t)W * c.y; un[1] += (uint64_t)W * c.z; un[2] += (uint64_t)W * c.w;
+      un[3] += (uint64_t)W * count;
+      mixed |= use && (c.x & kSmoothCountMixed) != 0;
     }
-    const int64_t W = wt[0][d & 1] * wt[1][(d >> 1) & 1] * wt[2][d >> 2];
-    num[0] += W * c.y; num[1] += W * c.z; num[2] += W * c.w;
-    den += W * count;
-    mixed |= (c.x & kSmoothCountMixed) != 0;
+    num[0] = (int64_t)un[0]; num[1] = (int64_t)un[1]; num[2] = (int64_t)un[2]; den = (int64_t)un[3];
+  } else {
+#pragma unroll
+    for (int d = 0; d < 8; ++d) {
+      const u32x4 c = h.c[d];
+      const uint32_t count = c.x & kCountMask;
+      if (!count) continue;
+      if (d != own) {
+        const float inv = 1.0f / (float)count;
+        const int32_t m0 = (int32_t)mean_small(c.y, count, inv) - mc[0], m1 = (int32_t)mean_small(c.z, count, inv) - mc[1],
+                      m2 = (int32_t)mean_small(c.w, count, inv) - mc[2];
+        const uint32_t diff = (uint32_t)((m0 < 0 ? -m0 : m0) + (m1 < 0 ? -m1 : m1) + (m2 < 0 ? -m2 : m2));
+        if (diff > Td) continue;
+      }
+      const int64_t W = wt[0][d & 1] * wt[1][(d >> 1) & 1] * wt[2][d >> 2];
+      num[0] += W * c.y; num[1] += W * c.z; num[2] += W * c.w;
+      den += W * count;
+      mixed |= (c.x & kSmoothCountMixed) != 0;
+    }
   }
   if (!mixed || den <= 0) return;
   int64_t m[3], dist = 0;
