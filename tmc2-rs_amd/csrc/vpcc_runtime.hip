@@ -1490,7 +1490,7 @@ extern "C" int vpcc_gof_smooth(vpcc_gof* g, uint32_t first, uint32_t count, cons
       T.end();
       T.begin(kNames[1][tag]);
       launch_smooth_mark(g->d_frames, c0, c, max_points, sg, w, s);
-      launch_smooth_spans(g->d_frames, c0, c, max_points, sg, false, s);     // (timed with the marking: which spans of points have anything to do)
+      launch_smooth_spans(g->d_frames, c0, c, max_points, sg, s);     // (timed with the marking: which spans of points have anything to do)
       T.end();
       if (geo) {
         T.begin("k_smooth_apply_geometry");
@@ -1500,7 +1500,6 @@ extern "C" int vpcc_gof_smooth(vpcc_gof* g, uint32_t first, uint32_t count, cons
       if (both) {
         T.begin("k_smooth_moved");
         launch_smooth_moved(g->d_frames, c0, c, max_points, sg, w, G, s);
-        launch_smooth_spans(g->d_frames, c0, c, max_points, sg, true, s);   // (cells may have become mixed)
         T.end();
       }
       if (!geo || both) {

@@ -14,7 +14,8 @@
 //   k_smooth_mark       : walks the lists; a cell that mixes patches (one in a hundred) gets its bit, a byte flag on each of
 //                         the eight 2x2x2 neighbourhoods it belongs to (a neighbourhood is named by its lower corner) and one
 //                         on each of the 27 cells around it;
-//   k_smooth_spans      : which spans have anything to do: those with a listed cell that carries the second kind of flag;
+//   k_smooth_spans      : which spans have anything to do: those with a listed cell that carries the second kind of flag
+//                         (once per pass; the colour filter looks again itself where the geometry filter made cells mixed);
 //   k_smooth_apply      : the filters.  Waves of the other spans leave at once; the rest derive each point's neighbourhood
 //                         from its position, ONE flag load says whether any of its eight cells mixes patches, and only then
 //                         are they read (16 bytes each) -> integer trilinear weights -> centroid / mean, thresholded
@@ -802,15 +803,9 @@ __device__ __forceinline__ void smooth_apply_color_point(const DevFrame& f, uint
 
 // Which spans of kSmoothListSpan points have anything to do: those whose list holds a cell with a mixed cell among the
 // 27 around it — one span in six.  A wave sees to four lists, their loads issued together.
-__global__ __launch_bounds__(256) void k_smooth_spans(const DevFrame* __restrict__ frames, uint32_t first, SmoothGrid sg,
-                                                      bool again) {
-  // again: the pass behind the geometry filter — nothing to do unless a cell has become mixed since (k_smooth_moved_mark)
-  uint32_t* dirty = sg.frame_dirty(blockIdx.y);
-  if (again) {
-    if (*gl(dirty) == 0u) return;
-  } else if (blockIdx.x == 0 && threadIdx.x == 0) {
-    *dirty = 0u;
-  }
+__global__ __launch_bounds__(256) void k_smooth_spans(const DevFrame* __restrict__ frames, uint32_t first, SmoothGrid sg) {
+  // (the frame's "a cell has become mixed behind the geometry filter" word starts at zero: k_smooth_moved_mark, k_smooth_apply)
+  if (blockIdx.x == 0 && threadIdx.x == 0) *sg.frame_dirty(blockIdx.y) = 0u;
   const DevFrame& f = frames[first + blockIdx.y];
   const uint32_t n = min(*gl(f.n_points), f.capacity);
   const uint32_t lane = threadIdx.x & 63u;
@@ -853,8 +848,20 @@ __global__ __launch_bounds__(256) void k_smooth_apply(const DevFrame* __restrict
   const uint32_t base = (blockIdx.x * 4u + wave) * kApplyUnit;
   if (base >= f.capacity) return;
   const uint32_t active = gl(sg.span_flags(blockIdx.y))[base / kSmoothListSpan];     // (a span beyond the frame's points: whatever)
+  // the colour filter of a pass that serves both: cells may have become mixed behind the geometry filter (k_smooth_moved_mark
+  // says so per frame, rarely) — then the span's list is looked through again here, as k_smooth_spans did
+  const uint32_t dirty = kColor && both ? *gl(sg.frame_dirty(blockIdx.y)) : 0u;
   const uint32_t n = min(*gl(f.n_points), f.capacity);
-  if (base >= n || !active) return;
+  if (base >= n) return;
+  if (!active) {
+    if (!dirty) return;
+    const uint32_t span = base / kSmoothListSpan, cnt = gl(sg.list_counts(blockIdx.y))[span];
+    const uint32_t* list = sg.lists(blockIdx.y) + (size_t)span * kSmoothListLen;
+    const unsigned char* near = sg.near(blockIdx.y);
+    bool any = false;
+    for (uint32_t j = lane; j < cnt; j += 64u) any = any || gl(near)[gl(list)[j]] != 0;
+    if (__ballot(any) == 0) return;
+  }
   const unsigned char* flags = sg.flags(blockIdx.y);
   QuadXyz raw[kApplyQuads];
 #pragma unroll
@@ -939,12 +946,11 @@ void launch_smooth_moved(const DevFrame* d_frames, uint32_t first, uint32_t coun
   if (pow2(G)) hipLaunchKernelGGL(k_smooth_moved_mark<true>, grid, block, 0, (hipStream_t)stream, d_frames, first, sg, gd);
   else hipLaunchKernelGGL(k_smooth_moved_mark<false>, grid, block, 0, (hipStream_t)stream, d_frames, first, sg, gd);
 }
-void launch_smooth_spans(const DevFrame* d_frames, uint32_t first, uint32_t count, uint32_t max_points, SmoothGrid sg, bool again,
-                         void* stream) {
+void launch_smooth_spans(const DevFrame* d_frames, uint32_t first, uint32_t count, uint32_t max_points, SmoothGrid sg, void* stream) {
   if (!count || !max_points) return;
   const uint32_t per_block = 16u * kSmoothListSpan;
   hipLaunchKernelGGL(k_smooth_spans, dim3((max_points + per_block - 1) / per_block, count), dim3(256), 0, (hipStream_t)stream, d_frames,
-                     first, sg, again);
+                     first, sg);
 }
 void launch_smooth_mark(const DevFrame* d_frames, uint32_t first, uint32_t count, uint32_t max_points, SmoothGrid sg,
                         uint32_t w, void* stream) {
