@@ -97,6 +97,7 @@ struct vpcc_gof {
   size_t ctrl_bytes = 0;
   uint32_t max_vb = 0;
   uint32_t* h_counts = nullptr;        // pinned: counts[n_frames] then errors[n_frames]
+  bool h_counts_in_stage = false;      // ... inside the descriptor staging buffer (not an allocation of its own)
   bool counts_valid = false;
   bool launched = false;
   std::vector<IngestPiece> ingest;     // plane ingest by kernel: the pieces (alive while their upload may read them)
@@ -612,7 +613,9 @@ extern "C" void vpcc_gof_destroy(vpcc_gof* gof) {
     else (void)hipHostFree(gof->stage);
   }
   for (vpcc_ctx::Block& B : gof->block) release_block(gof->ctx, B);
-  if (gof->h_counts) (void)hipHostFree(gof->h_counts);
+  // (hipHostFree waits for the whole device — in a lane of the streaming Decoder: for the next units' ingest, 70 ms — so a gof
+  // with a staging buffer keeps its counts in it, and the buffer goes back to the context's cache)
+  if (gof->h_counts && !gof->h_counts_in_stage) (void)hipHostFree(gof->h_counts);
   delete gof;
 }
 
@@ -858,18 +861,23 @@ int gof_create_impl(vpcc_ctx* ctx, const vpcc_frame_desc* frames, uint32_t n_fra
   char* base = (char*)g->arena;
   // descriptor staging: a page-locked buffer of the context's (kept for the next gof)
   const bool staged = pinned && !getenv("VPCC_NO_STAGED_DESCRIPTORS");
+  const size_t stage_need = align_up(host_end, 256) + sizeof(uint32_t) * 2 * n_frames;
   if (staged) {
     for (size_t k = 0; k < ctx->stage_cache.size(); ++k)
-      if (ctx->stage_cache[k].second >= host_end) {
+      if (ctx->stage_cache[k].second >= stage_need) {
         g->stage = ctx->stage_cache[k].first;
         g->stage_bytes = ctx->stage_cache[k].second;
         ctx->stage_cache.erase(ctx->stage_cache.begin() + k);
         break;
       }
     if (!g->stage) {
-      g->stage_bytes = host_end + host_end / 4;
+      g->stage_bytes = stage_need + stage_need / 4;
       HIP_TRY(ctx, hipHostMalloc(&g->stage, g->stage_bytes, hipHostMallocDefault));
     }
+    g->h_counts = (uint32_t*)((char*)g->stage + align_up(host_end, 256));      // the point counts come back into the same buffer
+    g->h_counts_in_stage = true;
+  } else {
+    HIP_TRY(ctx, hipHostMalloc((void**)&g->h_counts, sizeof(uint32_t) * 2 * n_frames, hipHostMallocDefault));
   }
   char* const stage = (char*)g->stage;
   auto kb = [&](uint32_t i, int kind, int) { return (char*)g->block[2 * part_of(i) + kind].ptr; };
@@ -879,7 +887,6 @@ int gof_create_impl(vpcc_ctx* ctx, const vpcc_frame_desc* frames, uint32_t n_fra
   g->d_tickets = (uint32_t*)(base + off_tickets);
   g->d_errors = (uint32_t*)(base + off_errors);
   g->d_scan = (uint64_t*)(base + off_scan);
-  HIP_TRY(ctx, hipHostMalloc((void**)&g->h_counts, sizeof(uint32_t) * 2 * n_frames, hipHostMallocDefault));
   HIP_TRY(ctx, hipEventCreateWithFlags(&g->upload_done, hipEventDisableTiming));
   HIP_TRY(ctx, hipEventCreateWithFlags(&g->results_ready, hipEventDisableTiming));
 
@@ -1196,9 +1203,23 @@ int fetch_counts(vpcc_gof* g) {
   if (g->counts_valid) return VPCC_OK;
   hipStream_t s = g->ctx->d2h_stream;
   HIP_TRY(g->ctx, hipStreamWaitEvent(s, g->results_ready, 0));
-  HIP_TRY(g->ctx, hipMemcpyAsync(g->h_counts, g->d_counts, sizeof(uint32_t) * g->n_frames, hipMemcpyDeviceToHost, s));
-  HIP_TRY(g->ctx, hipMemcpyAsync(g->h_counts + g->n_frames, g->d_errors, sizeof(uint32_t) * g->n_frames,
-                                 hipMemcpyDeviceToHost, s));
+  // The counts are PUSHED into their page-locked buffer by a kernel: as copies they go through a copy engine's queue, and in the
+  // streaming Decoder that queue holds the 40 ms of the next unit's planes — every unit's point counts came back a unit late,
+  // and with them its downloads and the creation of the unit after next (rocprofv3 --hip-runtime-trace: the lane sat in this
+  // synchronisation from the end of one unit's ingest to the end of the next one's).
+  void* dev_counts = nullptr;
+  if (!getenv("VPCC_NO_PUSH_DOWNLOAD") && hipHostGetDevicePointer(&dev_counts, g->h_counts, 0) == hipSuccess && dev_counts) {
+    IngestPiece pieces[3] = {};
+    pieces[0] = IngestPiece{g->d_counts, dev_counts, (uint32_t)(sizeof(uint32_t) * g->n_frames), 0u};
+    pieces[1] = IngestPiece{g->d_errors, (char*)dev_counts + sizeof(uint32_t) * g->n_frames, (uint32_t)(sizeof(uint32_t) * g->n_frames), 0u};
+    launch_push_results(pieces, s);
+    HIP_TRY(g->ctx, hipGetLastError());
+  } else {
+    (void)hipGetLastError();
+    HIP_TRY(g->ctx, hipMemcpyAsync(g->h_counts, g->d_counts, sizeof(uint32_t) * g->n_frames, hipMemcpyDeviceToHost, s));
+    HIP_TRY(g->ctx, hipMemcpyAsync(g->h_counts + g->n_frames, g->d_errors, sizeof(uint32_t) * g->n_frames,
+                                   hipMemcpyDeviceToHost, s));
+  }
   HIP_TRY(g->ctx, hipStreamSynchronize(s));
   for (uint32_t i = 0; i < g->n_frames; ++i)
     if (g->h_counts[g->n_frames + i] & kErrorSpinLimit)
@@ -1330,7 +1351,9 @@ extern "C" int vpcc_gof_download_wait(vpcc_gof* g, uint32_t frame) {
 extern "C" int vpcc_gof_kernel_times(vpcc_gof* g, const char** names_out, float* ms_out, int max) {
   if (!g || g->launches_profiled == 0) return 0;
   (void)hipSetDevice(g->ctx->device);
-  if (g->last_stream) (void)hipStreamSynchronize(g->last_stream);
+  // (this gof's last kernel — not its stream: in the streaming Decoder that stream already carries the NEXT unit's launch, which
+  // waits for that unit's 40 ms of planes; the lane sat here a whole unit long and posted the unit after next that much too late)
+  if (g->launched) (void)hipEventSynchronize(g->results_ready);
   const LaunchTimings& l = g->history[(g->launches_profiled - 1) % kProfileRing];
   int n = 0;
   for (uint32_t i = 0; i < l.n && n < max; ++i, ++n) {
@@ -1353,7 +1376,7 @@ extern "C" int vpcc_gof_kernel_time_means(vpcc_gof* g, uint32_t last_n, const ch
   if (launches_out) *launches_out = 0;
   if (!g || g->launches_profiled == 0 || max <= 0) return 0;
   (void)hipSetDevice(g->ctx->device);
-  if (g->last_stream) (void)hipStreamSynchronize(g->last_stream);
+  if (g->launched) (void)hipEventSynchronize(g->results_ready);
   const uint64_t have = std::min<uint64_t>(g->launches_profiled, kProfileRing);
   const uint64_t take = std::min<uint64_t>(last_n ? last_n : have, have);
   std::vector<const char*> names;
