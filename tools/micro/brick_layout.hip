@@ -1,7 +1,7 @@
 // micro-benchmark: does a BRICKED cell grid (4 x 4 x 4 cells = 2 KB contiguous) serve the smoothing passes' scattered 32-byte cell
 // accesses faster than the linear (z, y, x) one?  Real cell lists (tools/micro/bin/cell_lists.{hdr,bin}: 8 S-longdress frames, the cells
 // of every span of 1 024 points in order of first appearance), 128 frame slots of w^3 = 128^3 cells of 32 B + colour cells of 16 B, as
-// in k_smooth_clear (stores only) and k_smooth_mark (one 32-byte read per entry).
+// in k_smooth_clear (stores only) and k_smooth_mark (one 32-byte read per entry).  The lists: tools/micro/gen_cell_lists.py.
 #include <hip/hip_runtime.h>
 #include <cstdio>
 #include <cstdlib>
