@@ -565,8 +565,12 @@ __device__ __forceinline__ int64_t div_small(int64_t a, int64_t b, double inv_b)
   q += r < 0 ? -1 : r >= b ? 1 : 0;
   return q;
 }
-// floor(a / b) for a < 2^24 and a / b < 2^8 (a sum of up to 65 537 bytes over their number)
+// floor(a / b) for a < 2^24 and a / b < 2^8 (a sum of up to 65 537 bytes over their number), inv_b = fl(1 / b).
+// For b < 8 190 without a correction: (a + 0.5) / b has the integer part of a / b and is at least 0.5 / b > 6.1e-5 away from
+// every integer, and fl((a + 0.5) fl(1 / b)) — a + 0.5 < 2^21 + 0.5 is exact, one rounding in the product — is within
+// 255.5 x 2^-23 = 3.1e-5 of it.  (A cell of grid size 8 holds a few hundred points.)
 __device__ __forceinline__ uint32_t mean_small(uint32_t a, uint32_t b, float inv_b) {
+  if (b < 8190u) return (uint32_t)__builtin_fmaf((float)a, inv_b, 0.5f * inv_b);
   uint32_t q = (uint32_t)((float)a * inv_b);
   const int32_t r = (int32_t)(a - q * b);
   q += r < 0 ? -1 : (uint32_t)r >= b ? 1 : 0;
