@@ -14,6 +14,8 @@
 #include <sstream>
 #include <stdexcept>
 
+#include <sys/mman.h>
+
 namespace tmc2rs {
 
 // ------------------------------------------------------------------ PinnedPool
@@ -68,7 +70,15 @@ void Decoder::start() {
     std::ifstream in(path, std::ios::binary | std::ios::ate);
     if (!in) throw std::runtime_error("cannot open " + path);
     const size_t n = (size_t)in.tellg();
-    out->resize(at + ((n + 15) & ~size_t(15)));        // next section starts 16-B aligned
+    const size_t upto = at + ((n + 15) & ~size_t(15));     // next section starts 16-B aligned
+    // The buffer is page-locked later and read by the copy engines: ask for huge pages BEFORE its first touch (resize
+    // zero-fills) — page-locking then handles 2-MB pages instead of 4-KB ones.  Advice only; VPCC_DECODER_NO_HUGEPAGES=1: none.
+    if (upto > out->capacity() && upto >= (size_t(64) << 20) && !std::getenv("VPCC_DECODER_NO_HUGEPAGES")) {
+      out->reserve(upto);
+      const uintptr_t lo = ((uintptr_t)out->data() + 4095) & ~uintptr_t(4095), hi = ((uintptr_t)out->data() + out->capacity()) & ~uintptr_t(4095);
+      if (hi > lo) (void)madvise((void*)lo, (size_t)(hi - lo), MADV_HUGEPAGE);
+    }
+    out->resize(upto);
     in.seekg(0);
     in.read(reinterpret_cast<char*>(out->data() + at), (std::streamsize)n);
     return n;
@@ -194,7 +204,7 @@ void Decoder::worker() {
     if (lanes[d]->post([](vpcc_ctx* c) { return c ? 0 : 1; }).get()) { fail("vpcc_ctx_create failed: no usable gfx950 device (no CPU fallback)"); return; }
   step("contexts ready");
   // Two homes (vpcc_ctx_reserve): every lane's context gets its pool — on a thread of its own while this thread
-  // page-locks the input (50-130 ms of host work; the allocation and its classification take 30-50 ms of an otherwise
+  // page-locks the input (16-300 ms of host work; the allocation and its classification take 30-50 ms of an otherwise
   // idle GPU: timed beside uploads and kernels the classification goes wrong), joined before the first unit is launched.
   // Every gof then keeps its planes and outputs in it, spread over both kinds of VRAM regions.  Streams of a single
   // GOF do not bother; VPCC_DECODER_POOL_GIB=0 switches it off.
@@ -223,7 +233,8 @@ void Decoder::worker() {
   stats_.lanes = (uint32_t)G;
   for (size_t d = 0; d < G && d < 8; ++d) stats_.numa_node[d] = lanes[d]->numa_node();
 
-  // The input is page-locked (portable: every device may DMA from it) before the first unit is launched: 50-130 ms for 10 GB.
+  // The input is page-locked (portable: every device may DMA from it) before the first unit is launched: 16 ms for 10 GB of
+  // huge pages (start() asks for them), 50-300 ms for 4-KB pages.
   // (Page-locking it chunk by chunk on a thread of its own, ahead of the launches, was tried: the first unit's kernels were done
   // after 58 ms instead of 110 — but page-locking holds a lock of the runtime's that every allocation and enqueue waits for, the
   // first FRAME came no sooner and the stream ran at 1 800 frames/s instead of 2 450.)  VPCC_DECODER_PIN_CHUNK_MB page-locks it in
