@@ -190,7 +190,8 @@ void Decoder::worker() {
   // than four launches over 32.
   const size_t G = params_.devices.empty() ? 1 : params_.devices.size();
   const auto t_worker = std::chrono::steady_clock::now();
-  const bool trace_steps = std::getenv("VPCC_DECODER_TRACE") != nullptr && std::getenv("VPCC_DECODER_TRACE")[0] == '2';
+  const char* const trace_env = std::getenv("VPCC_DECODER_TRACE");
+  const bool trace_steps = trace_env != nullptr && trace_env[0] == '2';
   auto step = [&](const char* what) {                   // VPCC_DECODER_TRACE=2: the start-up, step by step
     if (trace_steps)
       std::fprintf(stderr, "[vpcc decoder] +%.1f ms %s   (@%.1f)\n",
