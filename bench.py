@@ -169,7 +169,9 @@ def main():
     red_dev = "cuda" if backend == "nccl" else "cpu"
     torch.cuda.set_device(local_rank)
     dist = None
-    if world > 1:
+    # (VPCC_BENCH_FORCE_DIST=1: a one-rank job joins a process group too — the RCCL bookkeeping of the N > 1 path, its
+    # barriers and reductions, rehearsed on a box with one GPU)
+    if world > 1 or os.environ.get("VPCC_BENCH_FORCE_DIST"):
         import torch.distributed as dist
         if backend == "nccl":
             dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))   # nccl == RCCL on ROCm
