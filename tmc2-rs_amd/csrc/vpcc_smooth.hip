@@ -23,8 +23,8 @@
 //   k_smooth_moved_mark : both filters in one pass: the cells moved points left and entered are looked at again;
 //   k_smooth_clear      : walks the lists again: zeroes exactly the listed cells and un-paints the flags (stores only).
 // Round 4 rewrote them around the quad (round 3: a thread per point, a 4-byte cell index stored per point and read back
-// by both filters, flags on the 3x3x3 block around a mixed cell): 2.19 -> 1.09 ms per 128 S-longdress frames, memory
-// traffic 2.13 -> 1.09 x the algorithmic bytes.
+// by both filters, flags on the 3x3x3 block around a mixed cell): 2.19 -> 0.98 ms per 128 S-longdress frames, memory
+// traffic 2.13 -> 1.16 x the algorithmic bytes.
 #include <hip/hip_runtime.h>
 
 #include "vpcc_device.hpp"
@@ -352,19 +352,18 @@ __global__ __launch_bounds__(256) void k_smooth_stats(const DevFrame* __restrict
   dst.cgrid = sg.color_cells(blockIdx.y);
   dst.list = sg.lists(blockIdx.y) + (size_t)span * kSmoothListLen;
   uint32_t m = 0, tpatch = 0;
-  // All of the wave's points are fetched before the first is looked at (fetching the next chunk during the current one is
-  // no faster and no slower; gfx9 counts loads and stores with ONE in-order counter, so a wait for a load issued while the
-  // table's atomics are in flight would be a wait for those atomics).
-  QuadIn in[kStatChunks];
-#pragma unroll
-  for (uint32_t c = 0; c < kStatChunks; ++c) in[c] = load_stat_input<kMode>(f, (span * kStatChunks + c) * 64u + lane, n);
+  // A chunk's points are fetched right before it is worked on.  (Fetching the next chunk during the current one is no faster:
+  // gfx9 counts loads and stores with ONE in-order counter, so a wait for a load issued while the table's atomics are in
+  // flight would be a wait for those atomics.  Fetching all four chunks up front is no faster per wave either and holds 44
+  // registers: 128 instead of 96, four waves per SIMD instead of five, 0.450 instead of 0.442 ms.)
 #pragma unroll
   for (uint32_t c = 0; c < kStatChunks; ++c) {
     const uint32_t chunk = span * kStatChunks + c;
     if (chunk * 256u >= n) break;
+    const QuadIn in = load_stat_input<kMode>(f, chunk * 64u + lane, n);
     const uint32_t i0 = chunk * 256u + 4u * lane;
     const uint32_t nvalid = i0 >= n ? 0u : min(n - i0, 4u);
-    stats_chunk<kMode, kPow2>(in[c], nvalid, gd, dst, T, tpatch, m);
+    stats_chunk<kMode, kPow2>(in, nvalid, gd, dst, T, tpatch, m);
   }
   stats_flush<kMode>(T, dst, tpatch, m, lane);
   if (lane == 0) sg.list_counts(blockIdx.y)[span] = m;
@@ -391,19 +390,22 @@ __device__ __forceinline__ void paint_flags(const SmoothGrid& sg, uint32_t frame
         near[((size_t)z * w + y) * w + x] = value;
 }
 
-// A wave per list: lane t sees to every 64th entry of the list (these passes are chains of dependent loads — entry,
-// cell, colour cell — so they want as many threads as there are entries: sixteen threads per list took 0.18 / 0.16 ms
-// for mark / clear, 34 us per wave).
+// A wave per list: lane t sees to entries t and 64 + t of the list at once (these passes are chains of dependent loads —
+// entry, cell, colour cell — so they want as many of them in flight as there are entries: a list holds 70 cells on
+// average, and with one entry per lane and trip most waves went through the chain twice, the second time for a handful
+// of lanes: mark / clear 0.080 / 0.122 ms per 128 frames; sixteen threads per list took 0.18 / 0.16, 34 us per wave).
+// body(key[2], span, j[2], valid[2], second): `second` = the list has entries in the second half of this trip.
 template <class F>
 __device__ __forceinline__ void for_listed_cells(const SmoothGrid& sg, uint32_t frame, uint32_t e, uint32_t n, F body) {
   const uint32_t span = e >> 6, t = e & 63u;
   if (span * kSmoothListSpan >= n) return;
   const uint32_t cnt = sg.list_counts(frame)[span];
   const uint32_t* list = sg.lists(frame) + (size_t)span * kSmoothListLen;
-  for (uint32_t j0 = 0; j0 < cnt; j0 += 64u) {              // (the trip count is the wave's: the body may use ballots)
-    const uint32_t j = j0 + t;
-    const bool valid = j < cnt;
-    body(valid ? gl(list)[j] : 0u, span, j, valid);
+  for (uint32_t j0 = 0; j0 < cnt; j0 += 128u) {             // (the trip count is the wave's: the body may use ballots)
+    const uint32_t j[2] = {j0 + t, j0 + 64u + t};
+    const bool valid[2] = {j[0] < cnt, j[1] < cnt};
+    const uint32_t key[2] = {valid[0] ? gl(list)[j[0]] : 0u, valid[1] ? gl(list)[j[1]] : 0u};
+    body(key, span, j, valid, j0 + 64u < cnt);
   }
 }
 }  // namespace
@@ -420,31 +422,38 @@ __global__ __launch_bounds__(256) void k_smooth_mark(const DevFrame* __restrict_
   const DevFrame& f = frames[first + blockIdx.y];
   const uint32_t n = min(*gl(f.n_points), f.capacity);
   if (blockIdx.x * (4u * kSmoothListSpan) >= n) return;     // 256 threads = 4 lists
-  for_listed_cells(sg, blockIdx.y, blockIdx.x * 256u + threadIdx.x, n, [&](uint32_t key, uint32_t span, uint32_t j, bool valid) {
-    bool painted = false;
-    if (valid) {
-      SmoothCell* cell = sg.cells(blockIdx.y) + key;
-      const SmoothCell c = gload(cell);
-      if (!(c.mixed & kSmoothMixed)) {                      // else: another list's entry of the same cell has been here
-        const uint32_t count = c.count & kCountMask;        // (a second visitor at the same moment may see the first one's bit)
-        // The cells' sums are 32 bits wide, two to a 64-bit atomic add: beyond this many points in ONE cell a sum of 16-bit
-        // values could carry into its neighbour (the specification's u32 sums would wrap instead) — reported, not smoothed over.
-        if (count > kSmoothCellMaxPoints) atomicOr(f.error_flag, kErrorSmoothCellOverflow);
-        if (sums_mixed(count, c.sp2, c.sp)) {
-          painted = true;
-          paint_flags(sg, blockIdx.y, key, w, 1);
-          cell->count = count | kSmoothCountMixed;          // (no atomic touches the cell during this kernel)
-          cell->mixed = kSmoothMixed | kSmoothPainted;
-          if (sg.color_offset) {                            // both filters: the colour filter reads the colour cells only
-            SmoothColorCell* cc = sg.color_cells(blockIdx.y) + key;
-            cc->count = count | kColorCellMixed;
+  for_listed_cells(sg, blockIdx.y, blockIdx.x * 256u + threadIdx.x, n, [&](const uint32_t (&key)[2], uint32_t span, const uint32_t (&j)[2],
+                                                                          const bool (&valid)[2], bool second) {
+    SmoothCell c2[2];
+#pragma unroll
+    for (int u = 0; u < 2; ++u) c2[u] = valid[u] ? gload(sg.cells(blockIdx.y) + key[u]) : SmoothCell{};
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      bool painted = false;
+      if (valid[u]) {
+        SmoothCell* cell = sg.cells(blockIdx.y) + key[u];
+        const SmoothCell& c = c2[u];
+        if (!(c.mixed & kSmoothMixed)) {                    // else: another entry of the same cell has been here
+          const uint32_t count = c.count & kCountMask;      // (a second visitor at the same moment may see the first one's bit)
+          // The cells' sums are 32 bits wide, two to a 64-bit atomic add: beyond this many points in ONE cell a sum of 16-bit
+          // values could carry into its neighbour (the specification's u32 sums would wrap instead) — reported, not smoothed over.
+          if (count > kSmoothCellMaxPoints) atomicOr(f.error_flag, kErrorSmoothCellOverflow);
+          if (sums_mixed(count, c.sp2, c.sp)) {
+            painted = true;
+            paint_flags(sg, blockIdx.y, key[u], w, 1);
+            cell->count = count | kSmoothCountMixed;        // (no atomic touches the cell during this kernel)
+            cell->mixed = kSmoothMixed | kSmoothPainted;
+            if (sg.color_offset) {                          // both filters: the colour filter reads the colour cells only
+              SmoothColorCell* cc = sg.color_cells(blockIdx.y) + key[u];
+              cc->count = count | kColorCellMixed;
+            }
           }
         }
       }
+      // which entries had their flags painted from here: k_smooth_clear un-paints those, and reads no cell for it
+      const uint64_t mask = __ballot(painted);
+      if ((threadIdx.x & 63u) == 0 && (u == 0 || second)) sg.painted(blockIdx.y)[(size_t)span * (kSmoothListLen / 64u) + (j[u] >> 6)] = mask;
     }
-    // which entries had their flags painted from here: k_smooth_clear un-paints those, and reads no cell for it
-    const uint64_t mask = __ballot(painted);
-    if ((threadIdx.x & 63u) == 0) sg.painted(blockIdx.y)[(size_t)span * (kSmoothListLen / 64u) + (j >> 6)] = mask;
   });
 }
 
@@ -468,11 +477,16 @@ __global__ __launch_bounds__(256) void k_smooth_clear(const DevFrame* __restrict
   const uint32_t n = min(*gl(f.n_points), f.capacity);
   if (blockIdx.x * (4u * kSmoothListSpan) >= n) return;
   const uint32_t e = blockIdx.x * 256u + threadIdx.x;
-  for_listed_cells(sg, blockIdx.y, e, n, [&](uint32_t key, uint32_t span, uint32_t j, bool valid) {
-    if (!valid) return;
-    zero_cell(sg, blockIdx.y, key, both);
-    const uint64_t painted = sg.painted(blockIdx.y)[(size_t)span * (kSmoothListLen / 64u) + (j >> 6)];
-    if ((painted >> (j & 63u)) & 1ull) paint_flags(sg, blockIdx.y, key, gd.w, 0);
+  for_listed_cells(sg, blockIdx.y, e, n, [&](const uint32_t (&key)[2], uint32_t span, const uint32_t (&j)[2], const bool (&valid)[2], bool) {
+    uint64_t painted[2];
+#pragma unroll
+    for (int u = 0; u < 2; ++u) painted[u] = valid[u] ? gl(sg.painted(blockIdx.y))[(size_t)span * (kSmoothListLen / 64u) + (j[u] >> 6)] : 0ull;
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      if (!valid[u]) continue;
+      zero_cell(sg, blockIdx.y, key[u], both);
+      if ((painted[u] >> (j[u] & 63u)) & 1ull) paint_flags(sg, blockIdx.y, key[u], gd.w, 0);
+    }
   });
   if (both) {
     // the cells moved points went INTO are in no list, and flags k_smooth_moved_mark painted are in no list's bits:
