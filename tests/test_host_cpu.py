@@ -29,6 +29,22 @@ def test_ply_writer_matches_reference_format(tmp_path):
                              "element face 0\nproperty list uint8 int32 vertex_index\nend_header\n1 2 3\n65535 0 7\n")
 
 
+def test_ply_writer_ascii_every_value(tmp_path):
+    """The ASCII writer looks every number up in a table of digits: every u16 as a coordinate, every u8 as a colour, in all
+    six columns, and the empty cloud."""
+    v = np.arange(65536, dtype=np.uint16)
+    xyz = np.stack([v, v[::-1], np.roll(v, 12345)], axis=1)
+    rgb = np.stack([(v & 255), (v >> 8), 255 - (v & 255)], axis=1).astype(np.uint8)
+    p = tmp_path / "all.ply"
+    recon.write_ply(p, xyz, rgb)
+    body = p.read_bytes().split(b"end_header\n", 1)[1]
+    assert body == "".join(f"{a[0]} {a[1]} {a[2]} {c[0]} {c[1]} {c[2]}\n" for a, c in zip(xyz.tolist(), rgb.tolist())).encode()
+    recon.write_ply(p, xyz, None)
+    assert p.read_bytes().split(b"end_header\n", 1)[1] == "".join(f"{a[0]} {a[1]} {a[2]}\n" for a in xyz.tolist()).encode()
+    recon.write_ply(p, xyz[:0], rgb[:0])
+    assert p.read_bytes().endswith(b"end_header\n") and b"element vertex 0\n" in p.read_bytes()
+
+
 def test_ply_writer_binary_little_endian(tmp_path):
     # the variant the reference's writer keeps commented out (src/writer.rs:10-11, 39-44): same properties
     rng = np.random.default_rng(5)

