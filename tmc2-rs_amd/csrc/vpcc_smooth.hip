@@ -23,7 +23,7 @@
 //   k_smooth_moved_mark : both filters in one pass: the cells moved points left and entered are looked at again;
 //   k_smooth_clear      : walks the lists again: zeroes exactly the listed cells and un-paints the flags (stores only).
 // Round 4 rewrote them around the quad (round 3: a thread per point, a 4-byte cell index stored per point and read back
-// by both filters, flags on the 3x3x3 block around a mixed cell): 2.19 -> 0.98 ms per 128 S-longdress frames, memory
+// by both filters, flags on the 3x3x3 block around a mixed cell): 2.19 -> 0.995 ms per 128 S-longdress frames, memory
 // traffic 2.13 -> 1.16 x the algorithmic bytes.
 #include <hip/hip_runtime.h>
 
@@ -391,9 +391,10 @@ __device__ __forceinline__ void paint_flags(const SmoothGrid& sg, uint32_t frame
 }
 
 // A wave per list: lane t sees to entries t and 64 + t of the list at once (these passes are chains of dependent loads —
-// entry, cell, colour cell — so they want as many of them in flight as there are entries: a list holds 70 cells on
-// average, and with one entry per lane and trip most waves went through the chain twice, the second time for a handful
-// of lanes: mark / clear 0.080 / 0.122 ms per 128 frames; sixteen threads per list took 0.18 / 0.16, 34 us per wave).
+// entry, cell, colour cell — so they want as many of them in flight as there are entries: a list holds 50 cells on
+// average, and with one entry per lane and trip the waves of the longer lists went through the chain twice, the second
+// time for a handful of lanes: mark / clear 0.080 / 0.122 ms per 128 frames instead of 0.077 / 0.120; sixteen threads per
+// list took 0.18 / 0.16, 34 us per wave; a wave per four lists, entry t of each per lane and trip, was no faster).
 // body(key[2], span, j[2], valid[2], second): `second` = the list has entries in the second half of this trip.
 template <class F>
 __device__ __forceinline__ void for_listed_cells(const SmoothGrid& sg, uint32_t frame, uint32_t e, uint32_t n, F body) {
