@@ -106,6 +106,15 @@ def test_decoder_ingest_paths(monkeypatch, longdress32, switch):
     assert err == "" and got == ref[:16] + ref[16:] + ref[:8]
 
 
+def test_decoder_input_interleaved_over_numa_nodes(monkeypatch, longdress32):
+    """The input's pages interleaved over two NUMA nodes (what the Decoder does by itself when its lanes' GPUs sit on more
+    than one node; on a machine with one node the request is refused and nothing changes): same frames."""
+    frames, ref = longdress32
+    monkeypatch.setenv("VPCC_DECODER_INTERLEAVE_NODES", "0,1")
+    got, err = _stream([frames[:16], frames[16:]], devices=(0, 0))
+    assert err == "" and got == ref
+
+
 @pytest.mark.parametrize("switch", [None, "VPCC_NO_EXTENT_INGEST", "VPCC_NO_PULL_INGEST"])
 def test_decoder_input_page_locked_in_chunks(monkeypatch, longdress32, switch):
     """An input that is page-locked in several adjacent regions (here: 48-MB chunks; a frame's planes are 18 MB): a stretch

@@ -3,6 +3,7 @@
 #include "decoder.hpp"
 #include "v3c_syntax.hpp"
 
+#include <cctype>
 #include <chrono>
 #include <cstdio>
 #include <cstdlib>
@@ -14,7 +15,10 @@
 #include <sstream>
 #include <stdexcept>
 
+#include <hip/hip_runtime_api.h>
 #include <sys/mman.h>
+#include <sys/syscall.h>
+#include <unistd.h>
 
 namespace tmc2rs {
 
@@ -62,21 +66,60 @@ Decoder::~Decoder() {
   if (thread_.joinable()) thread_.join();
 }
 
+namespace {
+// The NUMA nodes the input buffer is to be spread over, as a bit mask: the nodes of the lanes' GPUs when they are more than
+// one (sysfs: /sys/bus/pci/devices/<bus id>/numa_node) — every lane pulls 57 GB/s out of this buffer, and eight lanes out of
+// ONE node's memory would be 450 GB/s from one socket; pages interleaved over the GPUs' nodes share the load between the
+// sockets' memory controllers (a frame's planes are 18 MB = nine huge pages: every lane reads from every node).  0: leave the
+// placement to the first touch (one GPU, GPUs of one node, a machine that reports no nodes).  VPCC_DECODER_INTERLEAVE_NODES=a,b,..
+// names the nodes outright (tests; machines whose sysfs says nothing).
+unsigned long input_node_mask(const std::vector<int>& devices) {
+  unsigned long mask = 0;
+  if (const char* e = std::getenv("VPCC_DECODER_INTERLEAVE_NODES")) {
+    for (const char* c = e; *c;) {
+      char* end = nullptr;
+      const long v = std::strtol(c, &end, 10);
+      if (end == c) break;
+      if (v >= 0 && v < (long)(8 * sizeof mask)) mask |= 1ul << v;
+      c = *end ? end + 1 : end;
+    }
+    return mask;
+  }
+  for (int dev : devices) {
+    char bus[64] = {0};
+    if (hipDeviceGetPCIBusId(bus, (int)sizeof bus, dev) != hipSuccess) { (void)hipGetLastError(); return 0; }
+    for (char* c = bus; *c; ++c) *c = (char)std::tolower((unsigned char)*c);      // sysfs names are lower case
+    int node = -1;
+    if (FILE* f = std::fopen((std::string("/sys/bus/pci/devices/") + bus + "/numa_node").c_str(), "r")) {
+      if (std::fscanf(f, "%d", &node) != 1) node = -1;
+      std::fclose(f);
+    }
+    if (node < 0 || node >= (int)(8 * sizeof mask)) return 0;
+    mask |= 1ul << node;
+  }
+  return (mask & (mask - 1)) ? mask : 0;                // two nodes or more
+}
+}  // namespace
+
 void Decoder::start() {
   if (started_) throw std::logic_error("library decoder can only be started once");   // src/lib.rs:108-111
   started_ = true;
+  const unsigned long nodes = input_node_mask(params_.devices.empty() ? std::vector<int>{0} : params_.devices);
+  if (nodes && std::getenv("VPCC_DECODER_TRACE")) std::fprintf(stderr, "[vpcc decoder] input pages interleaved over the NUMA nodes of mask 0x%lx\n", nodes);
   // Bitstream::from_file on the caller's thread (src/lib.rs:98); the reference unwraps the io error
-  auto slurp = [](const std::string& path, std::vector<unsigned char>* out, size_t at) {
+  auto slurp = [nodes](const std::string& path, std::vector<unsigned char>* out, size_t at) {
     std::ifstream in(path, std::ios::binary | std::ios::ate);
     if (!in) throw std::runtime_error("cannot open " + path);
     const size_t n = (size_t)in.tellg();
     const size_t upto = at + ((n + 15) & ~size_t(15));     // next section starts 16-B aligned
     // The buffer is page-locked later and read by the copy engines: ask for huge pages BEFORE its first touch (resize
     // zero-fills) — page-locking then handles 2-MB pages instead of 4-KB ones.  Advice only; VPCC_DECODER_NO_HUGEPAGES=1: none.
-    if (upto > out->capacity() && upto >= (size_t(64) << 20) && !std::getenv("VPCC_DECODER_NO_HUGEPAGES")) {
+    if (upto > out->capacity() && upto >= (size_t(64) << 20) && (nodes || !std::getenv("VPCC_DECODER_NO_HUGEPAGES"))) {
       out->reserve(upto);
       const uintptr_t lo = ((uintptr_t)out->data() + 4095) & ~uintptr_t(4095), hi = ((uintptr_t)out->data() + out->capacity()) & ~uintptr_t(4095);
-      if (hi > lo) (void)madvise((void*)lo, (size_t)(hi - lo), MADV_HUGEPAGE);
+      if (hi > lo && !std::getenv("VPCC_DECODER_NO_HUGEPAGES")) (void)madvise((void*)lo, (size_t)(hi - lo), MADV_HUGEPAGE);
+      // (advice too: MPOL_INTERLEAVE = 3; a refusal leaves the pages where the first touch puts them)
+      if (hi > lo && nodes) (void)syscall(SYS_mbind, (void*)lo, (unsigned long)(hi - lo), 3, &nodes, (unsigned long)(8 * sizeof nodes + 1), 0u);
     }
     out->resize(upto);
     in.seekg(0);
