@@ -148,9 +148,10 @@ def test_config3_three_sequences_sharded_over_two_contexts(longdress32):
     got, err = _stream(gofs, devices=devices)
     assert err == ""
     assert len(got) == 288 and got == expect
-    # 9 GOFs: [0], [1..4], and the stream's last unit in halves — [5, 6], [7], [8] — each dealt over two lanes
+    # 9 GOFs, two lanes: a unit holds up to four GOFs PER LANE — [0], then [1..8] with the stream's last unit in halves
+    # while a half has 64 frames per lane: [1..4], [5, 6], [7, 8] — each dealt over the two lanes
     st = _stream.last_stats
-    assert st["lanes"] == 2 and st["launches"] == 10 and st["max_frames_per_launch"] == 64
+    assert st["lanes"] == 2 and st["launches"] == 8 and st["max_frames_per_launch"] == 64
 
 
 def test_decoder_to_ply_matches_oracle_bytes(tmp_path):

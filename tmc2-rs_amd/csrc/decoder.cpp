@@ -228,7 +228,7 @@ void Decoder::worker() {
   // while the current one is reconstructed and drained.
   //
   // A UNIT is what one launch per lane reconstructs: the first GOF alone (the consumer gets its first frame after
-  // one GOF's upload), then up to kGofsPerLaunch consecutive GOFs — GOFs are as independent of each other as
+  // one GOF's upload), then up to four consecutive GOFs per lane — GOFs are as independent of each other as
   // frames are (a fresh Context per GOF, src/lib.rs:120), and a launch over 128 frames costs 12 % less per frame
   // than four launches over 32.
   const size_t G = params_.devices.empty() ? 1 : params_.devices.size();
@@ -403,8 +403,10 @@ void Decoder::worker() {
     }
   } report{trace, stats_, t_counts, t_download, t_send};
 
-  // The units of the stream: [GOF 0], then runs of up to kGofsPerLaunch GOFs, each run below ~16 GiB of device memory.
-  constexpr size_t kGofsPerLaunch = 4;
+  // The units of the stream: [GOF 0], then runs of up to kGofsPerLaunch GOFs PER LANE, each run below ~16 GiB of device memory
+  // per lane: a lane's launch covers 128 frames however many lanes there are (with four GOFs per unit regardless, eight lanes would
+  // launch over 16 frames each and this thread's work per unit — counts, downloads, hand-over — would come round every 5 ms).
+  const size_t kGofsPerLaunch = 4 * G;
   std::vector<std::pair<size_t, size_t>> units;       // [first GOF, one past the last)
   for (size_t k = 0; k < gofs_.size();) {
     size_t end = k + 1;
@@ -428,13 +430,13 @@ void Decoder::worker() {
   }
   // The results of the stream's LAST unit travel back with nothing left to overlap them with (20 ms for 128 frames): it is
   // dealt out in halves — 4 GOFs as 2 + 1 + 1 — so that only a GOF's worth of downloads is left at the end (units of fewer than
-  // 64 frames are left alone: nothing to gain).
+  // 64 frames per lane are left alone: nothing to gain).
   auto frames_of = [&](const std::pair<size_t, size_t>& u) {
     size_t n = 0;
     for (size_t q = u.first; q < u.second; ++q) n += gofs_[q].frames.size();
     return n;
   };
-  while (units.size() > 1 && units.back().second - units.back().first > 1 && frames_of(units.back()) >= 64 &&
+  while (units.size() > 1 && units.back().second - units.back().first > 1 && frames_of(units.back()) >= 64 * G &&
          !std::getenv("VPCC_DECODER_NO_TAIL_SPLIT")) {
     const size_t a = units.back().first, b = units.back().second, mid = a + (b - a + 1) / 2;
     units.back().second = mid;
