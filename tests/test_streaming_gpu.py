@@ -91,6 +91,24 @@ def test_decoder_launch_covers_several_gofs_small_frames():
     assert st["lanes"] == 1 and len(st["numa_node"]) == 1
 
 
+def test_eight_lanes_deal_and_resequence(monkeypatch):
+    """Eight lanes (on one GPU: eight threads, contexts and result pools) over a stream of 70 ragged GOFs of small frames: a unit
+    holds up to 32 GOFs, every lane gets every eighth frame of it, the frames come back in presentation order."""
+    monkeypatch.setenv("VPCC_DECODER_POOL_GIB", "0")               # eight pools of 32 GiB on one GPU are not the point here
+    frames = [synth.small_frame(300 + i) for i in range(24)]
+    ref = _oracle_crcs(frames)
+    rng = np.random.RandomState(5)
+    gofs, expect = [], []
+    for g in range(70):
+        idx = [int(k) for k in rng.randint(0, len(frames), size=int(rng.randint(1, 12)))]
+        gofs.append([frames[k] for k in idx])
+        expect += [ref[k] for k in idx]
+    got, err = _stream(gofs, devices=(0,) * 8)
+    assert err == "" and got == expect
+    st = _stream.last_stats
+    assert st["lanes"] == 8 and st["frames"] == len(expect)
+
+
 @pytest.mark.parametrize("switch", ["VPCC_NO_EXTENT_INGEST", "VPCC_NO_STAGED_DESCRIPTORS", "VPCC_NO_PULL_INGEST", "VPCC_DECODER_NO_HUGEPAGES"])
 def test_decoder_ingest_paths(monkeypatch, longdress32, switch):
     """The Decoder's planes reach the device as whole stretches of its page-locked container by default (one copy per
