@@ -241,7 +241,8 @@ int vpcc_reconstruct_frame(vpcc_ctx* ctx, const vpcc_frame_desc* frame, vpcc_mem
  * gof.  capacity_points is the per-frame output capacity (0 = the safe bound
  * vpcc_frame_capacity_bound()).
  * Planes stay in the raster layout a video decoder hands over, whoever owns them: the reconstruction kernel
- * stages the tiles it needs in LDS itself (LDS-DMA), nothing is re-arranged in HBM. */
+ * reads them where they lie, nothing is re-arranged in HBM.  Frames whose capacity exceeds 715 827 880 points
+ * (32-bit byte offsets into the positions) are reconstructed by the general kernel sequence. */
 int  vpcc_gof_create(vpcc_ctx* ctx, const vpcc_frame_desc* frames, uint32_t n_frames,
                      vpcc_memory_kind planes, uint64_t capacity_points, uint32_t gof_flags,
                      vpcc_gof** out);

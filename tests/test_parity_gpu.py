@@ -83,6 +83,23 @@ def test_general_and_fast_paths_agree(ctx):
     b.close()
 
 
+def test_capacity_beyond_32_bit_byte_offsets_takes_the_general_sequence(ctx):
+    """The tile kernel's store loop addresses a frame's positions with 32-bit byte offsets: a gof whose frames may hold more
+    than 715 827 880 points is reconstructed by the general sequence (64-bit indices; `tools/exp_max_canvas.py` runs a
+    32768 x 32768 frame of 811 M points through it).  Here: a small frame with such a capacity (4.3 + 2.1 GB of outputs)."""
+    f = cases.medium_frame(3)
+    st, ref = ob.reconstruct(f)
+    assert st == 0
+    for cap, tiles in ((715_827_880, True), (715_827_881, False)):
+        g = ctx.gof([f], capacity=cap, flags=_abi.VPCC_GOF_PROFILE)
+        g.reconstruct()
+        got = g.download(0)
+        names = [n for n, _ in g.kernel_times()]
+        assert any("k_recon_tiles" in n for n in names) == tiles, names
+        assert got["n"] == ref["n"] and np.array_equal(got["xyz"], ob.xyz_array(ref)) and np.array_equal(got["rgb"], ob.rgb_array(ref))
+        g.close()
+
+
 def test_capacity_too_small_is_reported_not_overrun(ctx):
     f = cases.medium_frame(0)
     st, ref = ob.reconstruct(f)

@@ -1004,8 +1004,12 @@ int gof_create_impl(vpcc_ctx* ctx, const vpcc_frame_desc* frames, uint32_t n_fra
       HIP_TRY(ctx, hipMemcpyAsync(base + o.patch_items, P.patch_items.data(), sizeof(TileItem) * P.patch_items.size(),
                                   hipMemcpyHostToDevice, sd));
   }
-  // the tile kernel needs every frame eligible and its vector loads aligned on the final pointers
-  bool tiles_ok = all_simple && !(gof_flags & VPCC_GOF_FORCE_GENERAL);
+  // the tile kernel needs every frame eligible and its vector loads aligned on the final pointers; and its store loop addresses a
+  // frame's positions with 32-bit byte offsets (6 bytes per point): frames that may hold more than 715 827 880 points — canvases
+  // beyond 18 900 x 18 900 with two maps, unless the caller gives a smaller bound — take the general sequence, whose indices are 64 bits
+  // wide (tools/exp_max_canvas.py: a 32768 x 32768 frame of 811 M points, 4.5 GiB of positions, equals the oracle)
+  constexpr uint64_t kTilePathMaxPoints = 0xFFFFFFF0ull / sizeof(vpcc_point3);
+  bool tiles_ok = all_simple && !(gof_flags & VPCC_GOF_FORCE_GENERAL) && g->capacity <= kTilePathMaxPoints;
   for (uint32_t i = 0; i < n_frames && tiles_ok; ++i) tiles_ok = tile_planes_aligned(g->h_frames[i]);
   g->general = !tiles_ok;
   // Staged: everything of this gof goes onto the copy stream, in the order it is needed — nothing waits for another stream
