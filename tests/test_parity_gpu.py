@@ -83,6 +83,44 @@ def test_general_and_fast_paths_agree(ctx):
     b.close()
 
 
+def test_the_largest_patch_table(ctx):
+    """65 535 patches (the ABI's and the partition's limit: patch indices are 16 bits wide) of one block each on a 4096 x 4096
+    canvas, every orientation and view, the last block left to nobody; plus overlapping patches among the first ones (the later one
+    owns the block).  Points, colours, partition and block ownership against the oracle, on both kernel paths."""
+    W = H = 4096
+    n = 65535
+    k = np.arange(n)
+    p = np.zeros(n, dtype=_abi.PATCH_DTYPE)
+    p["u0"], p["v0"], p["size_u0"], p["size_v0"] = k % 256, k // 256, 1, 1
+    p["u0"][5], p["v0"][5] = p["u0"][4], p["v0"][4]               # patch 5 on top of patch 4
+    views = np.array([synth.VIEW_AXES[v] for v in range(6)])
+    v = k % 6
+    p["normal_axis"], p["tangent_axis"], p["bitangent_axis"], p["projection_mode"] = views[v, 0], views[v, 1], views[v, 2], views[v, 3]
+    p["orientation"] = np.where(k % 5 == 0, 1, 0)                  # Swap every fifth (one block: every orientation stays inside)
+    p["u1"], p["v1"], p["d1"] = (k * 7) % 60000, (k * 13) % 60000, (k * 3) % 900
+    p["lod_x"] = p["lod_y"] = 1
+    rng = np.random.RandomState(65535)
+    occ = (rng.randint(0, 4, size=(H // 4, W // 4)) != 0).astype(np.uint8)
+    g0 = rng.randint(0, 1000, size=(H, W)).astype(np.uint16)
+    g1 = (g0 + 4 * rng.randint(0, 3, size=(H, W))).astype(np.uint16)
+    attr = [(rng.randint(64, 941, size=(H, W)).astype(np.uint16), rng.randint(64, 961, size=(H // 2, W // 2)).astype(np.uint16),
+             rng.randint(64, 961, size=(H // 2, W // 2)).astype(np.uint16)) for _ in range(2)]
+    f = {"width": W, "height": H, "occupancy_resolution": 16, "occupancy_precision": 4, "map_count": 2, "absolute_d1": 1,
+         "attribute_count": 1, "flags": 0, "patches": p, "occupancy": occ, "geometry": [g0, g1], "attribute": attr}
+    st, ref = ob.reconstruct(f)
+    assert st == 0 and ref["n"] > 20_000_000
+    for flags in (0, _abi.VPCC_GOF_FORCE_GENERAL):
+        g = ctx.gof([f], flags=flags | _abi.VPCC_GOF_WANT_PATCH_INDEX)
+        g.reconstruct()
+        got = g.download(0, want_patch_index=True)
+        assert got["n"] == ref["n"]
+        assert np.array_equal(got["xyz"], ob.xyz_array(ref)) and np.array_equal(got["rgb"], ob.rgb_array(ref))
+        assert np.array_equal(got["patch_index"].astype(np.uint64), ref["partition"]) and int(got["patch_index"].max()) == n - 1
+        b2p, _ = g.block_to_patch(0, 65536)
+        assert np.array_equal(b2p.astype(np.uint64), ref["block_to_patch"]) and b2p[4] == 6 and b2p[5] == 0 and b2p[-1] == 0
+        g.close()
+
+
 def test_capacity_beyond_32_bit_byte_offsets_takes_the_general_sequence(ctx):
     """The tile kernel's store loop addresses a frame's positions with 32-bit byte offsets: a gof whose frames may hold more
     than 715 827 880 points is reconstructed by the general sequence (64-bit indices; `tools/exp_max_canvas.py` runs a
