@@ -83,6 +83,26 @@ def test_general_and_fast_paths_agree(ctx):
     b.close()
 
 
+def test_every_block_size_and_occupancy_precision(ctx):
+    """occupancy_resolution 1 .. 128 (log2_patch_packing_block_size 0 .. 7) x occupancy_precision 1, 2, 4, 8 — blocks smaller than an
+    occupancy sample included — on the path gof creation chooses (the tile kernel for blocks of 16) and on the general sequence:
+    points, colours, partition and block ownership against the oracle."""
+    import itertools
+    for R, prec in itertools.product((1, 2, 4, 8, 16, 32, 64, 128), (1, 2, 4, 8)):
+        W, H = max(256, 4 * R), max(192, 3 * R)
+        f = synth.make_frame(W, H, prec, R, seed=0x7E570000 + R * 16 + prec, max_side=max(2, 64 // R), cover_target=0.6, size_skew=1.5)
+        st, ref = ob.reconstruct(f)
+        assert st == 0 and ref["n"] > 20000
+        for flags in (0, _abi.VPCC_GOF_FORCE_GENERAL):
+            g = ctx.gof([f], flags=flags | _abi.VPCC_GOF_WANT_PATCH_INDEX)
+            g.reconstruct()
+            _check(g.download(0, want_patch_index=True), ref)
+            b2p, items = g.block_to_patch(0, (W // R) * (H // R))
+            assert np.array_equal(b2p.astype(np.uint64), ref["block_to_patch"]), (R, prec, flags)
+            assert (items > 0) == (R == 16 and flags == 0), (R, prec, flags, items)
+            g.close()
+
+
 def test_the_largest_patch_table(ctx):
     """65 535 patches (the ABI's and the partition's limit: patch indices are 16 bits wide) of one block each on a 4096 x 4096
     canvas, every orientation and view, the last block left to nobody; plus overlapping patches among the first ones (the later one
