@@ -85,6 +85,7 @@ unsigned long input_node_mask(const std::vector<int>& devices) {
     }
     return mask;
   }
+  if (devices.size() < 2) return 0;                     // one lane: one node (and no HIP call on the caller's thread)
   for (int dev : devices) {
     char bus[64] = {0};
     if (hipDeviceGetPCIBusId(bus, (int)sizeof bus, dev) != hipSuccess) { (void)hipGetLastError(); return 0; }
