@@ -91,6 +91,40 @@ def test_decoder_launch_covers_several_gofs_small_frames():
     assert st["lanes"] == 1 and len(st["numa_node"]) == 1
 
 
+def test_two_decoders_at_once():
+    """Two Decoders of one process streaming at the same time from two threads (one GPU): the process-wide state — the
+    registry of page-locked regions, the pools kept by device — is shared, everything else is a Decoder's own."""
+    import threading
+    frames = [cases.medium_frame(40 + i) for i in range(12)]
+    ref = _oracle_crcs(frames)
+    out = {}
+
+    def run(tag, order):
+        d = tempfile.mkdtemp(dir="/dev/shm" if os.path.isdir("/dev/shm") else None)
+        path = os.path.join(d, f"{tag}.vpccgof")
+        try:
+            container.write_container(path, [[frames[k] for k in order[g:g + 6]] for g in range(0, len(order), 6)])
+            dec = recon.Decoder(path, devices=(0,))
+            dec.start()
+            got = [(fr["n"], _crc(fr["xyz"], fr["rgb"])) for fr in dec]
+            out[tag] = (got, dec.error())
+            dec.close()
+        finally:
+            if os.path.exists(path):
+                os.remove(path)
+            os.rmdir(d)
+
+    orders = {"a": [i % 12 for i in range(60)], "b": [(7 * i + 3) % 12 for i in range(48)]}
+    threads = [threading.Thread(target=run, args=(t, o)) for t, o in orders.items()]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    for tag, order in orders.items():
+        got, err = out[tag]
+        assert err == "" and got == [ref[k] for k in order], tag
+
+
 def test_eight_lanes_deal_and_resequence(monkeypatch):
     """Eight lanes (on one GPU: eight threads, contexts and result pools) over a stream of 70 ragged GOFs of small frames: a unit
     holds up to 32 GOFs, every lane gets every eighth frame of it, the frames come back in presentation order."""
