@@ -91,6 +91,38 @@ def test_decoder_launch_covers_several_gofs_small_frames():
     assert st["lanes"] == 1 and len(st["numa_node"]) == 1
 
 
+@pytest.mark.timeout(300)
+def test_consumer_stops_early(longdress32):
+    """The receiver is dropped after a few frames (src/decoder.rs:311-313: the worker's next send fails and it stops) while
+    units of 128 full-size frames are being uploaded and reconstructed: close() comes back, nothing is left behind that a
+    second Decoder — which takes the first one's pool over — would trip on."""
+    import time
+    frames, ref = longdress32
+    d = tempfile.mkdtemp(dir="/dev/shm" if os.path.isdir("/dev/shm") else None)
+    path = os.path.join(d, "early.vpccgof")
+    try:
+        container.write_container(path, [frames] * 6)
+        dec = recon.Decoder(path, devices=(0,))
+        dec.start()
+        got = []
+        for fr in dec:
+            got.append((fr["n"], _crc(fr["xyz"], fr["rgb"])))
+            if len(got) == 3:
+                break
+        t0 = time.perf_counter()
+        dec.close()
+        assert time.perf_counter() - t0 < 30 and got == ref[:3]
+        dec = recon.Decoder(path, devices=(0,))
+        dec.start()
+        again = [(fr["n"], _crc(fr["xyz"], fr["rgb"])) for fr in dec]
+        assert dec.error() == "" and again == ref * 6
+        dec.close()
+    finally:
+        if os.path.exists(path):
+            os.remove(path)
+        os.rmdir(d)
+
+
 def test_two_decoders_at_once():
     """Two Decoders of one process streaming at the same time from two threads (one GPU): the process-wide state — the
     registry of page-locked regions, the pools kept by device — is shared, everything else is a Decoder's own."""
