@@ -1,0 +1,73 @@
+#!/usr/bin/env python3
+"""Soak of the streaming Decoder: random streams — 1 .. 14 GOFs of 1 .. 40 frames drawn from a pool of random frames of several canvas
+sizes —, 1 .. 4 lanes (on one GPU), random ingest switches (stretches / kernel / copy engine, staged descriptors or not, the input
+page-locked in chunks, with or without the tail split, with or without a pool), now and then a consumer that stops early; every
+frame that arrives is compared with the oracle's, in presentation order.  Usage: tools/soak_decoder.py [streams = 150] [first seed = 0]"""
+import os, sys, tempfile, time, zlib
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(REPO, "tmc2-rs_amd")); sys.path.insert(0, os.path.join(REPO, "tests"))
+import numpy as np
+from tmc2rs import container, recon, synth
+import oracle_binding as ob
+n_streams = int(sys.argv[1]) if len(sys.argv) > 1 else 150
+seed0 = int(sys.argv[2]) if len(sys.argv) > 2 else 0
+rng = np.random.default_rng(0xDEC0 + seed0)
+def crc(x, c): return zlib.crc32(np.ascontiguousarray(c).tobytes(), zlib.crc32(np.ascontiguousarray(x).tobytes()))
+pool = []
+for i in range(36):
+    big = i % 6 == 0
+    w = 16 * int(rng.integers(30, 81) if big else rng.integers(2, 26)); h = 16 * int(rng.integers(30, 70) if big else rng.integers(2, 20))
+    f = synth.make_frame(w, h, int(rng.choice([1, 2, 4, 4])), 16, seed=0xDEC00000 + seed0 * 1009 + i, max_side=int(rng.integers(2, 20 if big else 9)),
+                         cover_target=float(rng.uniform(0.2, 0.9)), swap_prob=float(rng.uniform(0, 1)), dup_prob=float(rng.uniform(0, 0.6)))
+    st, r = ob.reconstruct(f)
+    assert st == 0
+    pool.append((f, (r["n"], crc(ob.xyz_array(r), ob.rgb_array(r)))))
+switches = ["VPCC_NO_EXTENT_INGEST", "VPCC_NO_STAGED_DESCRIPTORS", "VPCC_NO_PULL_INGEST", "VPCC_NO_PUSH_DOWNLOAD", "VPCC_DECODER_NO_TAIL_SPLIT",
+            "VPCC_DECODER_NO_HUGEPAGES"]
+bad = frames = 0
+t0 = time.time()
+d = tempfile.mkdtemp(dir="/dev/shm" if os.path.isdir("/dev/shm") else None)
+path = os.path.join(d, "soak.vpccgof")
+try:
+    for si in range(n_streams):
+        for s in switches + ["VPCC_DECODER_PIN_CHUNK_MB", "VPCC_DECODER_POOL_GIB"]:
+            os.environ.pop(s, None)
+        on = [s for s in switches if rng.random() < 0.2]
+        for s in on:
+            os.environ[s] = "1"
+        if rng.random() < 0.25:
+            os.environ["VPCC_DECODER_PIN_CHUNK_MB"] = str(int(rng.choice([1, 3, 16])))
+        if rng.random() < 0.7:
+            os.environ["VPCC_DECODER_POOL_GIB"] = str(int(rng.choice([0, 0, 2, 4])))
+        gofs, expect = [], []
+        for g in range(int(rng.integers(1, 15))):
+            idx = [int(k) for k in rng.integers(0, len(pool), size=int(rng.integers(1, 41)))]
+            gofs.append([pool[k][0] for k in idx]); expect += [pool[k][1] for k in idx]
+        lanes = int(rng.choice([1, 1, 2, 3, 4]))
+        stop_at = int(rng.integers(0, len(expect))) if rng.random() < 0.15 else None
+        container.write_container(path, gofs)
+        dec = recon.Decoder(path, devices=(0,) * lanes)
+        dec.start()
+        got = []
+        for fr in dec:
+            got.append((fr["n"], crc(fr["xyz"], fr["rgb"])))
+            if stop_at is not None and len(got) > stop_at:
+                break
+        err = dec.error()
+        dec.close()
+        ok = err == "" and got == (expect if stop_at is None else expect[:stop_at + 1])
+        frames += len(got)
+        if not ok:
+            bad += 1
+            first = next((i for i, (a, b) in enumerate(zip(got, expect)) if a != b), None)
+            print(f"MISMATCH stream {si}: {len(gofs)} GOFs of {[len(g) for g in gofs]} frames, {lanes} lanes, {on}, "
+                  f"{ {k: os.environ[k] for k in ('VPCC_DECODER_PIN_CHUNK_MB', 'VPCC_DECODER_POOL_GIB') if k in os.environ} }, stop_at {stop_at}: "
+                  f"error {err!r}, {len(got)} of {len(expect)} frames, first difference at {first}", flush=True)
+        if si % 10 == 9:
+            print(f"{si + 1} streams, {frames} frames, {bad} bad, {time.time() - t0:.0f} s", flush=True)
+finally:
+    if os.path.exists(path):
+        os.remove(path)
+    os.rmdir(d)
+print(f"soak: {n_streams} streams, {frames} frames, {bad} bad")
+sys.exit(1 if bad else 0)
