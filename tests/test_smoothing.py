@@ -242,6 +242,35 @@ def test_smoothing_in_chunks_of_frames(monkeypatch):
     ctx.close()
 
 
+@pytest.mark.gpu
+def test_smoothing_makes_do_with_the_memory_there_is(monkeypatch):
+    """The grids of a range of frames are one allocation; when the device has not got that much the range is smoothed in
+    halves, quarters ... (the test hook makes allocations above a size fail) — and when not even one frame's grid fits, the
+    call says so instead of leaving a stale device error behind."""
+    from tmc2rs import recon
+    fr = [cases.overlapping_3d_frame(i) for i in range(5)]
+    params = dict(grid_size=8, threshold=1, color_grid_size=8, color_threshold_smoothing=5, color_threshold_difference=200)
+    ctx = recon.Context(0)
+    g = ctx.gof(fr, flags=_abi.VPCC_GOF_WANT_PATCH_INDEX)
+    g.reconstruct()
+    before = [g.download(i, want_patch_index=True) for i in range(len(fr))]
+    monkeypatch.setenv("VPCC_SMOOTH_ALLOC_FAIL_ABOVE_MB", "250")       # a slot is 98 MB: 5 frames fail, 3 fail, 2 fit
+    g.smooth(10, **params)
+    _check_against_spec(g, before, 10, params)
+    g.close()
+    g = ctx.gof(fr, flags=_abi.VPCC_GOF_WANT_PATCH_INDEX)
+    g.reconstruct()
+    monkeypatch.setenv("VPCC_SMOOTH_ALLOC_FAIL_ABOVE_MB", "50")
+    with pytest.raises(recon.VpccError) as e:
+        g.smooth(10, **params)
+    assert e.value.status == _abi.VPCC_ERR_DEVICE and "no device memory for the grid of one frame" in str(e.value)
+    monkeypatch.delenv("VPCC_SMOOTH_ALLOC_FAIL_ABOVE_MB")
+    g.smooth(10, **params)                                             # the gof is none the worse for it
+    _check_against_spec(g, before, 10, params)
+    g.close()
+    ctx.close()
+
+
 def _collapsed_frame(n_blocks, prec=4):
     """Every patch is one fully occupied block whose 512 points (lod 0: all pixels share the tangent and bitangent
     coordinate; two depths) fall into ONE grid cell."""

@@ -367,6 +367,19 @@ void retire_pool(vpcc_ctx* ctx) {
   P = vpcc_ctx::Pool{};
 }
 
+// Out of memory somewhere: the pools kept for the device's next context go back to the driver.  Returns whether any did.
+bool release_kept_pools(int device) {
+  std::lock_guard<std::mutex> keep(g_kept_pools_mutex);
+  bool any = false;
+  for (size_t k = g_kept_pools.size(); k-- > 0;)
+    if (g_kept_pools[k].first == device) {
+      for (void* q : g_kept_pools[k].second.slabs) (void)hipFree(q);
+      g_kept_pools.erase(g_kept_pools.begin() + (long)k);
+      any = true;
+    }
+  return any;
+}
+
 // Blocks of destroyed gofs that did not come from the pool are kept for the next gof of the same size: hipMalloc /
 // hipFree cost milliseconds and hipFree synchronises the whole device, which would stall a GOF pipeline.
 constexpr size_t kBlockCacheEntries = 8;
@@ -401,7 +414,15 @@ int acquire_block(vpcc_ctx* ctx, int part, size_t bytes, vpcc_ctx::Block* out) {
     (void)hipGetLastError();
     for (auto& b : cache) (void)hipFree(b.ptr);          // make room and try once more
     cache.clear();
-    if (hipMalloc(&p, bytes) != hipSuccess) { ctx->last_error = "hipMalloc of a gof block failed"; return VPCC_ERR_DEVICE; }
+    if (hipMalloc(&p, bytes) != hipSuccess) {
+      (void)hipGetLastError();                             // (a failed call's error stays "last" until somebody asks)
+      // ... and the pools kept for the device's next context
+      if (!release_kept_pools(ctx->device) || hipMalloc(&p, bytes) != hipSuccess) {
+        (void)hipGetLastError();
+        ctx->last_error = "no device memory for a gof block of " + std::to_string(bytes >> 20) + " MB";
+        return VPCC_ERR_DEVICE;
+      }
+    }
   }
   *out = vpcc_ctx::Block{p, bytes, false, 0};
   return VPCC_OK;
@@ -852,7 +873,15 @@ int gof_create_impl(vpcc_ctx* ctx, const vpcc_frame_desc* frames, uint32_t n_fra
     }
   }
   const auto t_alloc = std::chrono::steady_clock::now();
-  if (!g->arena) HIP_TRY(ctx, hipMalloc(&g->arena, g->arena_bytes));
+  if (!g->arena && hipMalloc(&g->arena, g->arena_bytes) != hipSuccess) {
+    (void)hipGetLastError();
+    g->arena = nullptr;
+    if (!release_kept_pools(ctx->device) || hipMalloc(&g->arena, g->arena_bytes) != hipSuccess) {
+      (void)hipGetLastError();
+      g->arena = nullptr;
+      return fail(ctx, VPCC_ERR_DEVICE, "no device memory for a gof's arena of " + std::to_string(g->arena_bytes >> 20) + " MB");
+    }
+  }
   for (int j = 0; j < 2 * vpcc_ctx::kParts; ++j)
     if (LB[j].total) {
       const int st = acquire_block(ctx, j / 2, LB[j].total + 256, &g->block[j]);
@@ -1486,15 +1515,29 @@ extern "C" int vpcc_gof_smooth(vpcc_gof* g, uint32_t first, uint32_t count, cons
     // (VPCC_SMOOTH_SCRATCH_LIMIT_MB: the limit in MB, for tests that want several chunks out of a small gof)
     const char* limit_env = getenv("VPCC_SMOOTH_SCRATCH_LIMIT_MB");
     const size_t scratch_limit = limit_env ? std::max<size_t>(1, (size_t)atoll(limit_env)) << 20 : size_t(16) << 30;
-    const uint32_t chunk = (uint32_t)std::max<size_t>(1, std::min<size_t>(count, scratch_limit / sg.slot_bytes));
-    const size_t need = sg.slot_bytes * chunk;
-    if (g->smooth_bytes < need) {
+    uint32_t chunk = (uint32_t)std::max<size_t>(1, std::min<size_t>(count, scratch_limit / sg.slot_bytes));
+    // The grids of `chunk` frames at a time — of fewer when the device has not got that much left (other gofs' scratch, other
+    // tenants): the chunk is halved while the allocation fails, the pools kept for the device's next context are given back
+    // before the last attempt.  (VPCC_SMOOTH_ALLOC_FAIL_ABOVE_MB: allocations above that size "fail", for the test of this path.)
+    const char* fail_env = getenv("VPCC_SMOOTH_ALLOC_FAIL_ABOVE_MB");
+    const size_t fail_above = fail_env ? (size_t)atoll(fail_env) << 20 : ~size_t(0);
+    for (bool pools_released = false;;) {
+      const size_t need = sg.slot_bytes * chunk;
+      if (g->smooth_bytes >= need) break;
       if (g->smooth_grid) HIP_TRY(ctx, hipFree(g->smooth_grid));
       g->smooth_grid = nullptr;
       g->smooth_bytes = 0;
-      HIP_TRY(ctx, hipMalloc(&g->smooth_grid, need));
-      g->smooth_bytes = need;
-      g->smooth_clean = false;
+      const hipError_t e = need > fail_above ? hipErrorOutOfMemory : hipMalloc(&g->smooth_grid, need);
+      if (e == hipSuccess) {
+        g->smooth_bytes = need;
+        g->smooth_clean = false;
+        break;
+      }
+      (void)hipGetLastError();
+      g->smooth_grid = nullptr;
+      if (chunk > 1) { chunk = (chunk + 1) / 2; continue; }
+      if (!pools_released && release_kept_pools(ctx->device)) { pools_released = true; continue; }
+      return fail(ctx, VPCC_ERR_DEVICE, "smoothing: no device memory for the grid of one frame (" + std::to_string(need >> 20) + " MB): " + hipGetErrorString(e));
     }
     if (!g->smooth_clean) {
       HIP_TRY(ctx, hipMemsetAsync(g->smooth_grid, 0, g->smooth_bytes, s));

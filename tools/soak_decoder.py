@@ -1,8 +1,8 @@
 #!/usr/bin/env python3
 """Soak of the streaming Decoder: random streams — 1 .. 14 GOFs of 1 .. 40 frames drawn from a pool of random frames of several canvas
 sizes —, 1 .. 4 lanes (on one GPU), random ingest switches (stretches / kernel / copy engine, staged descriptors or not, the input
-page-locked in chunks, with or without the tail split, with or without a pool), now and then a consumer that stops early; every
-frame that arrives is compared with the oracle's, in presentation order.  Usage: tools/soak_decoder.py [streams = 150] [first seed = 0]"""
+page-locked in chunks, with or without the tail split, with or without a pool), now and then a consumer that stops early, three streams in ten with the smoothing filters switched on (random parameters); every
+frame that arrives is compared with the oracle's (and the smoothing specification's), in presentation order.  Usage: tools/soak_decoder.py [streams = 150] [first seed = 0]"""
 import os, sys, tempfile, time, zlib
 REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(REPO, "tmc2-rs_amd")); sys.path.insert(0, os.path.join(REPO, "tests"))
@@ -19,9 +19,30 @@ for i in range(36):
     w = 16 * int(rng.integers(30, 81) if big else rng.integers(2, 26)); h = 16 * int(rng.integers(30, 70) if big else rng.integers(2, 20))
     f = synth.make_frame(w, h, int(rng.choice([1, 2, 4, 4])), 16, seed=0xDEC00000 + seed0 * 1009 + i, max_side=int(rng.integers(2, 20 if big else 9)),
                          cover_target=float(rng.uniform(0.2, 0.9)), swap_prob=float(rng.uniform(0, 1)), dup_prob=float(rng.uniform(0, 0.6)))
+    if i % 3 != 0:                                             # patches that overlap in 3-D: cells that mix patches, work for the filters
+        p = f["patches"].copy()
+        p["u1"] = 100 + (np.arange(len(p)) % 5) * 3; p["v1"] = 100 + (np.arange(len(p)) % 7) * 2
+        p["d1"] = np.where(p["projection_mode"] == 0, 100, 300)
+        f["patches"] = p
     st, r = ob.reconstruct(f)
     assert st == 0
-    pool.append((f, (r["n"], crc(ob.xyz_array(r), ob.rgb_array(r)))))
+    pool.append((f, (r["n"], crc(ob.xyz_array(r), ob.rgb_array(r))), (ob.xyz_array(r), ob.rgb_array(r), r["partition"].astype(np.uint16))))
+smoothed = {}
+changed = [0]
+def expected(k, sm):
+    """(points, CRC) of pool frame k behind the filters `sm` = (geometry, colour, grid, threshold, colour grid, Ts, Td) — the specification's."""
+    if sm is None:
+        return pool[k][1]
+    if (k, sm) not in smoothed:
+        xyz, rgb, part = pool[k][2]
+        geo, col, G, T, CG, Ts, Td = sm
+        if geo:
+            xyz = ob.spec_smooth_geometry(xyz, part, 10, G, T)
+        if col:
+            rgb = ob.spec_smooth_color(xyz, rgb, part, 10, CG, Ts, Td)
+        smoothed[(k, sm)] = (len(xyz), crc(xyz, rgb))
+        changed[0] += int(smoothed[(k, sm)] != pool[k][1])
+    return smoothed[(k, sm)]
 switches = ["VPCC_NO_EXTENT_INGEST", "VPCC_NO_STAGED_DESCRIPTORS", "VPCC_NO_PULL_INGEST", "VPCC_NO_PUSH_DOWNLOAD", "VPCC_DECODER_NO_TAIL_SPLIT",
             "VPCC_DECODER_NO_HUGEPAGES"]
 bad = frames = 0
@@ -39,14 +60,22 @@ try:
             os.environ["VPCC_DECODER_PIN_CHUNK_MB"] = str(int(rng.choice([1, 3, 16])))
         if rng.random() < 0.7:
             os.environ["VPCC_DECODER_POOL_GIB"] = str(int(rng.choice([0, 0, 2, 4])))
+        sm = None
+        if rng.random() < 0.3:                                 # the post-processing switches (src/lib.rs:45-46), parameters from Params
+            geo, col = [(True, False), (False, True), (True, True)][int(rng.integers(0, 3))]
+            G = int(rng.choice([4, 8, 8, 16]))
+            sm = (geo, col, G, int(rng.choice([0, 2, 4])), G if rng.random() < 0.6 else int(rng.choice([4, 8, 16])), int(rng.choice([0, 5, 10])), int(rng.choice([50, 100, 765])))
         gofs, expect = [], []
         for g in range(int(rng.integers(1, 15))):
             idx = [int(k) for k in rng.integers(0, len(pool), size=int(rng.integers(1, 41)))]
-            gofs.append([pool[k][0] for k in idx]); expect += [pool[k][1] for k in idx]
+            gofs.append([pool[k][0] for k in idx]); expect += [expected(k, sm) for k in idx]
         lanes = int(rng.choice([1, 1, 2, 3, 4]))
         stop_at = int(rng.integers(0, len(expect))) if rng.random() < 0.15 else None
         container.write_container(path, gofs)
         dec = recon.Decoder(path, devices=(0,) * lanes)
+        if sm is not None:
+            dec.set_smoothing(geometry=sm[0], color=sm[1], bitdepth=10, grid_size=sm[2], threshold=sm[3], color_grid_size=sm[4],
+                              color_threshold_smoothing=sm[5], color_threshold_difference=sm[6])
         dec.start()
         got = []
         for fr in dec:
@@ -61,7 +90,7 @@ try:
             bad += 1
             first = next((i for i, (a, b) in enumerate(zip(got, expect)) if a != b), None)
             print(f"MISMATCH stream {si}: {len(gofs)} GOFs of {[len(g) for g in gofs]} frames, {lanes} lanes, {on}, "
-                  f"{ {k: os.environ[k] for k in ('VPCC_DECODER_PIN_CHUNK_MB', 'VPCC_DECODER_POOL_GIB') if k in os.environ} }, stop_at {stop_at}: "
+                  f"{ {k: os.environ[k] for k in ('VPCC_DECODER_PIN_CHUNK_MB', 'VPCC_DECODER_POOL_GIB') if k in os.environ} }, smoothing {sm}, stop_at {stop_at}: "
                   f"error {err!r}, {len(got)} of {len(expect)} frames, first difference at {first}", flush=True)
         if si % 10 == 9:
             print(f"{si + 1} streams, {frames} frames, {bad} bad, {time.time() - t0:.0f} s", flush=True)
@@ -69,5 +98,5 @@ finally:
     if os.path.exists(path):
         os.remove(path)
     os.rmdir(d)
-print(f"soak: {n_streams} streams, {frames} frames, {bad} bad")
+print(f"soak: {n_streams} streams, {frames} frames, {bad} bad; {len(smoothed)} (frame, filter parameters) pairs, {changed[0]} of them changed by the filters")
 sys.exit(1 if bad else 0)
