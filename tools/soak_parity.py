@@ -1,12 +1,14 @@
 #!/usr/bin/env python3
 """Differential soak of the HIP path against the CPU oracle: thousands of seeded random frames — canvas sizes, block sizes,
 precisions, occupancy styles, patch statistics, orientations, relative D1, full-range samples, padded rows — in gofs of random
-sizes on the path gof creation chooses, points, colours and partition compared for every frame.
+sizes, planes in host memory or in the caller's device memory (borrowed or copied, some not aligned), on the path gof creation chooses, points, colours and partition compared for every frame.
 Usage: tools/soak_parity.py [frames = 2000] [first seed = 0]"""
 import os, sys, time
 REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(REPO, "tmc2-rs_amd")); sys.path.insert(0, os.path.join(REPO, "tests"))
 import numpy as np
+import torch                                                     # (the allocator of the caller's device planes; before the library's own HIP start-up)
+torch.cuda.init()
 from tmc2rs import _abi, recon, synth
 import oracle_binding as ob
 n_total = int(sys.argv[1]) if len(sys.argv) > 1 else 2000
@@ -38,12 +40,41 @@ ctx = recon.Context(0)
 done = bad = 0
 t0 = time.time()
 paths = {"tiles": 0, "general": 0}
+modes = [0, 0, 0]
 while done < n_total:
     k = int(rng.integers(1, 41))
     R = int(rng.choice([16] * 7 + [8, 32, 4]))                  # one block size per gof: gofs of 16s take the tile kernel
     frames = [frame(done + j, R) for j in range(k)]
     refs = [ob.reconstruct(f) for f in frames]
-    g = ctx.gof(frames, flags=_abi.VPCC_GOF_WANT_PATCH_INDEX | _abi.VPCC_GOF_PROFILE)
+    mode = int(rng.choice([0, 0, 1, 2]))                          # planes: the host's / the caller's device planes, borrowed / ... copied
+    if mode == 0:
+        g = ctx.gof(frames, flags=_abi.VPCC_GOF_WANT_PATCH_INDEX | _abi.VPCC_GOF_PROFILE)
+    else:
+        keep, descs = [], []
+        def up(a):
+            raw = np.ascontiguousarray(a).view(np.uint8).reshape(-1)
+            off = int(rng.choice([0, 0, 0, 2, 8, 16, 30, 256]))  # now and then a plane that does not start where an allocation does
+            x = torch.empty(len(raw) + off + 64, dtype=torch.uint8, device="cuda:0")
+            x[off:off + len(raw)] = torch.from_numpy(raw).to("cuda:0")
+            keep.append(x)
+            return x.data_ptr() + off
+        for f in frames:
+            d, k0 = _abi.host_frame_desc(f)
+            keep.append(k0)
+            d.occupancy.y = up(f["occupancy"]); d.occupancy.stride = d.occupancy.width
+            for m in range(f["map_count"]):
+                d.geometry[m].y = up(f["geometry"][m]); d.geometry[m].stride = d.geometry[m].width
+                if f["attribute_count"]:
+                    d.attribute[m].y, d.attribute[m].u, d.attribute[m].v = (up(pl) for pl in f["attribute"][m])
+                    d.attribute[m].stride, d.attribute[m].cstride = d.attribute[m].width, d.attribute[m].width // 2
+            descs.append(d)
+        torch.cuda.synchronize()
+        g = ctx.gof(None, memory=_abi.VPCC_MEM_DEVICE, descs=descs,
+                    flags=_abi.VPCC_GOF_WANT_PATCH_INDEX | _abi.VPCC_GOF_PROFILE | (_abi.VPCC_GOF_COPY_PLANES if mode == 2 else 0))
+        if mode == 2:
+            del keep[:]                                          # copied: the caller's planes may go
+            torch.cuda.synchronize()
+    modes[mode] += k
     g.reconstruct()
     names = [n for n, _ in g.kernel_times()]
     paths["tiles" if any("k_recon_tiles" in n for n in names) else "general"] += k
@@ -62,6 +93,6 @@ while done < n_total:
     g.close()
     done += k
     if (done // 200) != ((done - k) // 200):
-        print(f"{done} frames, {bad} mismatches, {time.time() - t0:.0f} s, frames by path {paths}", flush=True)
-print(f"soak: {done} frames, {bad} mismatches, frames by path {paths}")
+        print(f"{done} frames, {bad} mismatches, {time.time() - t0:.0f} s, frames by path {paths}, by plane memory (host, device, device copied) {modes}", flush=True)
+print(f"soak: {done} frames, {bad} mismatches, frames by path {paths}, by plane memory (host, device, device copied) {modes}")
 sys.exit(1 if bad else 0)
