@@ -5,15 +5,18 @@ A "step" is one pass of the hot path over one batch: ONE launch over four GOFs o
 S-longdress frames each (128 frames; 1280x1408 geometry+attribute, 320x352 occupancy, ~800 k points/frame —
 BASELINE.json configs[1]), all decoded planes — in the RASTER layout a video decoder hands over — and
 patch tables already resident in HBM when the timed region starts; every kernel between those planes and the points is
-inside the region (`roofline.all_kernels_ms`: k_recon_tiles alone; nothing is re-arranged, the work lists are built when the
-gof is created, like the upload).  The gof's blocks are allocated by the policy the product uses: the context's pool
-(vpcc_ctx_reserve, `config.pool`; the streaming Decoder's lanes reserve the same).  This is the launch the product issues:
-tmc2rs::Decoder reconstructs every run of up to four resident GOFs in one launch (`end_to_end.max_frames_per_launch`).  Frames are independent, so with N GPUs every
-rank reconstructs its own batch (weak scaling, no data-path collective); `value` is the whole-job Mpoints/s.
+inside the region (`roofline.all_kernels_ms`): k_plan_tiles — block_to_patch and the work list, the device port of
+generate_block_to_patch_from_occupancy_map_video, src/codec.rs:205-250, built by EVERY launch from the occupancy as it lies —
+and k_recon_tiles; nothing is re-arranged.  `roofline.frac` is the dominant kernel's, `roofline.path_frac` the same bytes over
+the sum of all kernels of the step.  The gof's blocks are allocated from the context's pool (vpcc_ctx_reserve, `config.pool`):
+the policy for callers whose planes are in HBM already — the streaming Decoder, whose kernels are under 1 % of its wall
+time, does without it by default.  Frames are independent, so with N GPUs every rank reconstructs its own batch (weak
+scaling, no data-path collective); `value` is the whole-job Mpoints/s.
 
   python bench.py --gpus 1 --steps 20 --warmup 3
+  python bench.py --gpus N --steps K --warmup W        # starts its N ranks itself (torch.distributed.run, one per GPU, RCCL)
   python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
-         --master-port P bench.py --gpus N --steps K --warmup W
+         --master-port P bench.py --gpus N --steps K --warmup W     # ... or is started as one of them
 
 The timed region is tmc2rs.sharding.timed_region (the function the world-size-2 gloo test runs): W warm-up
 steps, then K steps between barrier + synchronisation pairs; K is raised to `steps_effective` until the
@@ -35,8 +38,14 @@ One JSON line is printed by rank 0, with the contract fields plus
                     rgb by CRC) with the CPU oracle's output for its frame — the run fails if one differs.
   other_configs   : BASELINE configs 5 (S-owlii, 2048x2048) and 4 (S-longdress + grid smoothing, own spec), N=1
                     only, each a short timed loop over 128-frame launches with its own verification.
+  fresh_gof       : what the product pays ONCE PER GOF, none of which the headline's relaunches contain: three distinct
+                    128-frame batches of raster planes resident in HBM (VPCC_MEM_DEVICE, in the pool's homes), every step =
+                    vpcc_gof_create + vpcc_gof_reconstruct on the next batch + vpcc_gof_destroy of the one before last —
+                    validation, the host's O(patches) records, descriptors, planning and reconstruction kernels.  N=1 only.
   end_to_end      : host-buffer (PCIe-inclusive) rate through the C++ Decoder (pinned container -> H2D ->
-                    kernels -> D2H -> consumer); never `value`.  N=1 only.
+                    kernels -> D2H -> consumer); never `value`.  N=1 only.  Measured COLD: it is the first thing this
+                    process does on the GPU (no context, no pool, no warm allocator); `end_to_end.warm` is a second
+                    Decoder at the end of the run.
   cpu_baseline    : the CPU oracle (a port of the reference's algorithm; the Rust crate cannot be built
                     here) timed single-threaded on this box, rank 0 at N=1 only.
 """
@@ -115,10 +124,16 @@ def parse():
                          "launches of the same kernel would blur a rocprofv3 average of the run")
     ap.add_argument("--no-verify", action="store_true", help="skip the oracle check of the timed GOF's output (tools/ only)")
     ap.add_argument("--no-end-to-end", action="store_true", help="skip the PCIe-inclusive Decoder run")
+    ap.add_argument("--no-warm-e2e", action="store_true", help="skip the second (warm) Decoder run at the end")
     ap.add_argument("--e2e-gofs", type=int, default=17, help="GOFs in the end-to-end container (launches of 1 + 4 + 4 + 4 + 2 + 1 + 1 GOFs: the stream's last unit is dealt out in halves)")
     ap.add_argument("--profile-every", type=int, default=16,
                     help="an event pair around every n-th launch of the timed region (each costs a few us of stream time)")
     ap.add_argument("--profile-steps", type=int, default=0, help=argparse.SUPPRESS)   # accepted for old tool scripts
+    ap.add_argument("--no-fresh-gof", action="store_true", help="skip the `fresh_gof` leg (create + reconstruct + destroy per step)")
+    ap.add_argument("--dry-run", action="store_true",
+                    help="no GPU: the launch of the ranks, the process group (VPCC_BENCH_BACKEND, default gloo here), the timed "
+                         "region's barriers and its MAX / SUM / MIN reductions with a step that only sleeps — what `--gpus N` "
+                         "does around the kernels, for the CPU test of that path")
     return ap.parse_args()
 
 
@@ -142,16 +157,106 @@ def smoothing_algorithmic_bytes(gof, n_frames, bitdepth, grid, cgrid):
     return total
 
 
+def end_to_end_leg(frames, args, device):
+    """Host buffers in, host buffers out: the C++ Decoder on a container of --e2e-gofs copies of the GOF (written to /dev/shm)."""
+    import tempfile
+    from tmc2rs import container, recon
+    d = tempfile.mkdtemp(dir="/dev/shm" if os.path.isdir("/dev/shm") else None)
+    path = os.path.join(d, "bench_e2e.vpccgof")
+    try:
+        container.write_container(path, [frames] * args.e2e_gofs)
+        size = os.path.getsize(path)
+        dec = recon.Decoder(path, devices=(device,))
+        dec.start()
+        nf, npts, sec = dec.drain()
+        t_first = dec.first_frame_seconds()
+        dstats = dec.stats()
+        dec.close()
+        # Two bounds of the steady rate: the whole run includes the start-up (contexts, page-locking, first GOF);
+        # the rate after the first frame profits from the uploads of the next units that were already running
+        # during the start-up (two units of look-ahead).
+        after = (sec - t_first) / max(nf - 1, 1)
+        return {"_frames": nf, "_points": npts,
+                "whole_run_frames_per_s": round(nf / sec, 1), "after_first_frame_frames_per_s": round(1.0 / after, 1),
+                "whole_run_Mpoints_per_s": round(npts / sec / 1e6, 1),
+                "h2d_GBps_whole_run": round(size / sec / 1e9, 2), "d2h_GBps_whole_run": round(npts * 9 / sec / 1e9, 2),
+                "startup_s": round(t_first, 3),
+                # the product's own launches: GOF 0 alone, then every resident run of up to four GOFs in ONE launch
+                "launches": dstats["launches"], "max_frames_per_launch": dstats["max_frames_per_launch"],
+                "kernel_seconds": round(dstats["kernel_seconds"], 6),
+                "kernels_share_of_wall": round(dstats["kernel_seconds"] / sec, 4),
+                # host work of a unit on its lane's thread — validation, the O(patches) records, descriptors, the enqueue of
+                # ingest and launch — summed over units, per frame: it runs while the previous unit's transfers do
+                "host_plan_and_enqueue_us_per_frame": round(dstats["launch_seconds"] / max(nf, 1) * 1e6, 1),
+                "lane_numa_nodes": dstats["numa_node"],
+                "pool": os.environ.get("VPCC_DECODER_POOL_GIB", "none (the Decoder's default: its kernels are under 1 % of its wall time)"),
+                "sample": f"{args.e2e_gofs} GOFs x {args.frames} frames through tmc2rs::Decoder (pinned container -> "
+                          f"H2D -> kernels -> D2H -> consumer); the rate after the first frame still contains the stream's end, "
+                          f"where the last GOF's results travel back alone"}
+    finally:
+        if os.path.exists(path):
+            os.remove(path)
+        os.rmdir(d)
+
+
+def launch_ranks(n):
+    """`python bench.py --gpus N` outside a launcher: start the N ranks — `python -m torch.distributed.run`, one process per
+    GPU on this node, rendezvous on 127.0.0.1 at a free port — as a CHILD of this process, which has touched neither torch
+    nor the GPU (never a re-exec), pass rank 0's JSON line through and return the launcher's exit status."""
+    import socket
+    import subprocess
+    with socket.socket() as so:
+        so.bind(("127.0.0.1", 0))
+        port = so.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")          # RCCL between processes needs dmabuf IPC on this driver
+    env.setdefault("OMP_NUM_THREADS", "1")
+    return subprocess.call(cmd, env=env)
+
+
+def dry_run(args, rank, world):
+    """The rank path without a GPU: process group, timed region (barriers, K identical on every rank, MAX of the time, SUM
+    of the points), the MIN reduction of the verification flag, one JSON line from rank 0."""
+    import torch
+    from tmc2rs import sharding
+    backend = os.environ.get("VPCC_BENCH_BACKEND", "gloo")
+    dist = None
+    if world > 1 or os.environ.get("VPCC_BENCH_FORCE_DIST"):
+        import torch.distributed as dist
+        dist.init_process_group(backend)
+    points = 1000 * (rank + 1)
+    reg = sharding.timed_region(lambda: time.sleep(0.001 * (1 + rank)), lambda: None, args.steps, args.warmup, points, dist=dist,
+                                device="cpu", min_seconds=min(args.min_seconds, 0.05))
+    ok = 1
+    if dist is not None:
+        v = torch.tensor([ok], dtype=torch.int64)
+        dist.all_reduce(v, op=dist.ReduceOp.MIN)
+        ok = int(v.item())
+    if rank == 0:
+        print(json.dumps({"metric": "dry run: no kernel was launched", "value": round(reg["points_total_per_step"] * reg["steps_effective"] / reg["elapsed_s"] / 1e6, 3),
+                          "unit": "Mpoints/s", "n_gpus": world, "steps": args.steps, "steps_effective": reg["steps_effective"], "warmup": args.warmup,
+                          "ms_per_step": round(reg["elapsed_s"] / reg["steps_effective"] * 1e3, 4), "points_total_per_step": reg["points_total_per_step"],
+                          "verified": bool(ok), "dry_run": True, "backend": backend}))
+    if dist is not None:
+        dist.destroy_process_group()
+    return 0 if ok else 3
+
+
 def main():
     args = parse()
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(launch_ranks(args.gpus))
     if world != args.gpus:
         if rank == 0:
-            print(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}; launch with torch.distributed.run",
-                  file=sys.stderr)
+            print(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}", file=sys.stderr)
         sys.exit(2)
+    if args.dry_run:
+        sys.exit(dry_run(args, rank, world))
 
     import numpy as np
     import torch
@@ -188,8 +293,15 @@ def main():
     frames = [make(rank * args.frames + i, **kw) for i in range(args.frames)]
     cap = 1_000_000 if args.workload == "longdress" else 2_400_000
 
+    # ---- end to end FIRST, cold: the first thing this process does on the GPU (no context, no pool to take over, no warm
+    # allocator) — what a user who starts a Decoder gets.  Checked against the point counts further down.
+    e2e = None
+    if rank == 0 and world == 1 and not args.no_end_to_end and not args.smooth and not args.general:
+        e2e = end_to_end_leg(frames, args, local_rank)
+        e2e["cold"] = True
+
     ctx = recon.Context(local_rank)
-    # the allocation policy of the product: the Decoder's lanes reserve the same pool (decoder.cpp), at no cost per gof
+    # the pool: the allocation policy for callers whose planes are in HBM (this bench's legs; the Decoder does without)
     pool_info = ctx.reserve(args.pool_gib) if args.pool_gib >= 2 else None
     flags = (_abi.VPCC_GOF_FORCE_GENERAL if args.general else 0) | _abi.VPCC_GOF_PROFILE
     if args.smooth:
@@ -449,7 +561,11 @@ def main():
                     "frac_traffic": round(tr["hbm_bytes_per_launch"] / (dom_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4) if tr else None,
                     "traffic_source": tr.get("source") if tr else None,
                     "timed_region_ms_per_step": round(region_ms_per_step, 4),
-                    "all_kernels_ms": {k: round(v, 4) for k, v in kernels.items()}}
+                    "all_kernels_ms": {k: round(v, 4) for k, v in kernels.items()},
+                    # the same algorithmic bytes over EVERY kernel of the step — planning (block_to_patch + work list,
+                    # src/codec.rs:205-250) and reconstruction: the fraction the per-frame path as a whole reaches
+                    "path_kernels_ms": round(sum(kernels.values()), 4),
+                    "path_frac": None if args.smooth else round(alg_bytes / (sum(kernels.values()) * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4)}
         if args.smooth:
             roofline["smoothing_algorithmic_bytes_per_launch"] = smooth_bytes
             roofline["reconstruction_algorithmic_bytes_per_launch"] = alg_bytes
@@ -534,6 +650,138 @@ def main():
         return out2
 
     pool_after = ctx.pool_info() if pool_info else None          # (with the timed batches alive)
+    # ---- fresh_gof: what the product pays once per gof (N=1, rank 0) -----------------------------------------------
+    def fresh_gof_leg(n_batches=3):
+        """Three distinct 128-frame batches of raster planes RESIDENT IN HBM — a GPU video decoder's frame pool, in memory of
+        the context's pool (vpcc_ctx_pool_alloc: frames 0-7 in home 0, 8-15 in home 1, ...) — borrowed by the library
+        (VPCC_MEM_DEVICE).  A step = vpcc_gof_create on the next batch (validation, the host's O(patches) records, one
+        descriptor copy) + vpcc_gof_reconstruct (k_plan_tiles + k_recon_tiles) + vpcc_gof_destroy of the gof before last:
+        every gof is launched ONCE, as the streaming product launches it.  Timed like the headline."""
+        import ctypes as C
+        hip = C.CDLL("libamdhip64.so.7")
+        hip.hipMemcpy.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int]
+        lib = ctx.lib
+        held, keep, arrays = [], [], []
+        for b in range(n_batches):
+            order = [(i * (2 * b + 1) + 5 * b) % len(batch) for i in range(len(batch))]      # every batch in an order of its own
+            arr = (_abi.FrameDesc * len(batch))()
+            for r0 in range(0, len(batch), 8):
+                run = [batch[order[i]] for i in range(r0, min(r0 + 8, len(batch)))]
+                planes = []
+                for f in run:
+                    planes.append([f["occupancy"]] + [f["geometry"][m] for m in range(2)] + [pl for m in range(2) for pl in f["attribute"][m]])
+                total = sum((pl.nbytes + 255) // 256 * 256 for fr_ in planes for pl in fr_)
+                base = ctx.pool_alloc((r0 // 8) % 2, total)
+                held.append(base)
+                at = base
+                for j, f in enumerate(run):
+                    d, k_ = _abi.host_frame_desc(f)
+                    keep.append(k_)
+                    ptrs = []
+                    for pl in planes[j]:
+                        a_ = np.ascontiguousarray(pl)
+                        assert hip.hipMemcpy(at, a_.ctypes.data, a_.nbytes, 1) == 0
+                        ptrs.append(at)
+                        at += (a_.nbytes + 255) // 256 * 256
+                    d.occupancy.y = ptrs[0]
+                    d.occupancy.stride = d.occupancy.width
+                    for m in range(2):
+                        d.geometry[m].y = ptrs[1 + m]
+                        d.attribute[m].y, d.attribute[m].u, d.attribute[m].v = ptrs[3 + 3 * m], ptrs[4 + 3 * m], ptrs[5 + 3 * m]
+                    arr[r0 + j] = d
+            arrays.append((arr, order))
+        live, host_s, k_sum, k_n, turn_ = [], [0.0], {}, [0], [0]
+
+        def read_times(h_):
+            names = (C.c_char_p * 8)()
+            msv = (C.c_float * 8)()
+            n_ = lib.vpcc_gof_kernel_times(h_, names, msv, 8)
+            for q in range(n_):
+                k_sum[names[q].decode()] = k_sum.get(names[q].decode(), 0.0) + float(msv[q])
+            k_n[0] += 1
+
+        def step_():
+            t_ = time.perf_counter()
+            k = turn_[0]
+            turn_[0] += 1
+            h_ = C.c_void_p()
+            prof = _abi.VPCC_GOF_PROFILE if k % 16 == 0 else 0
+            st_ = lib.vpcc_gof_create(ctx.h, arrays[k % n_batches][0], len(batch), _abi.VPCC_MEM_DEVICE, cap, prof, C.byref(h_))
+            ctx._check(st_, "vpcc_gof_create")
+            ctx._check(lib.vpcc_gof_reconstruct(h_, 0, len(batch), None), "vpcc_gof_reconstruct")
+            live.append((h_, k % n_batches, bool(prof)))
+            if len(live) > 2:
+                old, _, was_prof = live.pop(0)
+                host_s[0] += time.perf_counter() - t_
+                if was_prof:
+                    read_times(old)                  # (waits for that gof's launch: outside the host-time account)
+                t_ = time.perf_counter()
+                lib.vpcc_gof_destroy(old)
+            host_s[0] += time.perf_counter() - t_
+
+        def sync_():
+            for h_, _, _ in live:
+                ctx._check(lib.vpcc_gof_sync(h_), "vpcc_gof_sync")
+
+        for _ in range(64):
+            step_()
+        sync_()
+        host_s[0], turn0 = 0.0, turn_[0]
+        k_sum.clear()
+        k_n[0] = 0
+        reg_ = sharding.timed_region(step_, sync_, args.steps, args.warmup, points_per_step, min_seconds=args.min_seconds,
+                                     device_sync=torch.cuda.synchronize)
+        steps_run = turn_[0] - turn0
+        host_us = host_s[0] / max(steps_run, 1) * 1e6
+        # the last gofs' output against the oracle (entries of each batch lie in that batch's order)
+        sys.path.insert(0, os.path.join(REPO, "tests"))
+        import oracle_binding as ob
+        good, checked = True, 0
+        for h_, bi, _ in live:
+            order = arrays[bi][1]
+            cts = np.zeros(len(batch), dtype=np.uint32)
+            ctx._check(lib.vpcc_gof_point_counts(h_, cts.ctypes.data), "vpcc_gof_point_counts")
+            for e in (0, len(batch) // 2 + 3, len(batch) - 1):
+                st_, ref = ob.reconstruct(batch[order[e]])
+                n_ = int(cts[e])
+                xyz = np.zeros(max(n_, 1), dtype=_abi.POINT3_DTYPE)
+                rgb = np.zeros(max(n_, 1), dtype=_abi.COLOR3_DTYPE)
+                kk = C.c_size_t(0)
+                ctx._check(lib.vpcc_gof_download(h_, e, xyz.ctypes.data, rgb.ctypes.data, None, max(n_, 1), C.byref(kk)), "vpcc_gof_download")
+                good = good and st_ == 0 and kk.value == ref["n"] and zlib.crc32(xyz[:kk.value].tobytes()) == zlib.crc32(ob.xyz_array(ref).tobytes()) \
+                    and zlib.crc32(rgb[:kk.value].tobytes()) == zlib.crc32(ob.rgb_array(ref).tobytes())
+                checked += 1
+        for h_, _, was_prof in live:
+            if was_prof:
+                read_times(h_)
+            lib.vpcc_gof_destroy(h_)
+        for p_ in held:
+            ctx.pool_free(p_)
+        ms_ = reg_["elapsed_s"] / reg_["steps_effective"] * 1e3
+        km = {k_: round(v / max(k_n[0], 1), 4) for k_, v in k_sum.items()}
+        ksum = sum(km.values())
+        return {"step": f"vpcc_gof_create + vpcc_gof_reconstruct on the next of {n_batches} resident {len(batch)}-frame batches (raster planes in HBM, "
+                        f"VPCC_MEM_DEVICE, frame pool in the context's pool) + vpcc_gof_destroy of the gof before last: every gof launched once",
+                "ms_per_step": round(ms_, 4), "steps_effective": reg_["steps_effective"],
+                "frames_per_s": round(len(batch) / (ms_ * 1e-3), 1), "Mpoints_per_s": round(points_per_step / (ms_ * 1e-3) / 1e6, 1),
+                "host_us_per_step": round(host_us, 1), "host_us_per_frame": round(host_us / len(batch), 3),
+                "host_is": "wall time of the three calls on the caller's thread (validation, O(patches) records, layout, one staged copy, "
+                           "memsets, launches, destroy); the wait a destroy spends on a gof whose kernels still run is in it",
+                "all_kernels_ms": km, "kernel_launches_averaged": k_n[0],
+                "frac": round(alg_bytes / (ksum * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4) if ksum else None,
+                "frac_of_the_step": round(alg_bytes / (ms_ * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4),
+                "entries_checked": checked, "equals_oracle": bool(good)}
+
+    fresh = None
+    if rank == 0 and world == 1 and not args.no_fresh_gof and not args.smooth and not args.general:
+        for g_ in gofs:                                          # their 5 GB are not needed any more
+            g_.close()
+        gofs = []
+        fresh = fresh_gof_leg()
+        if not fresh["equals_oracle"]:
+            print(f"bench.py: fresh_gof failed verification: {fresh}", file=sys.stderr)
+            sys.exit(3)
+
     other = None
     if rank == 0 and world == 1 and not args.no_other_configs and not args.smooth and not args.general and args.workload == "longdress":
         for g_ in gofs:                                          # their 5 GB are not needed any more
@@ -544,54 +792,20 @@ def main():
             print(f"bench.py: other_configs failed verification: {other}", file=sys.stderr)
             sys.exit(3)
 
-    # ---- end to end: host buffers in, host buffers out (C++ Decoder) -----------------------------
-    # The Decoder's lanes make contexts of their own, with the same pool policy: this process's context goes first, and
-    # the lane takes its pool over as it is (vpcc_ctx_reserve keeps retired pools with the process).
+    # ---- end to end once more, WARM: a second Decoder in a process whose allocator, page-locked buffers and clocks are up
     for g_ in gofs:
         g_.close()
     gofs = []
     ctx.close()
-    e2e = None
-    if rank == 0 and world == 1 and not args.no_end_to_end and not args.smooth and not args.general:
-        import tempfile
-        from tmc2rs import container
-        d = tempfile.mkdtemp(dir="/dev/shm" if os.path.isdir("/dev/shm") else None)
-        path = os.path.join(d, "bench_e2e.vpccgof")
-        try:
-            container.write_container(path, [frames] * args.e2e_gofs)
-            size = os.path.getsize(path)
-            dec = recon.Decoder(path, devices=(local_rank,))
-            dec.start()
-            nf, npts, sec = dec.drain()
-            t_first = dec.first_frame_seconds()
-            dstats = dec.stats()
-            dec.close()
-            points_per_gof = int(counts[:args.frames].sum())
-            assert nf == args.frames * args.e2e_gofs and npts == points_per_gof * args.e2e_gofs, "Decoder output differs"
-            # Two bounds of the steady rate: the whole run includes the start-up (contexts, page-locking, first GOF);
-            # the rate after the first frame profits from the uploads of the next units that were already running
-            # during the start-up (two units of look-ahead).
-            after = (sec - t_first) / max(nf - 1, 1)
-            e2e = {"whole_run_frames_per_s": round(nf / sec, 1), "after_first_frame_frames_per_s": round(1.0 / after, 1),
-                   "whole_run_Mpoints_per_s": round(npts / sec / 1e6, 1),
-                   "h2d_GBps_whole_run": round(size / sec / 1e9, 2), "d2h_GBps_whole_run": round(npts * 9 / sec / 1e9, 2),
-                   "startup_s": round(t_first, 3),
-                   # the product's own launches: GOF 0 alone, then every resident run of up to four GOFs in ONE launch
-                   "launches": dstats["launches"], "max_frames_per_launch": dstats["max_frames_per_launch"],
-                   "kernel_seconds": round(dstats["kernel_seconds"], 6),
-                   "kernels_share_of_wall": round(dstats["kernel_seconds"] / sec, 4),
-                   # host work of a unit on its lane's thread — validation, planning of the work lists (8 helper threads),
-                   # descriptors, the enqueue of ingest and launch — summed over units, per frame: it runs while the
-                   # previous unit's transfers do (two units of look-ahead)
-                   "host_plan_and_enqueue_us_per_frame": round(dstats["launch_seconds"] / max(nf, 1) * 1e6, 1),
-                   "lane_numa_nodes": dstats["numa_node"],
-                   "sample": f"{args.e2e_gofs} GOFs x {args.frames} frames through tmc2rs::Decoder (pinned container -> "
-                             f"H2D -> kernels -> D2H -> consumer); the rate after the first frame still contains the stream's end, "
-                             f"where the last GOF's results travel back alone"}
-        finally:
-            if os.path.exists(path):
-                os.remove(path)
-            os.rmdir(d)
+    if e2e is not None:
+        points_per_gof = int(counts[:args.frames].sum())
+        assert e2e.pop("_frames") == args.frames * args.e2e_gofs and e2e.pop("_points") == points_per_gof * args.e2e_gofs, "Decoder output differs"
+        if not args.no_warm_e2e:
+            warm = end_to_end_leg(frames, args, local_rank)
+            assert warm.pop("_frames") == args.frames * args.e2e_gofs and warm.pop("_points") == points_per_gof * args.e2e_gofs, "Decoder output differs"
+            e2e["warm"] = {k: warm[k] for k in ("whole_run_frames_per_s", "after_first_frame_frames_per_s", "startup_s", "h2d_GBps_whole_run",
+                                                "host_plan_and_enqueue_us_per_frame")}
+            e2e["warm"]["note"] = "a second Decoder at the end of the run (contexts, caches and clocks warm): secondary, never the figure quoted"
 
     # ---- CPU baseline: the oracle (port of the reference algorithm), single thread, rank 0, N=1 ---
     cpu = None
@@ -663,6 +877,7 @@ def main():
             "roofline": roofline,
             "library": lib_info,
             "gpu_state_under_load": gpu_state,
+            "fresh_gof": fresh,
             "other_configs": other,
             "launches_of_one_gof": one_gof,
             "repeat_one_batch": repeat,

@@ -34,7 +34,7 @@
 extern "C" {
 #endif
 
-#define VPCC_ABI_VERSION 4   /* 4: vpcc_ctx_reserve / vpcc_ctx_pool_info replace VPCC_GOF_TUNE_PLACEMENT / vpcc_gof_placement; planes stay raster.  3,  2: vpcc_ctx_bind_thread, vpcc_decoder_stats, vpcc_gof_profile_interval / _kernel_time_means; portable page-locking */
+#define VPCC_ABI_VERSION 5   /* 5: vpcc_ctx_reserve_within, vpcc_ctx_pool_alloc / _free, vpcc_release_kept_pools; block_to_patch and the work lists are built by every launch.  4: vpcc_ctx_reserve / vpcc_ctx_pool_info replace VPCC_GOF_TUNE_PLACEMENT / vpcc_gof_placement; planes stay raster.  3,  2: vpcc_ctx_bind_thread, vpcc_decoder_stats, vpcc_gof_profile_interval / _kernel_time_means; portable page-locking */
 
 /* ------------------------------------------------------------------ status */
 typedef enum vpcc_status {
@@ -166,7 +166,10 @@ int  vpcc_ctx_bind_thread(vpcc_ctx* ctx, int* node_out);
  * then plain allocations.  When the allocation turns out to lie in one kind only (on some GPUs the first 60 GB of VRAM
  * are alike), a second one of half its size is looked for further away — behind 16-GiB spacers that are freed again,
  * up to four times, while a third of the device's memory stays free — and kept as the other home: the pool then holds
- * 1.5 x `bytes`.  30-50 ms for 32 GiB.  The pool of a destroyed context stays with the process and is taken over,
+ * 1.5 x `bytes`.  Cost: 30-50 ms for 32 GiB on a GPU whose memory is clean; the median of 321 reservations on this pool of
+ * machines was 218 ms and the slowest took 4.4 s (the driver wipes what another process freed before it hands it out:
+ * profiles/r04/pool.txt) — reserve it beside the first work, not in front of it.  The pool of a destroyed context stays
+ * with the process and is taken over,
  * classification included, by the next context that reserves one on the device (memory given back to the driver is
  * wiped before it is handed out again, and every allocation of the process waits for that).  Call it once, before or
  * beside the context's first gofs (it may run on a thread of its own; gofs created meanwhile allocate as without it).  VPCC_ERR_STATE: the context has
@@ -186,7 +189,22 @@ typedef struct vpcc_pool_info {
   uint32_t reserved0;
 } vpcc_pool_info;
 int  vpcc_ctx_reserve(vpcc_ctx* ctx, uint64_t bytes, vpcc_pool_info* out /* may be NULL */);
+/* The same within a budget of wall-clock time: once `budget_ms` have passed (the allocation itself can take seconds right
+ * after another process has freed tens of GB: the driver wipes memory before it hands it out again) no second home is
+ * looked for — the pool is what the first allocation turned out to be, of one kind if need be.  0: no limit. */
+int  vpcc_ctx_reserve_within(vpcc_ctx* ctx, uint64_t bytes, float budget_ms, vpcc_pool_info* out /* may be NULL */);
 int  vpcc_ctx_pool_info(vpcc_ctx* ctx, vpcc_pool_info* out);
+/* Device memory of the pool for a PRODUCER that leaves decoded planes in HBM — a GPU video decoder's frame pool, handed to
+ * vpcc_gof_create as VPCC_MEM_DEVICE planes.  Planes take part in a launch's traffic like the outputs do: ask for the
+ * frames' planes as the gof places its outputs — frames 0-7 of a launch from home 0, 8-15 from home 1, and so on (`home` =
+ * (frame / 8) % 2).  Without a pool (or when it is full) the memory is a plain allocation.  The pointer is 256-byte
+ * aligned and stays valid until vpcc_ctx_pool_free or the end of the context. */
+int  vpcc_ctx_pool_alloc(vpcc_ctx* ctx, int home, size_t bytes, void** out);
+int  vpcc_ctx_pool_free(vpcc_ctx* ctx, void* ptr);
+/* Pools of destroyed contexts stay with the process (see above) until a context of the device takes them over, an
+ * allocation of the library fails, or this is called: gives every kept pool of `device` back to the driver — for a
+ * process that goes on to use the GPU by other means.  Returns 1 if there was one, else 0. */
+int  vpcc_release_kept_pools(int device);
 
 /* Plane ingest (stand-in for LibavcodecDecoder::decode, src/decoder.rs:1089-1156, whose Vec<u8> planes
  * are the H2D source): page-locks a host range so that uploads from it are true asynchronous DMA.
@@ -238,7 +256,11 @@ int vpcc_reconstruct_frame(vpcc_ctx* ctx, const vpcc_frame_desc* frame, vpcc_mem
  * A vpcc_gof keeps n_frames frames resident in HBM and reconstructs them in
  * one batched launch sequence.  With VPCC_MEM_HOST the planes are copied to
  * HBM at creation; with VPCC_MEM_DEVICE they are borrowed and must outlive the
- * gof.  capacity_points is the per-frame output capacity (0 = the safe bound
+ * gof: nothing reads them before vpcc_gof_reconstruct, which reads them on ITS
+ * stream (a decoder that writes them on that stream needs no other ordering),
+ * and vpcc_gof_create returns without waiting for the device — the host writes
+ * O(patches) per frame, the per-block work is the launches'.
+ * capacity_points is the per-frame output capacity (0 = the safe bound
  * vpcc_frame_capacity_bound()).
  * Planes stay in the raster layout a video decoder hands over, whoever owns them: the reconstruction kernel
  * reads them where they lie, nothing is re-arranged in HBM.  Frames whose capacity exceeds 715 827 880 points
@@ -276,11 +298,12 @@ int vpcc_gof_sync(vpcc_gof* gof);
 /* Per-frame point counts of the last reconstruct (synchronises). */
 int vpcc_gof_point_counts(vpcc_gof* gof, uint32_t* counts_out /* n_frames */);
 
-/* block_to_patch of frame `frame` as the gof holds it (src/codec.rs:205-250: 0 = unowned, else patch index + 1;
- * (width / R) x (height / R) entries) and the number of work items the single-pass kernel has for the frame (0 for a gof
- * of the general sequence, whose block_to_patch is valid after a reconstruct).  For the single-pass kernel both are
- * built on the device when the gof is created (k_plan_cover / k_plan_items), from the occupancy plane where it lies.
- * Synchronises; either out-pointer may be NULL. */
+/* block_to_patch of frame `frame` as the last launch that covered the frame built it (src/codec.rs:205-250: 0 = unowned,
+ * else patch index + 1; (width / R) x (height / R) entries) and the number of work items the single-pass kernel had for the
+ * frame (0 for a gof of the general sequence).  Every vpcc_gof_reconstruct builds both on the device, on its stream, from
+ * the occupancy plane as it is then (k_plan_tiles) — a gof that borrows the caller's device planes may be launched again
+ * after new frames have been decoded into them.  VPCC_ERR_STATE before the first launch.  Synchronises; either out-pointer
+ * may be NULL. */
 int vpcc_gof_block_to_patch(vpcc_gof* gof, uint32_t frame, uint32_t* block_to_patch_out, uint32_t* work_items_out);
 
 /* Device pointers of frame `frame`'s outputs (vpcc_point3[capacity],

@@ -48,10 +48,13 @@ static int parse_and_walk(const std::vector<unsigned char>& buf, long* frames, l
           touch(d.attribute[m].v, vpcc::chroma_elems(d.attribute[m]) * 2);
         }
       }
-      if (vpcc::validate_frame(&d) == VPCC_OK) {
+      vpcc::FrameShape shape;
+      if (vpcc::validate_frame(&d, &shape) == VPCC_OK) {
         ++*valid;
-        vpcc::FramePlan plan;
-        vpcc::plan_frame(d, &plan);
+        std::vector<uint32_t> vb_base(shape.n_patches + 1);
+        std::vector<vpcc::TileItem> items(shape.n_patches);
+        std::vector<vpcc::DevPatch> patches(shape.n_patches);
+        vpcc::write_frame_records(d, vb_base.data(), shape.tile_eligible ? items.data() : nullptr, patches.data());
       }
     }
   return 0;

@@ -4,6 +4,7 @@
 #include <cstdint>
 #include <cstdio>
 #include <cstdlib>
+#include <algorithm>
 #include <vector>
 
 #include "vpcc_host.hpp"
@@ -16,7 +17,7 @@ int main(int argc, char** argv) {
   const long iterations = argc > 1 ? std::atol(argv[1]) : 1000;
   static uint8_t dummy8[16];
   static uint16_t dummy16[16];
-  long accepted = 0, rejected = 0, items = 0;
+  long accepted = 0, rejected = 0, items = 0, rotated = 0;
   for (long it = 0; it < iterations; ++it) {
     vpcc_frame_desc f{};
     const uint32_t R = 1u << (3 + below(3)), prec = 1u << below(3);
@@ -35,14 +36,20 @@ int main(int argc, char** argv) {
     }
     std::vector<vpcc_patch> patches(below(40));
     const uint32_t bw = f.width / R, bh = f.height / R;
-    const bool wild = below(4) == 0;
+    const bool fitting = below(2) == 0;
+    const bool wild = below(4) == 0, exotic = !wild && below(3) == 0;       // exotic: all nine orientations on patches that may fit
     for (vpcc_patch& p : patches) {
       p = vpcc_patch{};
-      p.orientation = (uint8_t)below(wild ? 12 : 2);
+      p.orientation = (uint8_t)below(wild ? 12 : exotic ? 9 : 2);
       p.size_u0 = 1 + below(wild ? 70000 : 6);
       p.size_v0 = 1 + below(wild ? 70000 : 6);
       p.u0 = below(wild ? 0xFFFFFFFFu : bw + 1);
       p.v0 = below(wild ? 0xFFFFFFFFu : bh + 1);
+      if (!wild && fitting) {                                         // a square patch somewhere inside the canvas: fits in every orientation
+        p.size_u0 = p.size_v0 = 1 + below(std::min(bw, bh) < 4 ? std::min(bw, bh) : 4);
+        p.u0 = below(bw - p.size_u0 + 1);
+        p.v0 = below(bh - p.size_v0 + 1);
+      }
       p.u1 = (uint32_t)rnd(); p.v1 = (uint32_t)rnd(); p.d1 = (uint32_t)rnd();
       p.lod_x = wild ? (uint32_t)rnd() : 1; p.lod_y = wild ? below(3) : 1;
       p.normal_axis = (uint8_t)below(wild ? 5 : 3); p.tangent_axis = (uint8_t)below(3); p.bitangent_axis = (uint8_t)below(3);
@@ -51,25 +58,209 @@ int main(int argc, char** argv) {
     }
     f.patches = patches.empty() ? nullptr : patches.data();
     f.patch_count = (uint32_t)patches.size();
-    if (vpcc::validate_frame(&f) != VPCC_OK) { ++rejected; continue; }
+    vpcc::FrameShape shape;
+    if (vpcc::validate_frame(&f, &shape) != VPCC_OK) { ++rejected; continue; }
     ++accepted;
-    vpcc::FramePlan plan;
-    vpcc::plan_frame(f, &plan);
+    for (const vpcc_patch& p : patches) rotated += p.orientation >= 2 && p.orientation != 8;
+    // The host writes O(patches): vb_base, one item template per patch, the affine patches.  The virtual blocks are DERIVED
+    // from them on the device (patch_of_vblock + vblock_of in k_plan_vblocks; the templates' origin and size_u0 in
+    // k_plan_tiles): both derivations, run here on the CPU, must give the reference's loop nest — patches ascending, v0
+    // outer, u0 inner, patch_block_to_canvas_block (src/codec.rs:352-385, src/decoder.rs:827-838).
+    std::vector<uint32_t> vb_base(patches.size() + 1);
+    std::vector<vpcc::TileItem> templates(patches.size());
+    std::vector<vpcc::DevPatch> dev(patches.size());
+    vpcc::write_frame_records(f, vb_base.data(), shape.tile_eligible ? templates.data() : nullptr, dev.data());
     uint64_t expect_vb = 0;
     for (const vpcc_patch& p : patches) expect_vb += (uint64_t)p.size_u0 * p.size_v0;
-    if (plan.vblocks.size() != expect_vb) { std::fprintf(stderr, "vblock count\n"); return 1; }
-    for (const vpcc::VBlock& b : plan.vblocks)
-      if (b.canvas_block >= (uint64_t)plan.bw * plan.bh) { std::fprintf(stderr, "canvas block out of range\n"); return 1; }
-    // the tile kernel's items are completed on the device (k_plan_items) from one template per patch and the virtual
-    // blocks checked above: the host's part is the templates and the bound that sizes the device arrays
-    if (plan.tile_eligible) {
-      if (plan.patch_items.size() != patches.size()) { std::fprintf(stderr, "item templates\n"); return 1; }
-      if (plan.tile_bound > plan.vblocks.size() || plan.tile_bound > (uint64_t)plan.bw * plan.bh) { std::fprintf(stderr, "tile bound\n"); return 1; }
-      for (const vpcc::VBlock& b : plan.vblocks)
-        if ((b.canvas_block % plan.bw) * 16u + 16u > f.width || (b.canvas_block / plan.bw) * 16u + 16u > f.height) { std::fprintf(stderr, "tile outside the canvas\n"); return 1; }
-      items += plan.tile_bound;
+    if (shape.n_vblocks != expect_vb || vb_base.back() != expect_vb || shape.n_patches != patches.size() || shape.bw != bw || shape.bh != bh) { std::fprintf(stderr, "shape\n"); return 1; }
+    uint32_t vb = 0;
+    for (uint32_t i = 0; i < patches.size(); ++i) {
+      const vpcc_patch& p = patches[i];
+      if (vb_base[i] != vb) { std::fprintf(stderr, "vb_base\n"); return 1; }
+      const vpcc::Affine bl = vpcc::patch_affine(p, 1);
+      for (uint32_t v0 = 0; v0 < p.size_v0; ++v0)
+        for (uint32_t u0 = 0; u0 < p.size_u0; ++u0, ++vb) {
+          const int64_t bx = bl.ax_u * u0 + bl.ax_v * v0 + bl.cx, by = bl.ay_u * u0 + bl.ay_v * v0 + bl.cy;
+          const uint64_t cb = (uint64_t)(by * bw + bx);
+          if (cb >= (uint64_t)bw * bh) { std::fprintf(stderr, "canvas block out of range\n"); return 1; }
+          const uint32_t q = vpcc::patch_of_vblock(vb_base.data(), (uint32_t)patches.size(), vb);
+          const vpcc::VBlock b = vpcc::vblock_of(dev[q], q, vb, bw);
+          if (q != i || b.patch != i || b.u0 != u0 || b.v0 != v0 || b.canvas_block != cb) { std::fprintf(stderr, "derived virtual block %u: patch %u (%u) block (%u, %u) canvas block %u (%llu)\n", vb, q, i, b.u0, b.v0, b.canvas_block, (unsigned long long)cb); return 1; }
+          if (shape.tile_eligible) {                     // k_plan_tiles' route: the template's origin, size_u0 and Swap flag
+            const vpcc::TileItem& t = templates[q];
+            const uint32_t r = vb - vb_base[q], tv0 = r / t.patch, tu0 = r - tv0 * t.patch;
+            const bool swap = (t.flags & vpcc::kTileSwap) != 0;
+            const uint32_t tx = t.x0 + (swap ? tv0 : tu0), ty = t.y0 + (swap ? tu0 : tv0);
+            if (tu0 != u0 || tv0 != v0 || (uint64_t)ty * bw + tx != cb) { std::fprintf(stderr, "template route\n"); return 1; }
+            if (tx * 16u + 16u > f.width || ty * 16u + 16u > f.height) { std::fprintf(stderr, "tile outside the canvas\n"); return 1; }
+          }
+        }
     }
+    if (shape.tile_eligible) {
+      if (shape.tile_bound > expect_vb || shape.tile_bound > (uint64_t)bw * bh) { std::fprintf(stderr, "tile bound\n"); return 1; }
+      items += shape.tile_bound;
+    } else if (shape.tile_bound) { std::fprintf(stderr, "tile bound of an ineligible frame\n"); return 1; }
   }
+  // The memory of a gof (place_planes / classify_extents / layout_gof): random batches of frames whose planes lie in random
+  // arrangements — one container, scattered, partly outside page-locked memory.  Nothing overlaps: the regions of the arena,
+  // the arrays of an output block, the planes of a planes block; every plane keeps the alignment the ingest gives it; what
+  // the host writes lies in front of host_end; a stretch's device copy is congruent to its source modulo 256.
+  long layouts = 0, by_extent = 0;
+  for (long it = 0; it < iterations / 4 + 4; ++it) {
+    const uint32_t n = 1 + below(below(6) == 0 ? 40 : 6);
+    std::vector<vpcc_frame_desc> fr(n);
+    std::vector<vpcc::FrameShape> sh(n);
+    std::vector<std::vector<vpcc_patch>> pt(n);
+    // a fake "host memory": addresses only
+    const uintptr_t host0 = 0x100000000ull + 8 * below(64);
+    uintptr_t at = host0;
+    const bool container = below(2) == 0, attr = below(3) != 0;
+    const uint32_t prec = 1u << below(3);
+    auto put = [&](size_t bytes) { const uintptr_t p = at; at += bytes + (container ? below(4) * 8 : (size_t)below(1u << 20) * 8 + (below(4) == 0 ? (1u << 20) : 0)); return p; };
+    for (uint32_t i = 0; i < n; ++i) {
+      vpcc_frame_desc& f = fr[i];
+      f = vpcc_frame_desc{};
+      f.occupancy_resolution = 16; f.occupancy_precision = prec;
+      f.width = 16 * (1 + below(12)); f.height = 16 * (1 + below(12));
+      f.map_count = 1 + below(2); f.absolute_d1 = 1; f.attribute_count = attr ? 1 : 0;
+      const bool padded = below(10) == 0;
+      f.occupancy = vpcc_image_u8{(const uint8_t*)put((size_t)(f.width / prec) * (f.height / prec)), f.width / prec, f.height / prec, f.width / prec};
+      for (uint32_t m = 0; m < f.map_count; ++m) {
+        f.geometry[m] = vpcc_image_u16{(const uint16_t*)put((size_t)f.width * f.height * 2), nullptr, nullptr, f.width, f.height, f.width + (padded ? 8 : 0), f.width / 2};
+        if (attr) {
+          f.attribute[m] = vpcc_image_u16{(const uint16_t*)put((size_t)f.width * f.height * 2), nullptr, nullptr, f.width, f.height, f.width, f.width / 2};
+          f.attribute[m].u = (const uint16_t*)put(vpcc::chroma_elems(f.attribute[m]) * 2);
+          f.attribute[m].v = (const uint16_t*)put(vpcc::chroma_elems(f.attribute[m]) * 2);
+        }
+      }
+      pt[i].resize(below(6));
+      for (vpcc_patch& p : pt[i]) { p = vpcc_patch{}; p.size_u0 = 1 + below(f.width / 16); p.size_v0 = 1 + below(f.height / 16); p.u0 = below(f.width / 16 - p.size_u0 + 1); p.v0 = below(f.height / 16 - p.size_v0 + 1); p.lod_x = p.lod_y = 1; p.tangent_axis = 1; p.bitangent_axis = 2; }
+      f.patches = pt[i].empty() ? nullptr : pt[i].data();
+      f.patch_count = (uint32_t)pt[i].size();
+      if (vpcc::validate_frame(&f, &sh[i]) != VPCC_OK) { std::fprintf(stderr, "layout: frame rejected\n"); return 1; }
+    }
+    // page-locked regions: all of the "memory", or with a hole, or in two chunks that meet somewhere
+    const uintptr_t end = at + 4096;
+    std::vector<std::pair<uintptr_t, uintptr_t>> regions;
+    const uint32_t mode = below(4);
+    if (mode == 0) regions.push_back({host0 - 64, end});
+    else if (mode == 1) { const uintptr_t mid = host0 + below((uint32_t)std::min<uintptr_t>(end - host0, 0x7FFFFFFF)); regions.push_back({host0 - 64, mid}); regions.push_back({mid, end}); }
+    else if (mode == 2) { const uintptr_t mid = host0 + below((uint32_t)std::min<uintptr_t>(end - host0, 0x7FFFFFFF)); regions.push_back({host0 - 64, mid}); regions.push_back({mid + 4096, end}); }
+    vpcc::PinnedQuery pinned = [&](const char* lo, size_t bytes, std::vector<std::pair<const char*, size_t>>* pieces) {
+      pieces->clear();
+      uintptr_t cur = (uintptr_t)lo;
+      const uintptr_t hi = cur + bytes;
+      while (cur < hi) {
+        const std::pair<uintptr_t, uintptr_t>* in = nullptr;
+        for (const auto& r : regions) if (cur >= r.first && cur < r.second) { in = &r; break; }
+        if (!in) { pieces->clear(); return false; }
+        const uintptr_t e = std::min(hi, in->second);
+        pieces->emplace_back((const char*)cur, (size_t)(e - cur));
+        cur = e;
+      }
+      return true;
+    };
+    vpcc::GofLayout L;
+    L.f.assign(n, vpcc::FrameOffsets{});
+    std::vector<vpcc::IngestExtent> extents;
+    const bool own = below(5) != 0, pull = below(2) == 0;
+    bool ext = false;
+    vpcc::GofLayoutRequest rq{};
+    rq.frames = fr.data(); rq.shapes = sh.data(); rq.n_frames = n; rq.capacity = 1 + below(5000);
+    rq.want_patch_index = below(2) == 0; rq.tile_records = below(4) != 0; rq.general_records = !rq.tile_records || below(3) == 0;
+    rq.pull_ingest = own && pull;
+    if (own) {
+      ext = vpcc::classify_extents(fr.data(), n, pinned, &L, &extents);
+      if (!ext) {
+        for (const vpcc::FrameOffsets& o : L.f) if (o.planes.occ || o.planes.geo[0]) { std::fprintf(stderr, "layout: a refused classification left slots behind\n"); return 1; }
+        for (int j = 0; j < 2 * vpcc::kGofParts; ++j) if (L.block[j].total) { std::fprintf(stderr, "layout: a refused classification left block space behind\n"); return 1; }
+        vpcc::place_planes(rq, &L);
+      }
+    }
+    by_extent += ext;
+    vpcc::layout_gof(rq, &L);
+    ++layouts;
+    struct Span { size_t lo, hi; const char* what; };
+    auto disjoint = [](std::vector<Span>& v, size_t limit) -> const char* {
+      std::sort(v.begin(), v.end(), [](const Span& a, const Span& b) { return a.lo < b.lo; });
+      for (size_t k = 0; k < v.size(); ++k) {
+        if (v[k].hi > limit) return v[k].what;
+        if (k && v[k].lo < v[k - 1].hi) return v[k].what;
+      }
+      return nullptr;
+    };
+    std::vector<Span> arena, blocks[2 * vpcc::kGofParts];
+    arena.push_back({L.frames, L.frames + sizeof(vpcc::DevFrame) * n, "frames"});
+    arena.push_back({L.counts, L.counts + 4 * (size_t)n, "counts"});
+    arena.push_back({L.ctrl_begin, L.ctrl_begin + L.ctrl_bytes, "control words"});
+    if (L.tickets != L.ctrl_begin || L.errors < L.tickets + 256 * (size_t)n || L.scan < L.errors + 4 * (size_t)n || (L.scan & 7)) { std::fprintf(stderr, "layout: control words\n"); return 1; }
+    arena.push_back({L.b2p_begin, L.b2p_begin + 4 * L.b2p_words, "block_to_patch"});
+    if (rq.pull_ingest) arena.push_back({L.ingest_pieces, L.ingest_pieces + sizeof(vpcc::IngestPiece) * std::max<size_t>(L.ingest_bound, 1), "ingest pieces"});
+    size_t b2p_at = L.b2p_begin;
+    for (uint32_t i = 0; i < n; ++i) {
+      const vpcc::FrameOffsets& o = L.f[i];
+      const size_t P = sh[i].n_patches, vbn = std::max<size_t>(sh[i].n_vblocks, 1);
+      arena.push_back({o.vb_base, o.vb_base + 4 * (P + 1), "vb_base"});
+      if (o.vb_base + 4 * (P + 1) > L.host_end) { std::fprintf(stderr, "layout: vb_base behind host_end\n"); return 1; }
+      if (rq.tile_records) {
+        arena.push_back({o.patch_items, o.patch_items + 32 * std::max<size_t>(P, 1), "item templates"});
+        if (o.patch_items + 32 * P > L.host_end) { std::fprintf(stderr, "layout: templates behind host_end\n"); return 1; }
+        arena.push_back({o.items, o.items + 32 * ((size_t)sh[i].tile_bound + 16), "items"});
+      }
+      if (rq.general_records) {
+        arena.push_back({o.patches, o.patches + 64 * std::max<size_t>(P, 1), "patches"});
+        if (o.patches + 64 * P > L.host_end) { std::fprintf(stderr, "layout: patches behind host_end\n"); return 1; }
+        arena.push_back({o.vblocks, o.vblocks + 16 * vbn, "vblocks"});
+        arena.push_back({o.vb_count, o.vb_count + 4 * vbn, "vb_count"});
+        arena.push_back({o.vb_offset, o.vb_offset + 4 * vbn, "vb_offset"});
+      }
+      if (o.b2p != b2p_at) { std::fprintf(stderr, "layout: block_to_patch not contiguous\n"); return 1; }
+      b2p_at += 4 * (size_t)sh[i].bw * sh[i].bh;
+      const int part = vpcc::gof_part_of(i);
+      const size_t cap = (size_t)rq.capacity;
+      blocks[2 * part + 1].push_back({o.xyz, o.xyz + 6 * (cap + 4), "positions"});
+      if (fr[i].attribute_count) blocks[2 * part + 1].push_back({o.rgb, o.rgb + 3 * (cap + 4), "colours"});
+      if (rq.want_patch_index) blocks[2 * part + 1].push_back({o.pidx, o.pidx + 2 * (cap + 4), "partition"});
+      if ((o.xyz | o.rgb | o.pidx) & 255) { std::fprintf(stderr, "layout: output alignment\n"); return 1; }
+      if (own) {
+        const vpcc_frame_desc& F = fr[i];
+        auto plane = [&](size_t slot, const void* src, size_t bytes) -> bool {
+          blocks[2 * part + 0].push_back({slot, slot + bytes, "plane"});
+          if (ext) return ((slot ^ (uintptr_t)src) & 255u) == 0;                                  // keeps its alignment
+          return (slot & 255u) == (rq.pull_ingest && ((uintptr_t)src & 7u) == 0 ? ((uintptr_t)src & 15u) : 0u) ||
+                 (slot & 255u) == 0;                                                              // (a padded plane is copied row by row: no shift)
+        };
+        bool good = plane(o.planes.occ, F.occupancy.y, (size_t)F.occupancy.width * F.occupancy.height);
+        for (uint32_t m = 0; m < F.map_count; ++m) {
+          good = good && plane(o.planes.geo[m], F.geometry[m].y, (size_t)F.geometry[m].width * F.geometry[m].height * 2);
+          if (F.attribute_count) {
+            good = good && plane(o.planes.ay[m], F.attribute[m].y, (size_t)F.attribute[m].width * F.attribute[m].height * 2);
+            good = good && plane(o.planes.au[m], F.attribute[m].u, vpcc::chroma_elems(F.attribute[m]) * 2);
+            good = good && plane(o.planes.av[m], F.attribute[m].v, vpcc::chroma_elems(F.attribute[m]) * 2);
+          }
+        }
+        if (!good) { std::fprintf(stderr, "layout: a plane lost its alignment (%s)\n", ext ? "by extent" : "placed"); return 1; }
+      }
+    }
+    if (b2p_at != L.b2p_begin + 4 * L.b2p_words) { std::fprintf(stderr, "layout: block_to_patch size\n"); return 1; }
+    if (const char* w = disjoint(arena, L.arena_bytes)) { std::fprintf(stderr, "layout: arena region '%s' overlaps or leaves the arena\n", w); return 1; }
+    for (int j = 0; j < 2 * vpcc::kGofParts; ++j) {
+      if (ext && !(j & 1)) {
+        // planes of one stretch may share bytes only if the caller's planes did: compare against the host arrangement instead
+        for (const vpcc::IngestExtent& e : extents) {
+          if (((e.dev ^ (uintptr_t)e.lo) & 255u) != 0 || e.dev + e.bytes > L.block[2 * e.part].total) { std::fprintf(stderr, "layout: stretch\n"); return 1; }
+          size_t sum = 0;
+          for (const auto& pc : e.pieces) sum += pc.second;
+          if (sum != e.bytes || e.pieces.empty() || e.pieces.front().first != e.lo) { std::fprintf(stderr, "layout: stretch pieces\n"); return 1; }
+        }
+        for (const Span& sp : blocks[j]) if (sp.hi > L.block[j].total) { std::fprintf(stderr, "layout: plane outside its block\n"); return 1; }
+        continue;
+      }
+      if (const char* w = disjoint(blocks[j], L.block[j].total)) { std::fprintf(stderr, "layout: '%s' overlaps or leaves block %d\n", w, j); return 1; }
+    }
+    if (L.stage_counts < L.host_end || L.stage_bytes < L.stage_counts + 8 * (size_t)n) { std::fprintf(stderr, "layout: staging\n"); return 1; }
+  }
+  std::printf("layouts %ld, by extent %ld\n", layouts, by_extent);
   // Shares of the resident workgroups per frame (plan_tile_launch): every frame with tiles gets at least one
   // workgroup, the table's per-slot share equals the number of slots the frame really has (the kernel re-arms a
   // frame's ticket counter after exactly that many workgroups have left it), no slot names a frame outside the launch.
@@ -151,6 +342,6 @@ int main(int argc, char** argv) {
     if (extents != E.runs.size() || E.in_use[0] || E.in_use[1]) { std::fprintf(stderr, "pool: not whole again (%zu extents, %zu runs)\n", extents, E.runs.size()); return 1; }
   }
   std::printf("launch maps %ld, equal split %ld, pool operations %ld\n", maps, equal_split, pool_ops);
-  std::printf("iterations %ld accepted %ld rejected %ld tile items %ld\n", iterations, accepted, rejected, items);
+  std::printf("iterations %ld accepted %ld rejected %ld tile items %ld rotated or mirrored patches %ld\n", iterations, accepted, rejected, items, rotated);
   return accepted > 0 && rejected > 0 ? 0 : 1;
 }

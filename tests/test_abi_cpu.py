@@ -26,7 +26,7 @@ def test_library_exports_every_declared_symbol():
     assert len(names) >= 20
     for n in names:
         assert hasattr(lib, n), f"{n} declared in include/vpcc_recon.h but not exported"
-    assert lib.vpcc_abi_version() == 4
+    assert lib.vpcc_abi_version() == 5
 
 
 def test_struct_layout_matches_header():

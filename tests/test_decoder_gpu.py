@@ -78,7 +78,10 @@ def test_decoder_applies_the_smoothing_filters(tmp_path):
     def run(geometry, color):
         d = recon.Decoder(paths["bin"], **kw)
         if geometry or color:
-            d.set_smoothing(geometry=geometry, color=color, color_grid_size=8, color_threshold_smoothing=10, color_threshold_difference=100)
+            # (grid_size / threshold are for inputs WITHOUT syntax: a V3C GOF that carries no SEI — the second one — must stay
+            # unfiltered although they are given)
+            d.set_smoothing(geometry=geometry, color=color, grid_size=6, threshold=3, color_grid_size=8, color_threshold_smoothing=10,
+                            color_threshold_difference=100)
         d.start()
         frames = list(d)
         assert d.error() == "" and len(frames) == len(expected)

@@ -154,3 +154,30 @@ def test_timed_region_single_rank():
                                 points_per_step=42)
     assert reg["steps_effective"] == 5 and len(n) == 6 and reg["points_total_per_step"] == 42 and reg["world"] == 1
     assert reg["elapsed_s"] >= 0.005
+
+
+def test_bench_starts_its_own_ranks():
+    """`python bench.py --gpus 2 ...` outside any launcher (the shape of the driver's 1-GPU command at N = 2): bench.py starts
+    its ranks itself — torch.distributed.run as a CHILD process, before torch or the GPU are touched — and passes rank 0's
+    ONE JSON line and the exit status through.  --dry-run: process group (gloo), the timed region's barriers, K agreed by
+    all ranks, MAX of the time, SUM of the points, MIN of the verification flag, with a step that only sleeps."""
+    import json
+    import subprocess
+    import sys
+    repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env["VPCC_BENCH_BACKEND"] = "gloo"
+    out = subprocess.run([sys.executable, os.path.join(repo, "bench.py"), "--gpus", "2", "--steps", "4", "--warmup", "2", "--dry-run"],
+                         capture_output=True, text=True, timeout=300, env=env)
+    assert out.returncode == 0, out.stdout + out.stderr
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, out.stdout
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["dry_run"] and d["verified"] and d["steps"] == 4 and d["warmup"] == 2
+    assert d["points_total_per_step"] == 3000                       # SUM over the two ranks (1000 + 2000)
+    assert d["ms_per_step"] >= 2.0                                   # MAX over ranks: rank 1 sleeps 2 ms per step
+    # a rank count that does not match the launcher's is refused, not silently run
+    env2 = dict(env, WORLD_SIZE="3", RANK="0")
+    out = subprocess.run([sys.executable, os.path.join(repo, "bench.py"), "--gpus", "2", "--dry-run"], capture_output=True, text=True,
+                         timeout=120, env=env2)
+    assert out.returncode == 2

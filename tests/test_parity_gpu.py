@@ -4,6 +4,8 @@ same seeded inputs.  Bar: bit-exact for xyz, occupancy, block->patch, patch inde
 contraction so exact equality is asserted)."""
 import ctypes as C
 
+import os
+
 import numpy as np
 import pytest
 
@@ -210,7 +212,7 @@ def test_gof_of_very_unequal_frames_on_the_tile_path(ctx):
     g = ctx.gof(frames, flags=_abi.VPCC_GOF_PROFILE | _abi.VPCC_GOF_WANT_PATCH_INDEX)
     for first, count in [(0, None), (0, None), (3, 10), (0, 1), (23, 1), (5, 19), (0, None)]:
         g.reconstruct(first=first, count=count)
-        assert [k for k, _ in g.kernel_times()] == ["k_recon_tiles"]
+        assert [k for k, _ in g.kernel_times()] == ["k_plan_tiles", "k_recon_tiles"]
         counts = g.point_counts()
         for i in range(first, len(frames) if count is None else first + count):
             assert counts[i] == refs[i]["n"], (first, count, i)
@@ -236,7 +238,7 @@ def test_large_launch_runs_in_rounds(ctx):
     g = ctx.gof(frames, flags=_abi.VPCC_GOF_PROFILE | _abi.VPCC_GOF_WANT_PATCH_INDEX)
     for first, count in [(0, None), (0, None), (7, 137), (0, None)]:
         g.reconstruct(first=first, count=count)
-        assert [k for k, _ in g.kernel_times()] == ["k_recon_tiles"]
+        assert [k for k, _ in g.kernel_times()] == ["k_plan_tiles", "k_recon_tiles"]
         counts = g.point_counts()
         for i in range(first, len(frames) if count is None else first + count):
             assert counts[i] == refs[i]["n"], (first, count, i)
@@ -257,7 +259,7 @@ def test_launch_shapes(ctx, n_frames):
         ranges += [(n_frames // 3, n_frames - n_frames // 3 - 1), (0, n_frames)]
     for first, count in ranges:
         g.reconstruct(first=first, count=count)
-        assert [k for k, _ in g.kernel_times()] == ["k_recon_tiles"]
+        assert [k for k, _ in g.kernel_times()] == ["k_plan_tiles", "k_recon_tiles"]
         counts = g.point_counts()
         for i in range(first, first + count):
             assert counts[i] == refs_pool[pick[i]]["n"], (n_frames, first, count, i)
@@ -351,23 +353,35 @@ def test_device_outputs_stay_valid(ctx):
 
 
 def test_work_lists_are_planned_on_the_device(ctx):
-    """generate_block_to_patch_from_occupancy_map_video (src/codec.rs:205-250) on the production path: the gof's
-    block_to_patch and the single-pass kernel's work list are built by k_plan_cover / k_plan_items when the gof is created,
-    from the occupancy plane where it lies — host planes and the caller's device planes alike.  Against the oracle's
-    block_to_patch; the work list holds exactly the owned blocks."""
+    """generate_block_to_patch_from_occupancy_map_video (src/codec.rs:205-250) on the production path: block_to_patch and the
+    single-pass kernel's work list are built by EVERY launch (k_plan_tiles: a workgroup per frame, block_to_patch and the patch
+    table in LDS; the host writes O(patches) per frame, the virtual blocks are derived on the device), from the occupancy
+    plane where it lies — host planes and the caller's device planes alike.  Against the oracle's block_to_patch; the work
+    list holds exactly the owned blocks.  The same through the planning kernels that work in global memory (frames beyond
+    k_plan_tiles' LDS take them: VPCC_NO_LDS_PLANNING=1 sends every frame there)."""
     import torch
     frames = [synth.longdress_frame(3), cases.medium_frame(5, occupancy_values="random"), cases.precision_frame(2, 9),
-              cases.precision_frame(16, 4), synth.small_frame(1)]
+              cases.precision_frame(16, 4), cases.precision_frame(1, 2), cases.precision_frame(8, 6), synth.small_frame(1)]
     refs = [ob.reconstruct(f)[1] for f in frames]
-    for f, ref in zip(frames, refs):
-        g = ctx.gof([f])
-        nb = (f["width"] // 16) * (f["height"] // 16)
-        b2p, items = g.block_to_patch(0, nb)                          # before any launch
-        assert np.array_equal(b2p.astype(np.uint64), ref["block_to_patch"].astype(np.uint64))
-        assert items == int(np.count_nonzero(ref["block_to_patch"])) > 0
-        g.reconstruct()
-        _check(g.download(0), ref)
-        g.close()
+    for env in (None, "1"):
+        if env:
+            os.environ["VPCC_NO_LDS_PLANNING"] = env
+        try:
+            for f, ref in zip(frames, refs):
+                g = ctx.gof([f], flags=_abi.VPCC_GOF_PROFILE)
+                nb = (f["width"] // 16) * (f["height"] // 16)
+                with pytest.raises(recon.VpccError) as e:               # nothing is planned before a launch
+                    g.block_to_patch(0, nb)
+                assert e.value.status == _abi.VPCC_ERR_STATE
+                g.reconstruct()
+                assert [k for k, _ in g.kernel_times()] == (["k_plan_cover+items", "k_recon_tiles"] if env else ["k_plan_tiles", "k_recon_tiles"])
+                b2p, items = g.block_to_patch(0, nb)
+                assert np.array_equal(b2p.astype(np.uint64), ref["block_to_patch"].astype(np.uint64))
+                assert items == int(np.count_nonzero(ref["block_to_patch"])) > 0
+                _check(g.download(0), ref)
+                g.close()
+        finally:
+            os.environ.pop("VPCC_NO_LDS_PLANNING", None)
     # the caller's device planes: the same list (round 3 kept every covered block there: the host could not see the occupancy)
     f, ref = frames[0], refs[0]
     dev = torch.device("cuda:0")
@@ -385,11 +399,64 @@ def test_work_lists_are_planned_on_the_device(ctx):
         d.attribute[m].y, d.attribute[m].u, d.attribute[m].v = (up(p) for p in f["attribute"][m])
     torch.cuda.synchronize()
     g = ctx.gof(None, capacity=1_000_000, memory=_abi.VPCC_MEM_DEVICE, descs=[d])
+    g.reconstruct()
     b2p, items = g.block_to_patch(0, (f["width"] // 16) * (f["height"] // 16))
     assert np.array_equal(b2p.astype(np.uint64), ref["block_to_patch"].astype(np.uint64))
     assert items == int(np.count_nonzero(ref["block_to_patch"]))
-    g.reconstruct()
     _check(g.download(0), ref)
+    g.close()
+
+
+def test_borrowed_planes_may_change_between_launches(ctx):
+    """A gof that borrows the caller's device planes (VPCC_MEM_DEVICE) reads them at vpcc_gof_reconstruct, on the launch's
+    stream, and nowhere else: block_to_patch and the work lists are planned by every launch from the occupancy as it is
+    THEN.  A decoder's frame pool is refilled between two launches of the same gof — on the launch stream, without any
+    synchronisation with the host in between — with a frame whose occupancy covers blocks the first one left empty
+    (round 4 planned once, when the gof was created: the second launch would have dropped those blocks' points)."""
+    import torch
+    a, b = synth.longdress_frame(1), synth.longdress_frame(2)
+    refs = [ob.reconstruct(f)[1] for f in (a, b)]
+    assert not np.array_equal(refs[0]["block_to_patch"] != 0, refs[1]["block_to_patch"] != 0)
+    dev = torch.device("cuda:0")
+    d, keep = _abi.host_frame_desc(a)
+    slots, staged = [], {0: [], 1: []}
+
+    def plane(k, arr_a, arr_b):
+        ta = torch.from_numpy(np.ascontiguousarray(arr_a).view(np.uint8).reshape(-1)).to(dev)
+        tb = torch.from_numpy(np.ascontiguousarray(arr_b).view(np.uint8).reshape(-1)).to(dev)
+        slots.append(torch.empty_like(ta))
+        staged[0].append(ta)
+        staged[1].append(tb)
+        return slots[-1].data_ptr()
+
+    d.occupancy.y = plane(0, a["occupancy"], b["occupancy"])
+    d.occupancy.stride = d.occupancy.width
+    for m in range(2):
+        d.geometry[m].y = plane(0, a["geometry"][m], b["geometry"][m])
+        d.attribute[m].y, d.attribute[m].u, d.attribute[m].v = (plane(0, pa, pb) for pa, pb in zip(a["attribute"][m], b["attribute"][m]))
+    stream = torch.cuda.Stream(device=dev)
+    torch.cuda.synchronize()
+    # the patch table is the gof's (host side, read at creation): both frames are reconstructed with frame a's patches, so the
+    # reference for the second launch is the oracle on "a's patch table over b's planes"
+    mixed = dict(a)
+    mixed["occupancy"], mixed["geometry"], mixed["attribute"] = b["occupancy"], b["geometry"], b["attribute"]
+    ref_mixed = ob.reconstruct(mixed)[1]
+    g = ctx.gof(None, capacity=1_200_000, memory=_abi.VPCC_MEM_DEVICE, descs=[d])     # created BEFORE the planes hold anything
+    with torch.cuda.stream(stream):
+        for s_, t_ in zip(slots, staged[0]):
+            s_.copy_(t_, non_blocking=True)
+        g.reconstruct(stream=stream.cuda_stream)
+        first = None
+    first = g.download(0)
+    _check(first, refs[0])
+    with torch.cuda.stream(stream):
+        for s_, t_ in zip(slots, staged[1]):
+            s_.copy_(t_, non_blocking=True)
+        g.reconstruct(stream=stream.cuda_stream)
+    _check(g.download(0), ref_mixed)
+    b2p, items = g.block_to_patch(0, (a["width"] // 16) * (a["height"] // 16))
+    assert np.array_equal(b2p.astype(np.uint64), ref_mixed["block_to_patch"].astype(np.uint64))
+    assert items == int(np.count_nonzero(ref_mixed["block_to_patch"]))
     g.close()
 
 
@@ -485,7 +552,7 @@ def test_random_sweep_against_oracle(ctx):
     frames = cases.random_sweep_frames()
     g = ctx.gof(frames, flags=_abi.VPCC_GOF_PROFILE | _abi.VPCC_GOF_WANT_PATCH_INDEX)
     g.reconstruct()
-    assert [k for k, _ in g.kernel_times()] == ["k_recon_tiles"]
+    assert [k for k, _ in g.kernel_times()] == ["k_plan_tiles", "k_recon_tiles"]
     counts = g.point_counts()
     total = 0
     for i, f in enumerate(frames):

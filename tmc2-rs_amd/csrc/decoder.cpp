@@ -248,33 +248,39 @@ void Decoder::worker() {
   for (size_t d = 0; d < G; ++d)
     if (lanes[d]->post([](vpcc_ctx* c) { return c ? 0 : 1; }).get()) { fail("vpcc_ctx_create failed: no usable gfx950 device (no CPU fallback)"); return; }
   step("contexts ready");
-  // Two homes (vpcc_ctx_reserve): every lane's context gets its pool — on a thread of its own while this thread
-  // page-locks the input (16-300 ms of host work; the allocation and its classification take 30-50 ms of an otherwise
-  // idle GPU: timed beside uploads and kernels the classification goes wrong), joined before the first unit is launched.
-  // Every gof then keeps its planes and outputs in it, spread over both kinds of VRAM regions.  Streams of a single
-  // GOF do not bother; VPCC_DECODER_POOL_GIB=0 switches it off.
+  // Two homes (vpcc_ctx_reserve): OFF by default here.  A lane's kernels are under 1 % of its wall time (the link sets the
+  // pace: 44 ms of planes per 128-frame unit against 0.5 ms of kernels), the pool makes them a tenth faster — and costs
+  // 30-50 ms on a GPU whose memory is clean, 0.2 s at the median of 321 recorded reservations on this pool of machines and
+  // up to 4.4 s right after another process has freed tens of GB (profiles/r04/pool.txt): round 4 joined the reservation in
+  // front of the first launch and a cold Decoder's first frame waited for it.  VPCC_DECODER_POOL_GIB=<n> asks for it: it is
+  // then reserved on a thread of its own ONCE THE STREAM IS UNDER WAY (three units launched, the allocations of a steady
+  // state made) and only for streams with at least eight units still to come; nothing ever waits for it — gofs created
+  // meanwhile allocate as without it — and the search for a second home ends after 100 ms.  The pool is for callers whose
+  // planes are in HBM already (bench.py's headline and `fresh_gof` leg: thousands of launches per second).
   struct Reservers {
     std::vector<std::thread> t;
     ~Reservers() { for (auto& x : t) if (x.joinable()) x.join(); }      // before the lanes (and their contexts) go
   } reservers;
+  uint64_t pool_gib = 0;
   {
     const char* e = std::getenv("VPCC_DECODER_POOL_GIB");
-    const uint64_t gib = e ? (uint64_t)std::strtoull(e, nullptr, 10) : 32u;
-    const bool tr = std::getenv("VPCC_DECODER_TRACE") != nullptr;
-    if (gib >= 2 && gofs_.size() > 1)
-      for (size_t d = 0; d < G; ++d) {
-        vpcc_ctx* c = nullptr;
-        lanes[d]->post([&c](vpcc_ctx* x) { c = x; return 0; }).get();
-        reservers.t.emplace_back([c, gib, tr] {
-          vpcc_pool_info pi{};
-          const int st = vpcc_ctx_reserve(c, gib << 30, &pi);        // no memory for it: the gofs allocate as before
-          if (tr)
-            std::fprintf(stderr, "[vpcc decoder] pool of %llu GiB: %s, %u kind(s), %llu + %llu GiB, %.1f ms\n", (unsigned long long)gib,
-                         st ? vpcc_status_string(st) : "reserved", pi.kinds, (unsigned long long)(pi.bytes_of_kind[0] >> 30),
-                         (unsigned long long)(pi.bytes_of_kind[1] >> 30), pi.ms_spent);
-        });
-      }
+    pool_gib = e ? (uint64_t)std::strtoull(e, nullptr, 10) : 0u;
   }
+  auto reserve_pools = [&] {
+    const bool tr = std::getenv("VPCC_DECODER_TRACE") != nullptr;
+    for (size_t d = 0; d < G; ++d) {
+      vpcc_ctx* c = nullptr;
+      lanes[d]->post([&c](vpcc_ctx* x) { c = x; return 0; }).get();
+      reservers.t.emplace_back([c, pool_gib, tr] {
+        vpcc_pool_info pi{};
+        const int st = vpcc_ctx_reserve_within(c, pool_gib << 30, 100.f, &pi);     // no memory for it: the gofs allocate as before
+        if (tr)
+          std::fprintf(stderr, "[vpcc decoder] pool of %llu GiB: %s, %u kind(s), %llu + %llu GiB, %.1f ms\n", (unsigned long long)pool_gib,
+                       st ? vpcc_status_string(st) : "reserved", pi.kinds, (unsigned long long)(pi.bytes_of_kind[0] >> 30),
+                       (unsigned long long)(pi.bytes_of_kind[1] >> 30), pi.ms_spent);
+      });
+    }
+  };
   stats_.lanes = (uint32_t)G;
   for (size_t d = 0; d < G && d < 8; ++d) stats_.numa_node[d] = lanes[d]->numa_node();
 
@@ -311,8 +317,6 @@ void Decoder::worker() {
     pinned = lanes[0]->post([&](vpcc_ctx*) { return pins.lock(file_.data(), file_.size(), chunk) ? 0 : 1; }).get() == 0;
   }
   step("input page-locked");
-  for (auto& x : reservers.t) if (x.joinable()) x.join();
-  step("pools reserved");
   struct Part {                                       // one device's share of one unit
     std::vector<vpcc_frame_desc> frames;
     vpcc_gof* g = nullptr;
@@ -331,7 +335,9 @@ void Decoder::worker() {
     vpcc_smoothing_params sp{};
     const bool has_attr = !g.frames.empty() && g.frames[0].attribute_count > 0;
     if (params_.apply_geo_smoothing_type) {
-      const vpcc_smoothing_params& src = g.sei_smoothing.flags ? g.sei_smoothing : params_.geo_smoothing_without_sei;
+      // (a GOF of a V3C stream without the SEI is left alone whatever Params holds: the reference smooths `if the SEI is present`)
+      static const vpcc_smoothing_params none{};
+      const vpcc_smoothing_params& src = g.sei_smoothing.flags ? g.sei_smoothing : g.has_syntax ? none : params_.geo_smoothing_without_sei;
       if (src.grid_size >= 2) {
         sp.flags |= VPCC_SMOOTH_GEOMETRY;
         sp.geometry_bitdepth_3d = src.geometry_bitdepth_3d;
@@ -468,6 +474,7 @@ void Decoder::worker() {
     }
   };
   for (size_t k = 0; k < units.size(); ++k) {         // while ssvu.get_v3c_unit_count() > 0, src/lib.rs:118
+    if (pool_gib >= 2 && reservers.t.empty() && k == 3 && units.size() - k >= 8) reserve_pools();   // (never waited for)
     launch_upto(k);
     InFlight& cur = inflight.front();
     const size_t n = cur.frames.size();

@@ -159,6 +159,8 @@ struct DecodedGof {
   std::vector<vpcc_frame_desc> frames;
   // the GOF's geometry-smoothing SEI (V3C input; flags == 0: none): geometry_bitdepth_3d, grid_size, threshold
   vpcc_smoothing_params sei_smoothing{};
+  bool has_syntax = false;                            // V3C input: a GOF without the SEI is NOT smoothed (src/decoder.rs:291); a
+                                                      // container carries no syntax: Params' geometry parameters decide
   std::vector<std::vector<vpcc_patch>> patch_store;   // V3C input: patch tables built by the syntax parser
 };
 

@@ -136,6 +136,7 @@ bool parse_v3c_with_raw_video(const std::vector<unsigned char>& bin, const unsig
     const size_t vid_frame = luma + 2 * chroma;
     const bool has_attr = !syn.vps.ai.attributes.empty();
     DecodedGof gof;
+    gof.has_syntax = true;
     if (gp.geometry_smoothing_sei && gp.smoothing_grid_size >= 2) {      // SeiGeometrySmoothing, src/bitstream/reader.rs:1452-1505
       gof.sei_smoothing.flags = VPCC_SMOOTH_GEOMETRY;
       gof.sei_smoothing.geometry_bitdepth_3d = gp.geometry_bitdepth_3d;

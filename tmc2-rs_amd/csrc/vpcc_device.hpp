@@ -20,7 +20,9 @@ struct DevPatch {
   uint8_t normal_axis, tangent_axis, bitangent_axis, projection_mode;
   uint32_t size_u0, size_v0;
   uint32_t vb_base;   // first virtual block of this patch (emission order)
-  uint32_t pad;
+  uint32_t bc;        // the BLOCK map's constants, cx | cy << 16 (patch_affine at resolution 1: the a-coefficients are the
+                      // pixel map's, the constants are not — size_uv0 stays in blocks at every resolution): canvas block of
+                      // the patch's block (u0, v0) = (ax_u*u0 + ax_v*v0 + cx, ay_u*u0 + ay_v*v0 + cy); both < 32768
 };
 static_assert(sizeof(DevPatch) == 64, "DevPatch is one 64-B record");
 
@@ -35,11 +37,47 @@ struct VBlock {
 };
 static_assert(sizeof(VBlock) == 16, "VBlock is 16 B");
 
+#if defined(__HIPCC__)
+#define VPCC_HD __host__ __device__
+#else
+#define VPCC_HD
+#endif
+// The host writes O(patches) per frame: vb_base[p] = sum of size_u0 * size_v0 over the patches before p (n_patches + 1
+// entries, the last one the frame's number of virtual blocks).  Which patch a virtual block belongs to, and which block of
+// it, is derived where it is needed — on the device (k_plan_tiles, k_plan_vblocks), and by the CPU tests of these two
+// functions against the reference's loop nest (tests/fuzz_plan.cpp).
+// Patch of virtual block vb < vb_base[n_patches]: the last patch whose base is <= vb (patches without blocks share their
+// successor's base and are never the last).
+VPCC_HD inline uint32_t patch_of_vblock(const uint32_t* vb_base, uint32_t n_patches, uint32_t vb) {
+  uint32_t lo = 0, hi = n_patches;                    // vb_base[lo] <= vb < vb_base[hi]
+  while (hi - lo > 1u) {
+    const uint32_t mid = (lo + hi) >> 1;
+    if (vb_base[mid] <= vb) lo = mid; else hi = mid;
+  }
+  return lo;
+}
+// (patch, v0, u0) of a virtual block and its canvas block, from the patch's record: src/codec.rs:352-385 (v0 outer, u0
+// inner) and patch_block_to_canvas_block, src/decoder.rs:827-838.
+VPCC_HD inline VBlock vblock_of(const DevPatch& p, uint32_t patch, uint32_t vb, uint32_t bw) {
+  const uint32_t r = vb - p.vb_base, v0 = r / p.size_u0, u0 = r - v0 * p.size_u0;
+  const int32_t bx = p.ax_u * (int32_t)u0 + p.ax_v * (int32_t)v0 + (int32_t)(p.bc & 0xFFFFu);
+  const int32_t by = p.ay_u * (int32_t)u0 + p.ay_v * (int32_t)v0 + (int32_t)(p.bc >> 16);
+  VBlock b{};
+  b.patch = (uint16_t)patch;
+  b.u0 = (uint16_t)u0;
+  b.v0 = (uint16_t)v0;
+  b.canvas_block = (uint32_t)by * bw + (uint32_t)bx;
+  return b;
+}
+
 // Work item of the single-pass tile kernel: one virtual block that OWNS its canvas block, with the
 // patch fields the per-point arithmetic needs folded in (one 32-B scalar load per item).
+// The host writes one TEMPLATE per patch — everything of an item that the patch decides — and the planning kernel
+// completes a copy of it for every block the patch owns.  What the planning kernel needs to know of a patch beyond that
+// travels in the three fields it overwrites: x0, y0 = the patch's origin in BLOCKS (uv0), patch = size_u0.
 struct TileItem {
-  uint16_t x0, y0;        // canvas pixel origin of the block
-  uint16_t patch;         // patch index (partition output)
+  uint16_t x0, y0;        // canvas pixel origin of the block                      (template: u0, v0 of the patch, in blocks)
+  uint16_t patch;         // patch index (partition output)                        (template: size_u0)
   uint8_t flags;          // kTileSwap | kTileMode1
   uint8_t axes;           // normal | tangent << 2 | bitangent << 4
   uint32_t tb, bb;        // tangent / bitangent coordinate of the block's first pixel (mod 2^32):
@@ -65,8 +103,9 @@ struct DevFrame {
   const uint16_t* attr_y[2];
   const uint16_t* attr_u[2];
   const uint16_t* attr_v[2];
-  const DevPatch* patches;
-  const VBlock* vblocks;
+  const DevPatch* patches;    // general sequence (and tile frames too large for k_plan_tiles' LDS): host
+  VBlock* vblocks;            // ... every (patch, v0, u0) in emission order: written by k_plan_vblocks when the gof is created
+  const uint32_t* vb_base;    // n_patches + 1: first virtual block of every patch, then the frame's number of them (host)
   uint32_t* block_to_patch;   // bw*bh, 0 = unowned else patch+1
   uint32_t* vb_count;         // points per virtual block
   uint32_t* vb_offset;        // exclusive prefix of vb_count
@@ -75,8 +114,8 @@ struct DevFrame {
   uint16_t* out_patch;        // optional (partition), may be null
   uint32_t* n_points;         // device counter of this frame
   // single-pass tile kernel (R == 16, Default/Swap patches, aligned planes)
-  TileItem* tiles;            // the frame's work items, emission order: written by k_plan_items when the gof is created
-  const TileItem* patch_items;   // one item template per patch (host)
+  TileItem* tiles;            // the frame's work items, emission order: written by the planning kernel of every launch
+  const TileItem* patch_items;   // one item template per patch (host); null: a frame of the general sequence
   uint64_t* scan_state;       // one {status:2 | value:32} word per group of 16 items
   uint64_t* ticket;           // dynamic group counter {launch generation : 32 | groups drawn : 32} (deadlock-free ordering of
                               // the look-back chain; the generation makes a counter of an earlier launch read as fresh)
@@ -89,7 +128,7 @@ struct DevFrame {
   uint32_t n_patches, n_vblocks;
   uint32_t map_count, absolute_d1, has_attr;
   uint32_t capacity;
-  uint32_t n_tiles;           // number of work items, written by k_plan_items (the array is padded to a multiple of 16 readable items)
+  uint32_t n_tiles;           // number of work items, written by the planning kernel (the array is padded to a multiple of 16 readable items)
   uint32_t prec_shift;        // log2(prec) when prec is a power of two (tile kernel)
 };
 
@@ -121,11 +160,6 @@ constexpr uint32_t kColorCellMixed = 1u << 31;
 static_assert(sizeof(SmoothColorCell) == 16, "SmoothColorCell is 16 B");
 
 
-#if defined(__HIPCC__)
-#define VPCC_HD __host__ __device__
-#else
-#define VPCC_HD
-#endif
 // Scratch of the smoothing filters for a chunk of frames: per frame a dense grid of w^3 cells (all-zero between
 // launches), the neighbourhood flags, and the list of the cells every chunk of 256 consecutive points touched (the
 // geometry filter moves points in place, so the cells to clear afterwards cannot be recomputed from the positions).
@@ -184,8 +218,18 @@ void launch_smooth_clear(const DevFrame* d_frames, uint32_t first, uint32_t coun
 
 // Work lists of the tile kernel for frames [first, first + count): which virtual blocks own their canvas block and hold
 // occupancy (generate_block_to_patch_from_occupancy_map_video, src/codec.rs:205-250), in emission order.  Needs the frames'
-// occupancy planes in place and block_to_patch zeroed; writes block_to_patch, tiles and n_tiles.
-void launch_plan_tiles(DevFrame* d_frames, uint32_t first, uint32_t count, uint32_t max_vb, void* stream);
+// occupancy planes in place; writes block_to_patch, tiles and n_tiles.
+//   launch_plan_tiles: ONE kernel, a workgroup per frame with the frame's block_to_patch and patch table in LDS — frames of
+//     up to kPlanLdsBlocks canvas blocks and kPlanLdsPatches patches (`lds_bytes` from plan_tiles_lds_bytes of the launch's
+//     largest frame);
+//   launch_plan_tiles_global: any frame — block_to_patch zeroed in global memory (here), k_plan_cover, k_plan_items over
+//     the virtual blocks k_plan_vblocks wrote.
+constexpr uint32_t kPlanLdsBlocks = 32768, kPlanLdsPatches = 2048;
+inline size_t plan_tiles_lds_bytes(uint32_t blocks, uint32_t patches) { return 4u * (size_t)blocks + 12u * ((size_t)patches + 1u) + 256u; }
+void launch_plan_tiles(DevFrame* d_frames, uint32_t first, uint32_t count, size_t lds_bytes, void* stream);
+void launch_plan_tiles_global(DevFrame* d_frames, uint32_t first, uint32_t count, uint32_t max_vb, uint32_t* d_b2p, size_t b2p_words, void* stream);
+// The virtual blocks of frames [first, first + count) from their patch tables (once per gof: they do not depend on the planes)
+void launch_plan_vblocks(DevFrame* d_frames, uint32_t first, uint32_t count, uint32_t max_vb, void* stream);
 // Kernel launchers (vpcc_kernels.hip).  All asynchronous on `stream`.
 void launch_block_owner(const DevFrame* d_frames, uint32_t first, uint32_t count, uint32_t max_vb,
                         void* stream);

@@ -44,7 +44,7 @@ bool extent_inside(const Affine& a, int64_t nu, int64_t nv, int64_t w, int64_t h
 
 }  // namespace
 
-int validate_frame(const vpcc_frame_desc* f) {
+int validate_frame(const vpcc_frame_desc* f, FrameShape* shape) {
   if (!f) return VPCC_ERR_INVALID_ARG;
   if (f->width == 0 || f->height == 0 || f->occupancy_resolution == 0 || f->occupancy_precision == 0)
     return VPCC_ERR_INVALID_ARG;
@@ -64,11 +64,13 @@ int validate_frame(const vpcc_frame_desc* f) {
     return VPCC_ERR_PATCH_OUT_OF_CANVAS;
 
   // geometry frames f*map_count .. must exist: src/codec.rs:317-321
-  for (uint32_t m = 0; m < f->map_count; ++m) {
+  uint64_t plane_bytes = (uint64_t)f->occupancy.width * f->occupancy.height;    // B = Wo*Ho + M*W*H*2 +
+  for (uint32_t m = 0; m < f->map_count; ++m) {                                 //   M*(W*H*2 + 2*(W/2)*(H/2)*2) (+ 9*N at run time)
     const vpcc_image_u16& G = f->geometry[m];
     if (!G.y) return VPCC_ERR_SHORT_VIDEO;
     if (G.stride < G.width) return VPCC_ERR_INVALID_ARG;
     if ((int64_t)G.width < W || (int64_t)G.height < H) return VPCC_ERR_PATCH_OUT_OF_CANVAS;
+    plane_bytes += (uint64_t)G.width * G.height * 2;
   }
   if (f->attribute_count) {
     for (uint32_t m = 0; m < f->map_count; ++m) {
@@ -76,79 +78,92 @@ int validate_frame(const vpcc_frame_desc* f) {
       if (!A.y || !A.u || !A.v) return VPCC_ERR_SHORT_VIDEO;                    // src/codec.rs:589-590, 637
       if (A.stride < A.width || A.cstride < A.width / 2) return VPCC_ERR_INVALID_ARG;
       if ((int64_t)A.width < W || (int64_t)A.height < H) return VPCC_ERR_PATCH_OUT_OF_CANVAS;
+      plane_bytes += (uint64_t)A.width * A.height * 2 + 2ull * (A.width / 2) * (A.height / 2) * 2;
     }
   }
 
   uint64_t n_vb = 0;
+  bool simple = true;                 // Default / Swap (/ MRot270 == Swap) patches with levels of detail that fit a tile item
   for (uint32_t i = 0; i < f->patch_count; ++i) {
     const vpcc_patch& p = f->patches[i];
     if (p.axis_of_additional_plane != 0) return VPCC_ERR_UNSUPPORTED;           // src/codec.rs:437
     if (p.normal_axis > 2 || p.tangent_axis > 2 || p.bitangent_axis > 2) return VPCC_ERR_INVALID_ARG;
     if (p.projection_mode > 1) return VPCC_ERR_INVALID_ARG;                     // unreachable!() decoder.rs:886
     if (p.orientation > VPCC_ORIENT_MROT270) return VPCC_ERR_INVALID_ARG;
+    if (p.lod_x > 65535u || p.lod_y > 65535u) simple = false;
     if (p.size_u0 == 0 || p.size_v0 == 0) continue;
     if (p.size_u0 > 65535 || p.size_v0 > 65535) return VPCC_ERR_PATCH_OUT_OF_CANVAS;
-    // assert in patch_block_to_canvas_block, src/decoder.rs:835
-    if (!extent_inside(patch_affine(p, 1), p.size_u0, p.size_v0, bw, bh)) return VPCC_ERR_PATCH_OUT_OF_CANVAS;
-    // assert in patch_to_canvas, src/decoder.rs:848
-    if (!extent_inside(patch_affine(p, R), (int64_t)p.size_u0 * R, (int64_t)p.size_v0 * R, W, H))
-      return VPCC_ERR_PATCH_OUT_OF_CANVAS;
+    if (p.orientation == VPCC_ORIENT_DEFAULT || p.orientation == VPCC_ORIENT_SWAP || p.orientation == VPCC_ORIENT_MROT270) {
+      // the two orientations every stream has (use_eight_orientations_flag = 0), without the corner walk: the patch's
+      // blocks are [u0, u0 + su) x [v0, v0 + sv) (Default) or [u0, u0 + sv) x [v0, v0 + su) (Swap) of the canvas, and a
+      // rectangle of whole blocks that lies inside the canvas in blocks does so in pixels (bw * R <= W)
+      const bool swap = p.orientation != VPCC_ORIENT_DEFAULT;
+      if ((uint64_t)p.u0 + (swap ? p.size_v0 : p.size_u0) > (uint64_t)bw || (uint64_t)p.v0 + (swap ? p.size_u0 : p.size_v0) > (uint64_t)bh)
+        return VPCC_ERR_PATCH_OUT_OF_CANVAS;
+    } else {
+      simple = false;
+      // assert in patch_block_to_canvas_block, src/decoder.rs:835
+      if (!extent_inside(patch_affine(p, 1), p.size_u0, p.size_v0, bw, bh)) return VPCC_ERR_PATCH_OUT_OF_CANVAS;
+      // assert in patch_to_canvas, src/decoder.rs:848
+      if (!extent_inside(patch_affine(p, R), (int64_t)p.size_u0 * R, (int64_t)p.size_v0 * R, W, H))
+        return VPCC_ERR_PATCH_OUT_OF_CANVAS;
+    }
     n_vb += (uint64_t)p.size_u0 * p.size_v0;
   }
   if (n_vb > 0x7FFFFFFFull) return VPCC_ERR_INVALID_ARG;
+  if (shape) {
+    shape->bw = (uint32_t)bw;
+    shape->bh = (uint32_t)bh;
+    shape->n_patches = f->patch_count;
+    shape->n_vblocks = (uint32_t)n_vb;
+    // Tile kernel (R = 16, Default/Swap patches): the pixels of a virtual block are exactly the pixels of its canvas block,
+    // so every covering patch sees the same occupancy and the reference's ascending overwrite (src/codec.rs:217, 242-244)
+    // leaves "highest covering patch, if any occupancy"
+    shape->tile_eligible = simple && R == 16 && prec <= 16 && (prec & (prec - 1)) == 0;
+    shape->tile_bound = shape->tile_eligible ? (uint32_t)std::min<uint64_t>(n_vb, (uint64_t)bw * bh) : 0u;
+    shape->plane_bytes = plane_bytes;
+  }
   return VPCC_OK;
 }
 
-void plan_frame(const vpcc_frame_desc& f, FramePlan* out) {
+namespace {
+// v_perm_b32 selectors of a tile item by its axes byte (normal | tangent << 2 | bitangent << 4): coordinate a takes
+// bitangent if bitangent_axis == a, else tangent, else normal, else 0 — the reference assigns normal, tangent, bitangent
+// in this order (src/decoder.rs:874-876)
+struct AxisSelectors {
+  uint32_t xy[64], z[64];
+  AxisSelectors() {
+    for (uint32_t axes = 0; axes < 64; ++axes) {
+      const uint32_t n = axes & 3u, t = (axes >> 2) & 3u, b = (axes >> 4) & 3u;
+      uint32_t sel[3];
+      for (uint32_t a = 0; a < 3; ++a) {
+        uint32_t v = 0x0C0Cu;
+        if (n == a) v = 0x0100u;
+        if (t == a) v = 0x0302u;
+        if (b == a) v = 0x0504u;
+        sel[a] = v;
+      }
+      xy[axes] = sel[0] | (sel[1] << 16);
+      z[axes] = sel[2] | 0x0C0C0000u;
+    }
+  }
+};
+const AxisSelectors kAxisSelectors;
+}  // namespace
+
+void write_frame_records(const vpcc_frame_desc& f, uint32_t* vb_base, TileItem* items, DevPatch* patches) {
   const int64_t R = f.occupancy_resolution;
-  out->bw = f.width / f.occupancy_resolution;
-  out->bh = f.height / f.occupancy_resolution;
-  out->patches.resize(f.patch_count);
-  out->vblocks.clear();
-  out->simple_orientations = true;
-  uint32_t vb_base = 0;
+  uint32_t base = 0;
   for (uint32_t i = 0; i < f.patch_count; ++i) {
     const vpcc_patch& p = f.patches[i];
-    const Affine px = patch_affine(p, R), bl = patch_affine(p, 1);
-    DevPatch& d = out->patches[i];
-    d = DevPatch{};
-    d.ax_u = (int32_t)px.ax_u; d.ax_v = (int32_t)px.ax_v; d.cx = (int32_t)px.cx;
-    d.ay_u = (int32_t)px.ay_u; d.ay_v = (int32_t)px.ay_v; d.cy = (int32_t)px.cy;
-    d.u1 = p.u1; d.v1 = p.v1; d.d1 = p.d1;
-    d.lod_x = p.lod_x; d.lod_y = p.lod_y;
-    d.normal_axis = p.normal_axis; d.tangent_axis = p.tangent_axis; d.bitangent_axis = p.bitangent_axis;
-    d.projection_mode = p.projection_mode;
-    d.size_u0 = p.size_u0; d.size_v0 = p.size_v0;
-    d.vb_base = vb_base;
-    if (!(p.orientation == VPCC_ORIENT_DEFAULT || p.orientation == VPCC_ORIENT_SWAP ||
-          p.orientation == VPCC_ORIENT_MROT270))
-      out->simple_orientations = false;
-    for (uint32_t v0 = 0; v0 < p.size_v0; ++v0)
-      for (uint32_t u0 = 0; u0 < p.size_u0; ++u0) {
-        VBlock b{};
-        b.patch = (uint16_t)i;
-        b.u0 = (uint16_t)u0;
-        b.v0 = (uint16_t)v0;
-        const int64_t bx = bl.ax_u * u0 + bl.ax_v * v0 + bl.cx, by = bl.ay_u * u0 + bl.ay_v * v0 + bl.cy;
-        b.canvas_block = (uint32_t)(by * out->bw + bx);
-        out->vblocks.push_back(b);
-      }
-    vb_base += p.size_u0 * p.size_v0;
-  }
-  // Tile kernel (R = 16, Default/Swap patches): one item TEMPLATE per patch — the fields of a work item that the patch
-  // decides.  For such patches the pixels of a virtual block are exactly the pixels of its canvas block, so every covering
-  // patch sees the same occupancy and the reference's ascending overwrite (src/codec.rs:217, 242-244) leaves "highest
-  // covering patch, if any occupancy": the device finds those blocks (k_plan_cover, k_plan_items) and completes the items.
-  out->patch_items.clear();
-  const uint32_t prec = f.occupancy_precision;
-  out->tile_eligible = out->simple_orientations && f.occupancy_resolution == 16 && prec <= 16 && (prec & (prec - 1)) == 0;
-  out->tile_bound = 0;
-  if (out->tile_eligible) {
-    out->patch_items.resize(f.patch_count);
-    for (uint32_t i = 0; i < f.patch_count; ++i) {
-      const vpcc_patch& p = f.patches[i];
+    vb_base[i] = base;
+    if (items) {
+      // one item TEMPLATE per patch: the fields of a work item that the patch decides, and — in the fields the planning kernel
+      // overwrites — where the patch lies: x0, y0 = uv0 in blocks, patch = size_u0
       TileItem t{};
-      t.patch = (uint16_t)i;
+      t.x0 = (uint16_t)p.u0;
+      t.y0 = (uint16_t)p.v0;
+      t.patch = (uint16_t)p.size_u0;
       t.flags = (uint8_t)((p.orientation == VPCC_ORIENT_DEFAULT ? 0 : kTileSwap) | (p.projection_mode ? kTileMode1 : 0));
       t.axes = (uint8_t)(p.normal_axis | (p.tangent_axis << 2) | (p.bitangent_axis << 4));
       t.tb = p.u1;                                     // + u0 * 16 * lod_x of the block   (src/decoder.rs:875-876)
@@ -156,33 +171,163 @@ void plan_frame(const vpcc_frame_desc& f, FramePlan* out) {
       t.d1 = p.d1;
       t.lod_x = (uint16_t)p.lod_x;
       t.lod_y = (uint16_t)p.lod_y;
-      // coordinate a takes bitangent if bitangent_axis == a, else tangent, else normal, else 0: the
-      // reference assigns normal, tangent, bitangent in this order (src/decoder.rs:874-876)
-      uint32_t sel[3];
-      for (uint32_t a = 0; a < 3; ++a) {
-        uint32_t v = 0x0C0Cu;
-        if (p.normal_axis == a) v = 0x0100u;
-        if (p.tangent_axis == a) v = 0x0302u;
-        if (p.bitangent_axis == a) v = 0x0504u;
-        sel[a] = v;
-      }
-      t.sel_xy = sel[0] | (sel[1] << 16);
-      t.sel_z = sel[2] | 0x0C0C0000u;
-      if (p.lod_x > 65535u || p.lod_y > 65535u) out->tile_eligible = false;
-      out->patch_items[i] = t;
+      t.sel_xy = kAxisSelectors.xy[t.axes];
+      t.sel_z = kAxisSelectors.z[t.axes];
+      items[i] = t;
     }
-    if (!out->tile_eligible) out->patch_items.clear();
-    else out->tile_bound = (uint32_t)std::min<uint64_t>(out->vblocks.size(), (uint64_t)out->bw * out->bh);
+    if (patches) {
+      const Affine px = patch_affine(p, R), bl = patch_affine(p, 1);
+      DevPatch d{};
+      d.ax_u = (int32_t)px.ax_u; d.ax_v = (int32_t)px.ax_v; d.cx = (int32_t)px.cx;
+      d.ay_u = (int32_t)px.ay_u; d.ay_v = (int32_t)px.ay_v; d.cy = (int32_t)px.cy;
+      d.u1 = p.u1; d.v1 = p.v1; d.d1 = p.d1;
+      d.lod_x = p.lod_x; d.lod_y = p.lod_y;
+      d.normal_axis = p.normal_axis; d.tangent_axis = p.tangent_axis; d.bitangent_axis = p.bitangent_axis;
+      d.projection_mode = p.projection_mode;
+      d.size_u0 = p.size_u0; d.size_v0 = p.size_v0;
+      d.vb_base = base;
+      // the image of block (0, 0) lies inside the canvas (validate_frame) — patches without blocks are never looked at
+      d.bc = ((uint32_t)bl.cx & 0xFFFFu) | ((uint32_t)bl.cy << 16);
+      patches[i] = d;
+    }
+    base += p.size_u0 * p.size_v0;
   }
-  // B = Wo*Ho + M*W*H*2 + M*(W*H*2 + 2*(W/2)*(H/2)*2) + 9*N (N added at run time)
-  uint64_t bytes = (uint64_t)f.occupancy.width * f.occupancy.height;
-  for (uint32_t m = 0; m < f.map_count; ++m) {
-    bytes += (uint64_t)f.geometry[m].width * f.geometry[m].height * 2;
-    if (f.attribute_count)
-      bytes += (uint64_t)f.attribute[m].width * f.attribute[m].height * 2 +
-               2ull * (f.attribute[m].width / 2) * (f.attribute[m].height / 2) * 2;
+  vb_base[f.patch_count] = base;
+}
+
+// ------------------------------------------------------------------------------------------------ memory of a gof
+namespace {
+struct PlaneRef { const char* src; size_t bytes; size_t* slot; int part; };
+// every plane the gof ingests, with the slot that will say where it lies on the device
+template <class Fn>
+void for_each_plane(const vpcc_frame_desc& F, PlaneSlots& o, Fn&& fn) {
+  fn(F.occupancy.y, (size_t)F.occupancy.width * F.occupancy.height, &o.occ, F.occupancy.stride == F.occupancy.width);
+  for (uint32_t m = 0; m < F.map_count; ++m) {
+    fn(F.geometry[m].y, (size_t)F.geometry[m].width * F.geometry[m].height * 2, &o.geo[m], F.geometry[m].stride == F.geometry[m].width);
+    if (F.attribute_count) {
+      fn(F.attribute[m].y, (size_t)F.attribute[m].width * F.attribute[m].height * 2, &o.ay[m], F.attribute[m].stride == F.attribute[m].width);
+      // chroma keeps its source stride: the reference indexes it as a flat array (v/2)*(width/2)+(u/2), src/decoder.rs:977
+      fn(F.attribute[m].u, chroma_elems(F.attribute[m]) * 2, &o.au[m], true);
+      fn(F.attribute[m].v, chroma_elems(F.attribute[m]) * 2, &o.av[m], true);
+    }
   }
-  out->plane_bytes = bytes;
+}
+}  // namespace
+
+bool classify_extents(const vpcc_frame_desc* frames, uint32_t n_frames, const PinnedQuery& pinned, GofLayout* layout,
+                      std::vector<IngestExtent>* extents) {
+  extents->clear();
+  std::vector<PlaneSlots> slots(n_frames);
+  std::vector<PlaneRef> refs;
+  bool tight = true;
+  for (uint32_t i = 0; i < n_frames && tight; ++i)
+    for_each_plane(frames[i], slots[i], [&](const void* src, size_t bytes, size_t* slot, bool is_tight) {
+      tight = tight && is_tight;
+      refs.push_back(PlaneRef{(const char*)src, bytes, slot, gof_part_of(i)});
+    });
+  if (!tight || refs.empty()) return false;
+  std::stable_sort(refs.begin(), refs.end(), [](const PlaneRef& a, const PlaneRef& b) { return a.part != b.part ? a.part < b.part : a.src < b.src; });
+  const size_t kGap = 256u << 10;                         // what may lie between two planes of a stretch (patch tables, headers)
+  std::vector<std::pair<size_t, size_t>> span;             // [first, last] plane of every stretch
+  for (size_t k = 0; k < refs.size(); ++k) {
+    const char* end = extents->empty() ? nullptr : extents->back().lo + extents->back().bytes;
+    if (!extents->empty() && extents->back().part == refs[k].part && refs[k].src <= end + kGap) {
+      extents->back().bytes = std::max<size_t>(extents->back().bytes, (size_t)(refs[k].src + refs[k].bytes - extents->back().lo));
+      span.back().second = k;
+    } else {
+      extents->push_back(IngestExtent{refs[k].src, refs[k].bytes, 0, refs[k].part, {}});
+      span.emplace_back(k, k);
+    }
+  }
+  // worth it when stretches are long, and every stretch must be page-locked memory from end to end (what lies between its
+  // planes is copied along)
+  bool ok = extents->size() * 4 <= refs.size();
+  for (size_t e = 0; e < extents->size() && ok; ++e) ok = pinned((*extents)[e].lo, (*extents)[e].bytes, &(*extents)[e].pieces);
+  if (!ok) { extents->clear(); return false; }
+  for (size_t e = 0; e < extents->size(); ++e) {
+    // the device copy lies where the host stretch lies modulo 256: every plane keeps its alignment
+    IngestExtent& E = (*extents)[e];
+    const size_t shift = (uintptr_t)E.lo & 255u;
+    E.dev = layout->block[2 * E.part + 0].take(E.bytes + 256) + shift;
+    for (size_t k = span[e].first; k <= span[e].second; ++k) *refs[k].slot = E.dev + (size_t)(refs[k].src - E.lo);
+  }
+  for (uint32_t i = 0; i < n_frames; ++i) layout->f[i].planes = slots[i];
+  return true;
+}
+
+void place_planes(const GofLayoutRequest& rq, GofLayout* L) {
+  L->ingest_bound = 0;
+  for (uint32_t i = 0; i < rq.n_frames; ++i) {
+    ArenaLayout& B = L->block[2 * gof_part_of(i) + 0];
+    for_each_plane(rq.frames[i], L->f[i].planes, [&](const void* src, size_t bytes, size_t* slot, bool is_tight) {
+      // (+ 16: a plane pulled by the ingest kernel starts 0 or 8 bytes behind its 256-byte boundary — where its source does
+      // modulo 16, so that 16-byte pieces line up on both sides)
+      const size_t shift = rq.pull_ingest && is_tight && ((uintptr_t)src & 7u) == 0 ? ((uintptr_t)src & 15u) : 0u;
+      *slot = B.take(bytes + 16) + shift;
+      L->ingest_bound += bytes / kIngestPieceBytes + 2;
+    });
+  }
+}
+
+void layout_gof(const GofLayoutRequest& rq, GofLayout* Lp) {
+  GofLayout& G = *Lp;
+  const uint32_t n = rq.n_frames;
+  ArenaLayout L;
+  G.frames = L.take(sizeof(DevFrame) * n);
+  // what the HOST writes — frame descriptors, vb_base, item templates, patches — lies together at the arena's start: it is
+  // put together in a page-locked staging buffer and arrives as ONE copy at the head of the gof's ingest
+  for (uint32_t i = 0; i < n; ++i) {
+    const size_t P = rq.shapes[i].n_patches;
+    G.f[i].vb_base = L.take(sizeof(uint32_t) * (P + 1));
+    G.f[i].patch_items = rq.tile_records ? L.take(sizeof(TileItem) * std::max<size_t>(P, 1)) : 0;
+    G.f[i].patches = rq.general_records ? L.take(sizeof(DevPatch) * std::max<size_t>(P, 1)) : 0;
+  }
+  G.host_end = L.total;
+  G.counts = L.take(sizeof(uint32_t) * n);
+  // control words of the single-pass path: one contiguous region, zeroed once at creation
+  size_t scan_words = 0;
+  for (uint32_t i = 0; i < n; ++i) {
+    G.f[i].scan_word = scan_words;
+    scan_words += (rq.shapes[i].tile_bound + kTileScanGranule - 1) / kTileScanGranule;
+  }
+  G.ctrl_begin = L.total;
+  G.tickets = L.total;
+  L.total += 256 * (size_t)n;                     // one ticket per 256-B line: same-line atomics serialise
+  G.errors = L.total;
+  L.total += sizeof(uint32_t) * n;
+  L.total = align_up(L.total, 8);
+  G.scan = L.total;
+  L.total += sizeof(uint64_t) * std::max<size_t>(scan_words, 1);
+  G.ctrl_bytes = L.total - G.ctrl_begin;
+  L.total = align_up(L.total, 256);
+  // block_to_patch of all frames contiguous: one memset per launch where it is cleared in global memory
+  G.b2p_begin = L.total;
+  for (uint32_t i = 0; i < n; ++i) {
+    G.f[i].b2p = L.total;
+    L.total += sizeof(uint32_t) * (size_t)rq.shapes[i].bw * rq.shapes[i].bh;
+  }
+  G.b2p_words = (L.total - G.b2p_begin) / sizeof(uint32_t);
+  L.total = align_up(L.total, 256);
+  const size_t cap = (size_t)rq.capacity;
+  for (uint32_t i = 0; i < n; ++i) {
+    const FrameShape& S = rq.shapes[i];
+    FrameOffsets& o = G.f[i];
+    const size_t vb = std::max<size_t>(S.n_vblocks, 1);
+    o.items = rq.tile_records ? L.take(sizeof(TileItem) * (((S.tile_bound + kTileItemsPerGroup - 1) / kTileItemsPerGroup) * kTileItemsPerGroup + kTileItemsPerGroup)) : 0;
+    o.vblocks = rq.general_records ? L.take(sizeof(VBlock) * vb) : 0;
+    o.vb_count = rq.general_records ? L.take(sizeof(uint32_t) * vb) : 0;
+    o.vb_offset = rq.general_records ? L.take(sizeof(uint32_t) * vb) : 0;
+    // output block: positions, colours, partition; + 4: the smoothing kernels read whole quads of points, so a quad that
+    // begins inside an array must end in memory
+    ArenaLayout& B = G.block[2 * gof_part_of(i) + 1];
+    o.xyz = B.take(sizeof(vpcc_point3) * (cap + 4));
+    o.rgb = rq.frames[i].attribute_count ? B.take(sizeof(vpcc_color3) * (cap + 4)) : 0;
+    o.pidx = rq.want_patch_index ? B.take(sizeof(uint16_t) * (cap + 4)) : 0;
+  }
+  G.ingest_pieces = rq.pull_ingest ? L.take(sizeof(IngestPiece) * std::max<size_t>(G.ingest_bound, 1)) : 0;
+  G.arena_bytes = L.total;
+  G.stage_counts = align_up(G.host_end, 256);
+  G.stage_bytes = G.stage_counts + sizeof(uint32_t) * 2 * n;
 }
 
 uint32_t PoolExtents::add_run(char* ptr, size_t bytes, int kind) {

@@ -43,22 +43,127 @@ __global__ __launch_bounds__(256) void k_block_owner(const DevFrame* __restrict_
   if (__ballot(any) != 0ull && lane_id() == 0) atomicMax(f.block_to_patch + b.canvas_block, (uint32_t)b.patch + 1u);
 }
 
-// ------------------------------------------------------ k_plan_cover / k_plan_items
-// The tile kernel's work list, built where the occupancy plane lies.  For Default/Swap patches and 16x16 blocks the
-// reference's block_to_patch (src/codec.rs:205-250: ascending patches, each overwriting the blocks under its occupied
-// virtual blocks) is "the highest patch that covers the block, if the block holds any occupancy":
-//   k_plan_cover: a thread per virtual block: atomicMax(block_to_patch[canvas block], patch + 1) if the block is occupied;
-//   k_plan_items: a workgroup per frame walks the virtual blocks in emission order, keeps those that own their canvas
-//                 block (ordered compaction: ballot + wave scan + a running base), and completes each item from its
-//                 patch's template.
+// ------------------------------------------------------------------ planning
+// generate_block_to_patch_from_occupancy_map_video (src/codec.rs:205-250) and the tile kernel's work list, built where the
+// occupancy plane lies, by every launch (the planes of a gof that borrows them may have changed since the last one).  For
+// Default/Swap patches and 16x16 blocks the pixels of a virtual block are the pixels of its canvas block, so the reference's
+// block_to_patch — ascending patches, each overwriting the blocks under its occupied virtual blocks — is "the highest patch
+// that covers the block, if the block holds any occupancy".
+//
+// The host writes O(patches) per frame (vb_base, one item template per patch); the virtual blocks are derived here.
 __device__ __forceinline__ bool block_occupied(const DevFrame& f, uint32_t cb) {
   const uint32_t spb = f.prec >= 16u ? 1u : 16u / f.prec;                // occupancy samples per block side
   const uint32_t sx = (cb % f.bw) * 16u / f.prec, sy = (cb / f.bw) * 16u / f.prec;
+  // A block's samples lie inside the plane (validate_frame: the plane covers the canvas, the blocks lie inside the canvas).
+  // Rows of 4, 8 or 16 samples whose addresses are multiples of their length come as whole words.
+  const bool words = spb >= 4u && (((uint32_t)(uintptr_t)f.occ | f.occ_stride) & (spb - 1u)) == 0u;
   uint32_t any = 0;
+  if (words) {
+    const VPCC_GLOBAL uint8_t* row = gl(f.occ) + (size_t)sy * f.occ_stride + sx;
+    for (uint32_t y = 0; y < spb; ++y, row += f.occ_stride)
+      for (uint32_t x = 0; x < spb; x += 4u) any |= *(const VPCC_GLOBAL uint32_t*)(row + x);
+    return any != 0;
+  }
   for (uint32_t y = sy; y < sy + spb && y < f.occ_h; ++y)
     for (uint32_t x = sx; x < sx + spb && x < f.occ_w; ++x) any |= gl(f.occ)[y * f.occ_stride + x];
   return any != 0;
 }
+
+// k_plan_tiles: ONE kernel, a workgroup per frame, the frame's block_to_patch and patch table in LDS.
+//   1. a thread per canvas block: does the block hold any occupancy?  LDS word = 0 (yes) or kPlanEmpty (no);
+//      a thread per patch: {vb_base, origin, size_u0 | swap} into LDS;
+//   2. a thread per virtual block (binary search of vb_base in LDS): LDS max(word, patch + 1) where the block is occupied;
+//   3. the virtual blocks once more, in emission order: those that own their canvas block are compacted in order (ballot +
+//      wave totals + a running base) and completed from their patch's template; block_to_patch goes to global memory for
+//      whoever asks (vpcc_gof_block_to_patch).
+constexpr uint32_t kPlanEmpty = 0x80000000u;
+constexpr uint32_t kPlanThreads = 1024;
+__global__ __launch_bounds__(kPlanThreads) void k_plan_tiles(DevFrame* __restrict__ frames, uint32_t first) {
+  DevFrame& f = frames[first + blockIdx.x];
+  if (!f.patch_items) return;                                              // (a frame of the general sequence)
+  extern __shared__ uint32_t plan_lds[];
+  __shared__ uint32_t wave_total[kPlanThreads / 64];
+  __shared__ uint32_t base_s;
+  const uint32_t nb = f.bw * f.bh, P = f.n_patches, n = f.n_vblocks;
+  uint32_t* const b2p = plan_lds;                                          // [nb]
+  uint32_t* const pbase = plan_lds + nb;                                   // [P + 1]
+  uint32_t* const porg = pbase + P + 1;                                    // [P]: u0 | v0 << 16 (blocks)
+  uint32_t* const pdim = porg + P;                                         // [P]: size_u0 | swap << 16
+  const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
+  if (tid == 0) base_s = 0;
+  for (uint32_t cb = tid; cb < nb; cb += kPlanThreads) b2p[cb] = block_occupied(f, cb) ? 0u : kPlanEmpty;
+  for (uint32_t p = tid; p <= P; p += kPlanThreads) {
+    pbase[p] = gl(f.vb_base)[p];
+    if (p < P) {
+      const TileItem t = gload(f.patch_items + p);
+      porg[p] = (uint32_t)t.x0 | ((uint32_t)t.y0 << 16);
+      pdim[p] = (uint32_t)t.patch | ((uint32_t)(t.flags & kTileSwap) << 16);
+    }
+  }
+  __syncthreads();
+  // (patch, u0, v0, canvas block) of virtual block vb
+  auto locate = [&](uint32_t vb, uint32_t& p, uint32_t& u0, uint32_t& v0) -> uint32_t {
+    p = patch_of_vblock(pbase, P, vb);
+    const uint32_t r = vb - pbase[p], su = pdim[p] & 0xFFFFu, org = porg[p];
+    v0 = r / su;
+    u0 = r - v0 * su;
+    const bool swap = (pdim[p] >> 16) != 0;
+    const uint32_t bx = (org & 0xFFFFu) + (swap ? v0 : u0), by = (org >> 16) + (swap ? u0 : v0);   // src/decoder.rs:853-867
+    return by * f.bw + bx;
+  };
+  for (uint32_t vb = tid; vb < n; vb += kPlanThreads) {
+    uint32_t p, u0, v0;
+    const uint32_t cb = locate(vb, p, u0, v0);
+    if (b2p[cb] != kPlanEmpty) atomicMax(&b2p[cb], p + 1u);               // (an empty block's word never changes)
+  }
+  __syncthreads();
+  for (uint32_t v_first = 0; v_first < n; v_first += kPlanThreads) {
+    const uint32_t vb = v_first + tid;
+    uint32_t p = 0, u0 = 0, v0 = 0, cb = 0;
+    bool own = false;
+    if (vb < n) {
+      cb = locate(vb, p, u0, v0);
+      own = b2p[cb] == p + 1u;
+    }
+    const uint64_t m = __ballot(own);
+    if (lane == 0) wave_total[wave] = (uint32_t)__builtin_popcountll(m);
+    __syncthreads();
+    uint32_t before = base_s, tot = 0;
+    for (uint32_t w = 0; w < kPlanThreads / 64; ++w) {
+      const uint32_t t = wave_total[w];
+      if (w < wave) before += t;
+      tot += t;
+    }
+    if (own) {
+      TileItem t = gload(f.patch_items + p);
+      t.x0 = (uint16_t)((cb % f.bw) * 16u);
+      t.y0 = (uint16_t)((cb / f.bw) * 16u);
+      t.patch = (uint16_t)p;
+      t.tb += u0 * 16u * t.lod_x;
+      t.bb += v0 * 16u * t.lod_y;
+      gstore(f.tiles + before + (uint32_t)__builtin_popcountll(m & ((1ull << lane) - 1ull)), t);
+    }
+    __syncthreads();
+    if (tid == 0) base_s += tot;
+    __syncthreads();
+  }
+  if (tid == 0) f.n_tiles = base_s;
+  for (uint32_t cb = tid; cb < nb; cb += kPlanThreads) glw(f.block_to_patch)[cb] = b2p[cb] & ~kPlanEmpty;
+}
+
+// Frames beyond k_plan_tiles' LDS, and the general sequence: the virtual blocks written out once per gof ...
+__global__ __launch_bounds__(256) void k_plan_vblocks(DevFrame* __restrict__ frames, uint32_t first) {
+  const DevFrame& f = frames[first + blockIdx.y];
+  const uint32_t vb = blockIdx.x * 256u + threadIdx.x;
+  if (!f.patches || vb >= f.n_vblocks) return;
+  const uint32_t p = patch_of_vblock(f.vb_base, f.n_patches, vb);
+  gstore(f.vblocks + vb, vblock_of(gload(f.patches + p), p, vb, f.bw));
+}
+// ... and, per launch, over block_to_patch zeroed in global memory:
+//   k_plan_cover: a thread per virtual block: atomicMax(block_to_patch[canvas block], patch + 1) if the block is occupied;
+//   k_plan_items: a workgroup per frame walks the virtual blocks in emission order, keeps those that own their canvas
+//                 block (ordered compaction: ballot + wave scan + a running base), and completes each item from its
+//                 patch's template.
 __global__ __launch_bounds__(256) void k_plan_cover(const DevFrame* __restrict__ frames, uint32_t first) {
   const DevFrame& f = frames[first + blockIdx.y];
   const uint32_t vb = blockIdx.x * 256u + threadIdx.x;
@@ -91,6 +196,7 @@ __global__ __launch_bounds__(1024) void k_plan_items(DevFrame* __restrict__ fram
       TileItem t = gload(f.patch_items + b.patch);
       t.x0 = (uint16_t)((b.canvas_block % f.bw) * 16u);
       t.y0 = (uint16_t)((b.canvas_block / f.bw) * 16u);
+      t.patch = b.patch;
       t.tb += (uint32_t)b.u0 * 16u * t.lod_x;
       t.bb += (uint32_t)b.v0 * 16u * t.lod_y;
       gstore(f.tiles + before + (uint32_t)__builtin_popcountll(m & ((1ull << lane) - 1ull)), t);
@@ -105,10 +211,24 @@ __global__ __launch_bounds__(1024) void k_plan_items(DevFrame* __restrict__ fram
   }
   if (threadIdx.x == 0) f.n_tiles = base_s;
 }
-void launch_plan_tiles(DevFrame* d_frames, uint32_t first, uint32_t count, uint32_t max_vb, void* stream) {
-  if (!count || !max_vb) return;
-  hipLaunchKernelGGL(k_plan_cover, dim3((max_vb + 255u) / 256u, count), dim3(256), 0, (hipStream_t)stream, d_frames, first);
+void launch_plan_tiles(DevFrame* d_frames, uint32_t first, uint32_t count, size_t lds_bytes, void* stream) {
+  if (!count) return;
+  // (a frame beyond 64 KB of LDS: the function's limit on the calling thread's device is raised first — a microsecond)
+  if (lds_bytes > (size_t(60) << 10))
+    (void)hipFuncSetAttribute((const void*)k_plan_tiles, hipFuncAttributeMaxDynamicSharedMemorySize,
+                              (int)plan_tiles_lds_bytes(kPlanLdsBlocks, kPlanLdsPatches));
+  hipLaunchKernelGGL(k_plan_tiles, dim3(count), dim3(kPlanThreads), lds_bytes, (hipStream_t)stream, d_frames, first);
+}
+void launch_plan_tiles_global(DevFrame* d_frames, uint32_t first, uint32_t count, uint32_t max_vb, uint32_t* d_b2p, size_t b2p_words,
+                              void* stream) {
+  if (!count) return;
+  if (b2p_words) (void)hipMemsetAsync(d_b2p, 0, b2p_words * sizeof(uint32_t), (hipStream_t)stream);
+  if (max_vb) hipLaunchKernelGGL(k_plan_cover, dim3((max_vb + 255u) / 256u, count), dim3(256), 0, (hipStream_t)stream, d_frames, first);
   hipLaunchKernelGGL(k_plan_items, dim3(count), dim3(1024), 0, (hipStream_t)stream, d_frames, first);
+}
+void launch_plan_vblocks(DevFrame* d_frames, uint32_t first, uint32_t count, uint32_t max_vb, void* stream) {
+  if (!count || !max_vb) return;
+  hipLaunchKernelGGL(k_plan_vblocks, dim3((max_vb + 255u) / 256u, count), dim3(256), 0, (hipStream_t)stream, d_frames, first);
 }
 
 // ------------------------------------------------------------------ k_count

@@ -233,6 +233,10 @@ def load_library():
     lib.vpcc_gof_profile_interval.argtypes = [vp, u32]
     lib.vpcc_decoder_set_smoothing.argtypes = [vp, C.c_int, C.c_int, C.POINTER(SmoothingParams)]
     lib.vpcc_ctx_reserve.argtypes = [vp, C.c_uint64, C.POINTER(PoolInfo)]
+    lib.vpcc_ctx_reserve_within.argtypes = [vp, C.c_uint64, C.c_float, C.POINTER(PoolInfo)]
+    lib.vpcc_release_kept_pools.argtypes = [C.c_int]
+    lib.vpcc_ctx_pool_alloc.argtypes = [vp, C.c_int, sz, C.POINTER(vp)]
+    lib.vpcc_ctx_pool_free.argtypes = [vp, vp]
     lib.vpcc_ctx_pool_info.argtypes = [vp, C.POINTER(PoolInfo)]
     lib.vpcc_gof_kernel_time_means.argtypes = [vp, u32, C.POINTER(C.c_char_p), C.POINTER(C.c_float),
                                                C.POINTER(u32), C.c_int]

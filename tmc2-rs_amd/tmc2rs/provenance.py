@@ -9,13 +9,13 @@ from . import _abi
 
 # every file the tile / smoothing kernels are compiled from — and the host code that decides what they are given: the
 # work lists (vpcc_kernels.hip: k_plan_*; vpcc_host.cpp), where the planes and outputs lie and how launches are shaped
-# (vpcc_runtime.hip) change a kernel's memory traffic as surely as its own source does
+# (vpcc_gof_create.hip, vpcc_gof.hip, vpcc_pool.hip) change a kernel's memory traffic as surely as its own source does
 KERNEL_SOURCES = ("vpcc_tiles.hip", "vpcc_smooth.hip", "vpcc_kernels.hip", "vpcc_device.hpp", "vpcc_devfn.hpp",
-                  "vpcc_colour.h", "vpcc_runtime.hip", "vpcc_host.cpp")
+                  "vpcc_colour.h", "vpcc_gof_create.hip", "vpcc_gof.hip", "vpcc_gof_smooth.hip", "vpcc_pool.hip", "vpcc_host.cpp")
 # ... and per kernel family (a traffic figure of the tile kernel does not go stale when a smoothing kernel changes)
 FAMILY_SOURCES = {"k_recon_tiles": ("vpcc_tiles.hip", "vpcc_kernels.hip", "vpcc_device.hpp", "vpcc_devfn.hpp", "vpcc_colour.h",
-                                    "vpcc_runtime.hip", "vpcc_host.cpp"),
-                  "k_smooth": ("vpcc_smooth.hip", "vpcc_device.hpp", "vpcc_devfn.hpp", "vpcc_runtime.hip")}
+                                    "vpcc_gof_create.hip", "vpcc_gof.hip", "vpcc_pool.hip", "vpcc_host.cpp"),
+                  "k_smooth": ("vpcc_smooth.hip", "vpcc_device.hpp", "vpcc_devfn.hpp", "vpcc_gof_smooth.hip")}
 
 
 def _sha16(chunks):

@@ -67,12 +67,22 @@ class Context:
                 "ms_spent": round(p.ms_spent, 1), "blocks_in_other_home": int(p.other_home), "blocks_outside_pool": int(p.fallbacks),
                 "taken_over_from_an_earlier_context": bool(p.reused)}
 
-    def reserve(self, gib):
-        """vpcc_ctx_reserve: one allocation of `gib` GiB, classified by kind of VRAM region; every later gof of this
-        context keeps its big blocks in its two homes."""
+    def reserve(self, gib, budget_ms=0.0):
+        """vpcc_ctx_reserve(_within): one allocation of `gib` GiB, classified by kind of VRAM region; every later gof of
+        this context keeps its big blocks in its two homes.  budget_ms > 0: no search for a second home once that much
+        wall-clock time has passed."""
         p = _abi.PoolInfo()
-        self._check(self.lib.vpcc_ctx_reserve(self.h, int(gib) << 30, C.byref(p)), "vpcc_ctx_reserve")
+        self._check(self.lib.vpcc_ctx_reserve_within(self.h, int(gib) << 30, float(budget_ms), C.byref(p)), "vpcc_ctx_reserve")
         return self._pool_dict(p)
+
+    def pool_alloc(self, home, nbytes):
+        """vpcc_ctx_pool_alloc: device memory of the pool's home `home` for a producer of device planes; returns the pointer."""
+        p = C.c_void_p()
+        self._check(self.lib.vpcc_ctx_pool_alloc(self.h, int(home), int(nbytes), C.byref(p)), "vpcc_ctx_pool_alloc")
+        return p.value
+
+    def pool_free(self, ptr):
+        self._check(self.lib.vpcc_ctx_pool_free(self.h, C.c_void_p(ptr)), "vpcc_ctx_pool_free")
 
     def pool_info(self):
         p = _abi.PoolInfo()
@@ -140,6 +150,8 @@ class Gof:
                 d, keep = host_frame_desc(f)
                 arr[i] = d
                 self._keep.append(keep)
+        elif isinstance(descs, C.Array):                 # a prebuilt array (bench.py's fresh_gof leg: no conversion per gof)
+            arr = descs
         else:
             arr = (FrameDesc * self.n_frames)(*descs)
         self._descs = arr
