@@ -690,7 +690,7 @@ def main():
                         d.attribute[m].y, d.attribute[m].u, d.attribute[m].v = ptrs[3 + 3 * m], ptrs[4 + 3 * m], ptrs[5 + 3 * m]
                     arr[r0 + j] = d
             arrays.append((arr, order))
-        live, host_s, k_sum, k_n, turn_ = [], [0.0], {}, [0], [0]
+        live, host_s, wait_s, k_sum, k_n, turn_ = [], [0.0], [0.0], {}, [0], [0]
 
         def read_times(h_):
             names = (C.c_char_p * 8)()
@@ -710,14 +710,17 @@ def main():
             ctx._check(st_, "vpcc_gof_create")
             ctx._check(lib.vpcc_gof_reconstruct(h_, 0, len(batch), None), "vpcc_gof_reconstruct")
             live.append((h_, k % n_batches, bool(prof)))
+            host_s[0] += time.perf_counter() - t_
             if len(live) > 2:
                 old, _, was_prof = live.pop(0)
-                host_s[0] += time.perf_counter() - t_
+                t_ = time.perf_counter()
+                ctx._check(lib.vpcc_gof_sync(old), "vpcc_gof_sync")          # the caller's thread runs ahead of the GPU: it waits HERE
+                wait_s[0] += time.perf_counter() - t_
                 if was_prof:
-                    read_times(old)                  # (waits for that gof's launch: outside the host-time account)
+                    read_times(old)
                 t_ = time.perf_counter()
                 lib.vpcc_gof_destroy(old)
-            host_s[0] += time.perf_counter() - t_
+                host_s[0] += time.perf_counter() - t_
 
         def sync_():
             for h_, _, _ in live:
@@ -726,7 +729,7 @@ def main():
         for _ in range(64):
             step_()
         sync_()
-        host_s[0], turn0 = 0.0, turn_[0]
+        host_s[0], wait_s[0], turn0 = 0.0, 0.0, turn_[0]
         k_sum.clear()
         k_n[0] = 0
         reg_ = sharding.timed_region(step_, sync_, args.steps, args.warmup, points_per_step, min_seconds=args.min_seconds,
@@ -765,8 +768,10 @@ def main():
                 "ms_per_step": round(ms_, 4), "steps_effective": reg_["steps_effective"],
                 "frames_per_s": round(len(batch) / (ms_ * 1e-3), 1), "Mpoints_per_s": round(points_per_step / (ms_ * 1e-3) / 1e6, 1),
                 "host_us_per_step": round(host_us, 1), "host_us_per_frame": round(host_us / len(batch), 3),
-                "host_is": "wall time of the three calls on the caller's thread (validation, O(patches) records, layout, one staged copy, "
-                           "memsets, launches, destroy); the wait a destroy spends on a gof whose kernels still run is in it",
+                "host_is": "wall time of vpcc_gof_create + vpcc_gof_reconstruct + vpcc_gof_destroy on the caller's thread (validation, "
+                           "O(patches) records, layout, one staged copy, memsets, launches, release); the thread runs ahead of the GPU and "
+                           "waits for the gof before last in a vpcc_gof_sync of its own, which is not in it",
+                "host_waits_for_gpu_us_per_step": round(wait_s[0] / max(steps_run, 1) * 1e6, 1),
                 "all_kernels_ms": km, "kernel_launches_averaged": k_n[0],
                 "frac": round(alg_bytes / (ksum * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4) if ksum else None,
                 "frac_of_the_step": round(alg_bytes / (ms_ * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4),

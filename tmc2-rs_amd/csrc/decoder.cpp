@@ -64,6 +64,7 @@ Decoder::Decoder(Params params) : params_(std::move(params)) {}
 Decoder::~Decoder() {
   chan_.drop_rx();                            // receiver dropped: the worker's next send fails and it stops
   if (thread_.joinable()) thread_.join();
+  lanes_.reset();                             // (after the worker: contexts are destroyed on their lanes' threads)
 }
 
 namespace {
@@ -102,56 +103,6 @@ unsigned long input_node_mask(const std::vector<int>& devices) {
 }
 }  // namespace
 
-void Decoder::start() {
-  if (started_) throw std::logic_error("library decoder can only be started once");   // src/lib.rs:108-111
-  started_ = true;
-  const unsigned long nodes = input_node_mask(params_.devices.empty() ? std::vector<int>{0} : params_.devices);
-  if (nodes && std::getenv("VPCC_DECODER_TRACE")) std::fprintf(stderr, "[vpcc decoder] input pages interleaved over the NUMA nodes of mask 0x%lx\n", nodes);
-  // Bitstream::from_file on the caller's thread (src/lib.rs:98); the reference unwraps the io error
-  auto slurp = [nodes](const std::string& path, std::vector<unsigned char>* out, size_t at) {
-    std::ifstream in(path, std::ios::binary | std::ios::ate);
-    if (!in) throw std::runtime_error("cannot open " + path);
-    const size_t n = (size_t)in.tellg();
-    const size_t upto = at + ((n + 15) & ~size_t(15));     // next section starts 16-B aligned
-    // The buffer is page-locked later and read by the copy engines: ask for huge pages BEFORE its first touch (resize
-    // zero-fills) — page-locking then handles 2-MB pages instead of 4-KB ones.  Advice only; VPCC_DECODER_NO_HUGEPAGES=1: none.
-    if (upto > out->capacity() && upto >= (size_t(64) << 20) && (nodes || !std::getenv("VPCC_DECODER_NO_HUGEPAGES"))) {
-      out->reserve(upto);
-      const uintptr_t lo = ((uintptr_t)out->data() + 4095) & ~uintptr_t(4095), hi = ((uintptr_t)out->data() + out->capacity()) & ~uintptr_t(4095);
-      if (hi > lo && !std::getenv("VPCC_DECODER_NO_HUGEPAGES")) (void)madvise((void*)lo, (size_t)(hi - lo), MADV_HUGEPAGE);
-      // (advice too: MPOL_INTERLEAVE = 3; a refusal leaves the pages where the first touch puts them)
-      if (hi > lo && nodes) (void)syscall(SYS_mbind, (void*)lo, (unsigned long)(hi - lo), 3, &nodes, (unsigned long)(8 * sizeof nodes + 1), 0u);
-    }
-    out->resize(upto);
-    in.seekg(0);
-    in.read(reinterpret_cast<char*>(out->data() + at), (std::streamsize)n);
-    return n;
-  };
-  std::vector<unsigned char> head;
-  head.resize(slurp(params_.compressed_stream_path, &head, 0));   // no padding behind the stream itself
-  std::string err;
-  if (head.size() >= 8 && std::memcmp(head.data(), "VPCCGOF1", 8) == 0) {
-    file_ = std::move(head);
-    if (!parse_container(file_, &gofs_, &err)) throw std::runtime_error(err);
-  } else {
-    if (params_.occupancy_yuv_path.empty() || params_.geometry_yuv_path.empty())
-      throw std::runtime_error("V3C input needs the externally decoded occupancy and geometry videos "
-                               "(HEVC decoding is not part of this library)");
-    bin_ = std::move(head);
-    const size_t o0 = 0, on = slurp(params_.occupancy_yuv_path, &file_, o0);
-    const size_t g0 = file_.size(), gn = slurp(params_.geometry_yuv_path, &file_, g0);
-    const size_t a0 = file_.size(), an = params_.attribute_yuv_path.empty() ? 0 : slurp(params_.attribute_yuv_path, &file_, a0);
-    int status = 0;
-    if (!parse_v3c_with_raw_video(bin_, file_.data() + o0, on, file_.data() + g0, gn, file_.data() + a0, an,
-                                  params_.occupancy_precision, &gofs_, &err, &status))
-      throw std::runtime_error(std::string(vpcc_status_string(status)) + ": " + err);
-  }
-  thread_ = std::thread([this] { worker(); });
-}
-
-std::optional<PointSet3> Decoder::recv_frame() { return chan_.recv(); }
-
-namespace {
 struct CtxDeleter { void operator()(vpcc_ctx* c) const { vpcc_ctx_destroy(c); } };
 
 // One lane per GPU: a thread that owns the device's vpcc_ctx and runs every call on it, in FIFO order.  A
@@ -219,7 +170,67 @@ class Lane {
   int create_status_ = 0;
   std::thread th_;                                   // last member: starts when everything above exists
 };
-}  // namespace
+
+// The lanes of a Decoder.  They are made at the very beginning of start(): a lane's first act is vpcc_ctx_create, and the
+// first HIP call of a process initialises the runtime — 0.19-0.24 s on this pool of machines (profiles/r05/cold_start.txt)
+// that now pass while start() reads the input on the caller's thread (src/lib.rs:98), instead of in front of the first frame.
+struct Decoder::LaneSet {
+  std::vector<std::unique_ptr<Lane>> lanes;
+};
+
+void Decoder::start() {
+  if (started_) throw std::logic_error("library decoder can only be started once");   // src/lib.rs:108-111
+  started_ = true;
+  lanes_ = std::make_shared<LaneSet>();
+  {
+    const size_t G = params_.devices.empty() ? 1 : params_.devices.size();
+    for (size_t d = 0; d < G; ++d) lanes_->lanes.push_back(std::make_unique<Lane>(params_.devices.empty() ? 0 : params_.devices[d]));
+  }
+  const unsigned long nodes = input_node_mask(params_.devices.empty() ? std::vector<int>{0} : params_.devices);
+  if (nodes && std::getenv("VPCC_DECODER_TRACE")) std::fprintf(stderr, "[vpcc decoder] input pages interleaved over the NUMA nodes of mask 0x%lx\n", nodes);
+  // Bitstream::from_file on the caller's thread (src/lib.rs:98); the reference unwraps the io error
+  auto slurp = [nodes](const std::string& path, std::vector<unsigned char>* out, size_t at) {
+    std::ifstream in(path, std::ios::binary | std::ios::ate);
+    if (!in) throw std::runtime_error("cannot open " + path);
+    const size_t n = (size_t)in.tellg();
+    const size_t upto = at + ((n + 15) & ~size_t(15));     // next section starts 16-B aligned
+    // The buffer is page-locked later and read by the copy engines: ask for huge pages BEFORE its first touch (resize
+    // zero-fills) — page-locking then handles 2-MB pages instead of 4-KB ones.  Advice only; VPCC_DECODER_NO_HUGEPAGES=1: none.
+    if (upto > out->capacity() && upto >= (size_t(64) << 20) && (nodes || !std::getenv("VPCC_DECODER_NO_HUGEPAGES"))) {
+      out->reserve(upto);
+      const uintptr_t lo = ((uintptr_t)out->data() + 4095) & ~uintptr_t(4095), hi = ((uintptr_t)out->data() + out->capacity()) & ~uintptr_t(4095);
+      if (hi > lo && !std::getenv("VPCC_DECODER_NO_HUGEPAGES")) (void)madvise((void*)lo, (size_t)(hi - lo), MADV_HUGEPAGE);
+      // (advice too: MPOL_INTERLEAVE = 3; a refusal leaves the pages where the first touch puts them)
+      if (hi > lo && nodes) (void)syscall(SYS_mbind, (void*)lo, (unsigned long)(hi - lo), 3, &nodes, (unsigned long)(8 * sizeof nodes + 1), 0u);
+    }
+    out->resize(upto);
+    in.seekg(0);
+    in.read(reinterpret_cast<char*>(out->data() + at), (std::streamsize)n);
+    return n;
+  };
+  std::vector<unsigned char> head;
+  head.resize(slurp(params_.compressed_stream_path, &head, 0));   // no padding behind the stream itself
+  std::string err;
+  if (head.size() >= 8 && std::memcmp(head.data(), "VPCCGOF1", 8) == 0) {
+    file_ = std::move(head);
+    if (!parse_container(file_, &gofs_, &err)) throw std::runtime_error(err);
+  } else {
+    if (params_.occupancy_yuv_path.empty() || params_.geometry_yuv_path.empty())
+      throw std::runtime_error("V3C input needs the externally decoded occupancy and geometry videos "
+                               "(HEVC decoding is not part of this library)");
+    bin_ = std::move(head);
+    const size_t o0 = 0, on = slurp(params_.occupancy_yuv_path, &file_, o0);
+    const size_t g0 = file_.size(), gn = slurp(params_.geometry_yuv_path, &file_, g0);
+    const size_t a0 = file_.size(), an = params_.attribute_yuv_path.empty() ? 0 : slurp(params_.attribute_yuv_path, &file_, a0);
+    int status = 0;
+    if (!parse_v3c_with_raw_video(bin_, file_.data() + o0, on, file_.data() + g0, gn, file_.data() + a0, an,
+                                  params_.occupancy_precision, &gofs_, &err, &status))
+      throw std::runtime_error(std::string(vpcc_status_string(status)) + ": " + err);
+  }
+  thread_ = std::thread([this] { worker(); });
+}
+
+std::optional<PointSet3> Decoder::recv_frame() { return chan_.recv(); }
 
 void Decoder::worker() {
   // One lane (thread + context) per GPU; the frames of a unit are dealt round-robin (frame f -> device f % G) and
@@ -242,8 +253,7 @@ void Decoder::worker() {
                    std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_worker).count(), what,
                    std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count());
   };
-  std::vector<std::unique_ptr<Lane>> lanes;
-  for (size_t d = 0; d < G; ++d) lanes.push_back(std::make_unique<Lane>(params_.devices.empty() ? 0 : params_.devices[d]));
+  std::vector<std::unique_ptr<Lane>>& lanes = lanes_->lanes;         // (made by start(), before it read the input)
   auto fail = [&](const std::string& why) { error_ = why; chan_.close_tx(); };
   for (size_t d = 0; d < G; ++d)
     if (lanes[d]->post([](vpcc_ctx* c) { return c ? 0 : 1; }).get()) { fail("vpcc_ctx_create failed: no usable gfx950 device (no CPU fallback)"); return; }

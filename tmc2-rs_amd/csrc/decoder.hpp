@@ -198,6 +198,8 @@ class Decoder {
 
  private:
   void worker();
+  struct LaneSet;                           // one thread + vpcc_ctx per GPU (decoder.cpp)
+  std::shared_ptr<LaneSet> lanes_;
   Params params_;
   BoundedChannel<PointSet3> chan_{1};
   std::vector<unsigned char> file_;

@@ -261,6 +261,8 @@ void launch_ingest_planes(const IngestPiece* d_pieces, uint32_t n, void* stream)
 void launch_push_results(const IngestPiece pieces[3], void* stream);
 // vpcc_ctx_reserve's probe: the tile kernel's output pattern between two arrays (positions: items * 1824 B, colours: items * 912 B)
 void launch_probe_outputs(unsigned char* xyz, unsigned char* rgb, uint32_t items, void* stream);
+void launch_warm_kernels(void* stream);   // empty kernels: the first launch out of a translation unit loads its code object
+void launch_warm_tiles(void* stream);
 void launch_upsample_occupancy(const DevFrame* d_frames, uint32_t frame, uint8_t* d_out, uint32_t width,
                                uint32_t height, void* stream);
 

@@ -70,28 +70,34 @@ __device__ __forceinline__ bool block_occupied(const DevFrame& f, uint32_t cb) {
 }
 
 // k_plan_tiles: ONE kernel, a workgroup per frame, the frame's block_to_patch and patch table in LDS.
-//   1. a thread per canvas block: does the block hold any occupancy?  LDS word = 0 (yes) or kPlanEmpty (no);
-//      a thread per patch: {vb_base, origin, size_u0 | swap} into LDS;
+//   1. a thread per canvas block: does the block hold any occupancy?  LDS word = 0 (yes) or kPlanEmpty (no) — eight blocks
+//      per thread with all their loads issued together (the occupancy plane comes from HBM: one round trip for a frame of up
+//      to 8 192 blocks, not one per block); a thread per patch: {vb_base, origin, size_u0 | swap} into LDS;
 //   2. a thread per virtual block (binary search of vb_base in LDS): LDS max(word, patch + 1) where the block is occupied;
-//   3. the virtual blocks once more, in emission order: those that own their canvas block are compacted in order (ballot +
-//      wave totals + a running base) and completed from their patch's template; block_to_patch goes to global memory for
-//      whoever asks (vpcc_gof_block_to_patch).
+//   3. ordered compaction of the virtual blocks that own their canvas block: every thread takes a CONTIGUOUS run of them
+//      (emission order = thread order), counts its owners, ONE workgroup-wide exclusive scan of the counts, then every
+//      thread completes its owners' items from their patches' templates — no barrier per step of the walk;
+//      block_to_patch goes to global memory for whoever asks (vpcc_gof_block_to_patch).
 constexpr uint32_t kPlanEmpty = 0x80000000u;
 constexpr uint32_t kPlanThreads = 1024;
+// floor(a / d) for a * d < 2^32 by one multiply-high with m = ceil(2^32 / d) (d >= 2; d == 1: the caller's business): the
+// kernel is ONE workgroup per frame, and the ~40 instructions of a 32-bit division per block and per virtual block were most
+// of its time.  Here a < 32768 (canvas blocks of a frame that fits the LDS) and d <= 2048.
+__device__ __forceinline__ uint32_t magic_of(uint32_t d) { return d > 1u ? (uint32_t)(0x100000000ull / d) + ((0x100000000ull % d) ? 1u : 0u) : 0u; }
+__device__ __forceinline__ uint32_t div_by(uint32_t a, uint32_t d, uint32_t magic) { return d > 1u ? __umulhi(a, magic) : a; }
+
 __global__ __launch_bounds__(kPlanThreads) void k_plan_tiles(DevFrame* __restrict__ frames, uint32_t first) {
   DevFrame& f = frames[first + blockIdx.x];
   if (!f.patch_items) return;                                              // (a frame of the general sequence)
   extern __shared__ uint32_t plan_lds[];
   __shared__ uint32_t wave_total[kPlanThreads / 64];
-  __shared__ uint32_t base_s;
-  const uint32_t nb = f.bw * f.bh, P = f.n_patches, n = f.n_vblocks;
+  const uint32_t bw = f.bw, nb = bw * f.bh, P = f.n_patches, n = f.n_vblocks;
+  const uint32_t bw_magic = magic_of(bw);
   uint32_t* const b2p = plan_lds;                                          // [nb]
   uint32_t* const pbase = plan_lds + nb;                                   // [P + 1]
   uint32_t* const porg = pbase + P + 1;                                    // [P]: u0 | v0 << 16 (blocks)
   uint32_t* const pdim = porg + P;                                         // [P]: size_u0 | swap << 16
   const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
-  if (tid == 0) base_s = 0;
-  for (uint32_t cb = tid; cb < nb; cb += kPlanThreads) b2p[cb] = block_occupied(f, cb) ? 0u : kPlanEmpty;
   for (uint32_t p = tid; p <= P; p += kPlanThreads) {
     pbase[p] = gl(f.vb_base)[p];
     if (p < P) {
@@ -100,54 +106,122 @@ __global__ __launch_bounds__(kPlanThreads) void k_plan_tiles(DevFrame* __restric
       pdim[p] = (uint32_t)t.patch | ((uint32_t)(t.flags & kTileSwap) << 16);
     }
   }
+  {
+    // occupancy of the canvas blocks.  Rows of 4 samples (precision 4) whose addresses are multiples of four come as whole
+    // words, eight blocks per thread in flight; anything else block by block (block_occupied).
+    const uint32_t spb = f.prec >= 16u ? 1u : 16u / f.prec;                // occupancy samples per block side
+    const bool words = spb == 4u && (((uint32_t)(uintptr_t)f.occ | f.occ_stride) & 3u) == 0u;
+    if (words) {
+      const uint32_t stride = f.occ_stride;
+      for (uint32_t c0 = 0; c0 < nb; c0 += 8u * kPlanThreads) {
+        uint32_t v[8];
+#pragma unroll
+        for (uint32_t k = 0; k < 8u; ++k) {
+          const uint32_t cb = c0 + k * kPlanThreads + tid;
+          v[k] = 0;
+          if (cb < nb) {
+            const uint32_t by = div_by(cb, bw, bw_magic), bx = cb - by * bw;
+            const VPCC_GLOBAL uint8_t* row = gl(f.occ) + (by * 4u) * stride + bx * 4u;      // (the tile path's planes: 32-bit offsets)
+            v[k] = *(const VPCC_GLOBAL uint32_t*)row | *(const VPCC_GLOBAL uint32_t*)(row + stride) |
+                   *(const VPCC_GLOBAL uint32_t*)(row + 2u * stride) | *(const VPCC_GLOBAL uint32_t*)(row + 3u * stride);
+          }
+        }
+#pragma unroll
+        for (uint32_t k = 0; k < 8u; ++k) {
+          const uint32_t cb = c0 + k * kPlanThreads + tid;
+          if (cb < nb) b2p[cb] = v[k] ? 0u : kPlanEmpty;
+        }
+      }
+    } else {
+      for (uint32_t cb = tid; cb < nb; cb += kPlanThreads) b2p[cb] = block_occupied(f, cb) ? 0u : kPlanEmpty;
+    }
+  }
   __syncthreads();
-  // (patch, u0, v0, canvas block) of virtual block vb
-  auto locate = [&](uint32_t vb, uint32_t& p, uint32_t& u0, uint32_t& v0) -> uint32_t {
-    p = patch_of_vblock(pbase, P, vb);
-    const uint32_t r = vb - pbase[p], su = pdim[p] & 0xFFFFu, org = porg[p];
-    v0 = r / su;
-    u0 = r - v0 * su;
-    const bool swap = (pdim[p] >> 16) != 0;
-    const uint32_t bx = (org & 0xFFFFu) + (swap ? v0 : u0), by = (org >> 16) + (swap ? u0 : v0);   // src/decoder.rs:853-867
-    return by * f.bw + bx;
+  // Thread t walks the virtual blocks [t * per, (t + 1) * per): a CONTIGUOUS run of the emission order — located once (binary
+  // search of vb_base, one division), then stepped: u0, v0, the patch.
+  struct Walk {
+    uint32_t p, u0, v0, su, org, next;       // patch, block of it, its size_u0, origin u0 | v0 << 16, first virtual block of the patch after it
+    bool swap;
   };
-  for (uint32_t vb = tid; vb < n; vb += kPlanThreads) {
-    uint32_t p, u0, v0;
-    const uint32_t cb = locate(vb, p, u0, v0);
-    if (b2p[cb] != kPlanEmpty) atomicMax(&b2p[cb], p + 1u);               // (an empty block's word never changes)
+  auto enter = [&](Walk& w, uint32_t p) {      // patch p (with blocks), at its first block
+    w.p = p; w.u0 = 0; w.v0 = 0;
+    w.su = pdim[p] & 0xFFFFu; w.swap = (pdim[p] >> 16) != 0; w.org = porg[p]; w.next = pbase[p + 1];
+  };
+  auto locate = [&](Walk& w, uint32_t vb) {
+    enter(w, patch_of_vblock(pbase, P, vb));
+    const uint32_t r = vb - pbase[w.p];
+    w.v0 = w.su > 1u ? r / w.su : r;           // (once per thread)
+    w.u0 = r - w.v0 * w.su;
+  };
+  auto step = [&](Walk& w, uint32_t vb_next) { // to virtual block vb_next = the current one + 1 (< n)
+    if (vb_next == w.next) {
+      uint32_t p = w.p + 1u;
+      while (pbase[p + 1] == vb_next) ++p;     // patches without blocks
+      enter(w, p);
+    } else if (++w.u0 == w.su) { w.u0 = 0; ++w.v0; }
+  };
+  auto canvas_block = [&](const Walk& w) {     // src/decoder.rs:853-867: Default (u0 + u, v0 + v), Swap (u0 + v, v0 + u)
+    const uint32_t bx = (w.org & 0xFFFFu) + (w.swap ? w.v0 : w.u0), by = (w.org >> 16) + (w.swap ? w.u0 : w.v0);
+    return by * bw + bx;
+  };
+  const uint32_t per = (n + kPlanThreads - 1u) / kPlanThreads;
+  const uint32_t v_lo = min(tid * per, n), v_hi = min(v_lo + per, n);
+  Walk w0{};
+  if (v_lo < v_hi) locate(w0, v_lo);
+  {
+    Walk w = w0;
+    for (uint32_t vb = v_lo; vb < v_hi; ++vb) {
+      const uint32_t cb = canvas_block(w);
+      if (b2p[cb] != kPlanEmpty) atomicMax(&b2p[cb], w.p + 1u);           // (an empty block's word never changes)
+      if (vb + 1u < v_hi) step(w, vb + 1u);
+    }
   }
   __syncthreads();
-  for (uint32_t v_first = 0; v_first < n; v_first += kPlanThreads) {
-    const uint32_t vb = v_first + tid;
-    uint32_t p = 0, u0 = 0, v0 = 0, cb = 0;
-    bool own = false;
-    if (vb < n) {
-      cb = locate(vb, p, u0, v0);
-      own = b2p[cb] == p + 1u;
+  // ordered compaction: the owners of a thread's run follow those of all threads before it
+  uint32_t owners = 0, mine = 0;                                           // (a bit per virtual block of the run, up to 32 of them)
+  {
+    Walk w = w0;
+    for (uint32_t vb = v_lo; vb < v_hi; ++vb) {
+      const bool own = b2p[canvas_block(w)] == w.p + 1u;
+      mine += own ? 1u : 0u;
+      if (vb - v_lo < 32u) owners |= (own ? 1u : 0u) << (vb - v_lo);
+      if (vb + 1u < v_hi) step(w, vb + 1u);
     }
-    const uint64_t m = __ballot(own);
-    if (lane == 0) wave_total[wave] = (uint32_t)__builtin_popcountll(m);
-    __syncthreads();
-    uint32_t before = base_s, tot = 0;
-    for (uint32_t w = 0; w < kPlanThreads / 64; ++w) {
-      const uint32_t t = wave_total[w];
-      if (w < wave) before += t;
-      tot += t;
-    }
-    if (own) {
-      TileItem t = gload(f.patch_items + p);
-      t.x0 = (uint16_t)((cb % f.bw) * 16u);
-      t.y0 = (uint16_t)((cb / f.bw) * 16u);
-      t.patch = (uint16_t)p;
-      t.tb += u0 * 16u * t.lod_x;
-      t.bb += v0 * 16u * t.lod_y;
-      gstore(f.tiles + before + (uint32_t)__builtin_popcountll(m & ((1ull << lane) - 1ull)), t);
-    }
-    __syncthreads();
-    if (tid == 0) base_s += tot;
-    __syncthreads();
   }
-  if (tid == 0) f.n_tiles = base_s;
+  uint32_t incl = mine;                                                    // inclusive scan inside the wave, then over the waves
+#pragma unroll
+  for (int off = 1; off < 64; off <<= 1) {
+    const uint32_t t = __shfl_up(incl, off, 64);
+    if ((int)lane >= off) incl += t;
+  }
+  if (lane == 63u) wave_total[wave] = incl;
+  __syncthreads();
+  uint32_t at = incl - mine, total = 0;
+  for (uint32_t w = 0; w < kPlanThreads / 64; ++w) {
+    const uint32_t t = wave_total[w];
+    if (w < wave) at += t;
+    total += t;
+  }
+  if (mine) {
+    Walk w = w0;
+    for (uint32_t vb = v_lo; vb < v_hi; ++vb) {
+      const uint32_t cb = canvas_block(w);
+      const bool own = vb - v_lo < 32u ? ((owners >> (vb - v_lo)) & 1u) != 0 : b2p[cb] == w.p + 1u;
+      if (own) {
+        TileItem t = gload(f.patch_items + w.p);
+        const uint32_t bx = (w.org & 0xFFFFu) + (w.swap ? w.v0 : w.u0), by = (w.org >> 16) + (w.swap ? w.u0 : w.v0);
+        t.x0 = (uint16_t)(bx * 16u);
+        t.y0 = (uint16_t)(by * 16u);
+        t.patch = (uint16_t)w.p;
+        t.tb += w.u0 * 16u * t.lod_x;
+        t.bb += w.v0 * 16u * t.lod_y;
+        gstore(f.tiles + at, t);
+        ++at;
+      }
+      if (vb + 1u < v_hi) step(w, vb + 1u);
+    }
+  }
+  if (tid == 0) f.n_tiles = total;
   for (uint32_t cb = tid; cb < nb; cb += kPlanThreads) glw(f.block_to_patch)[cb] = b2p[cb] & ~kPlanEmpty;
 }
 
@@ -468,6 +542,11 @@ __global__ __launch_bounds__(256) void k_probe_outputs(unsigned char* __restrict
 void launch_probe_outputs(unsigned char* xyz, unsigned char* rgb, uint32_t items, void* stream) {
   hipLaunchKernelGGL(k_probe_outputs, dim3(1024), dim3(256), 0, (hipStream_t)stream, xyz, rgb, items);
 }
+
+// An empty kernel per translation unit with kernels of the per-frame path: the runtime loads a unit's code object at its
+// first launch (milliseconds) — vpcc_ctx_create pays that, not the first gof.
+__global__ void k_warm_kernels() {}
+void launch_warm_kernels(void* stream) { hipLaunchKernelGGL(k_warm_kernels, dim3(1), dim3(64), 0, (hipStream_t)stream); }
 
 void launch_upsample_occupancy(const DevFrame* d_frames, uint32_t frame, uint8_t* d_out, uint32_t width,
                                uint32_t height, void* stream) {

@@ -48,6 +48,11 @@ extern "C" int vpcc_ctx_create(int device_id, vpcc_ctx** out) {
     delete ctx;
     return VPCC_ERR_DEVICE;
   }
+  // the code objects of the per-frame path are loaded now (the runtime loads a translation unit's at its first launch:
+  // 8 ms in front of a cold process's first gof), asynchronously on the copy stream
+  launch_warm_kernels(ctx->copy_stream);
+  launch_warm_tiles(ctx->stream);
+  (void)hipGetLastError();
   *out = ctx;
   return VPCC_OK;
 }

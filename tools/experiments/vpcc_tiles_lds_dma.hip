@@ -1136,4 +1136,7 @@ void launch_tiles(const DevFrame* d_frames, uint32_t first, uint32_t count, uint
                      gen, variant, map);
 }
 
+__global__ void k_warm_tiles() {}
+void launch_warm_tiles(void* stream) { hipLaunchKernelGGL(k_warm_tiles, dim3(1), dim3(64), 0, (hipStream_t)stream); }
+
 }  // namespace vpcc
