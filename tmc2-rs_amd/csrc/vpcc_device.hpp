@@ -225,7 +225,16 @@ void launch_smooth_clear(const DevFrame* d_frames, uint32_t first, uint32_t coun
 //   launch_plan_tiles_global: any frame — block_to_patch zeroed in global memory (here), k_plan_cover, k_plan_items over
 //     the virtual blocks k_plan_vblocks wrote.
 constexpr uint32_t kPlanLdsBlocks = 32768, kPlanLdsPatches = 2048;
-inline size_t plan_tiles_lds_bytes(uint32_t blocks, uint32_t patches) { return 4u * (size_t)blocks + 12u * ((size_t)patches + 1u) + 256u; }
+constexpr size_t kPlanLdsMax = 160u * 1024u - 1024u;              // a workgroup may have all of a CU's 160 KB (less the kernel's static words)
+// block_to_patch word per block, {vb_base, origin, size | swap} per patch (+ the 32-byte item templates where they fit)
+VPCC_HD inline size_t plan_tiles_lds_bytes(uint32_t blocks, uint32_t patches, bool with_templates) {
+  return 4u * (size_t)blocks + 12u * ((size_t)patches + 1u) + 16u + (with_templates ? 32u * (size_t)patches : 0u) + 256u;
+}
+// what a launch asks for: with the templates when that fits a workgroup's LDS
+inline size_t plan_tiles_lds_launch_bytes(uint32_t blocks, uint32_t patches) {
+  const size_t with = plan_tiles_lds_bytes(blocks, patches, true);
+  return with <= kPlanLdsMax ? with : plan_tiles_lds_bytes(blocks, patches, false);
+}
 void launch_plan_tiles(DevFrame* d_frames, uint32_t first, uint32_t count, size_t lds_bytes, void* stream);
 void launch_plan_tiles_global(DevFrame* d_frames, uint32_t first, uint32_t count, uint32_t max_vb, uint32_t* d_b2p, size_t b2p_words, void* stream);
 // The virtual blocks of frames [first, first + count) from their patch tables (once per gof: they do not depend on the planes)

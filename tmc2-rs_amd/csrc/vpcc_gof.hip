@@ -103,7 +103,7 @@ extern "C" int vpcc_gof_reconstruct(vpcc_gof* g, uint32_t first, uint32_t count,
     }
     if (g->plan_in_lds) {
       T.begin("k_plan_tiles");
-      launch_plan_tiles(g->d_frames, first, count, plan_tiles_lds_bytes(max_blocks, max_patches), s);
+      launch_plan_tiles(g->d_frames, first, count, plan_tiles_lds_launch_bytes(max_blocks, max_patches), s);
       T.end();
     } else {
       T.begin("k_plan_cover+items");

@@ -86,7 +86,7 @@ constexpr uint32_t kPlanThreads = 1024;
 __device__ __forceinline__ uint32_t magic_of(uint32_t d) { return d > 1u ? (uint32_t)(0x100000000ull / d) + ((0x100000000ull % d) ? 1u : 0u) : 0u; }
 __device__ __forceinline__ uint32_t div_by(uint32_t a, uint32_t d, uint32_t magic) { return d > 1u ? __umulhi(a, magic) : a; }
 
-__global__ __launch_bounds__(kPlanThreads) void k_plan_tiles(DevFrame* __restrict__ frames, uint32_t first) {
+__global__ __launch_bounds__(kPlanThreads) void k_plan_tiles(DevFrame* __restrict__ frames, uint32_t first, uint32_t lds_bytes) {
   DevFrame& f = frames[first + blockIdx.x];
   if (!f.patch_items) return;                                              // (a frame of the general sequence)
   extern __shared__ uint32_t plan_lds[];
@@ -97,44 +97,66 @@ __global__ __launch_bounds__(kPlanThreads) void k_plan_tiles(DevFrame* __restric
   uint32_t* const pbase = plan_lds + nb;                                   // [P + 1]
   uint32_t* const porg = pbase + P + 1;                                    // [P]: u0 | v0 << 16 (blocks)
   uint32_t* const pdim = porg + P;                                         // [P]: size_u0 | swap << 16
+  // the item templates too, where the launch's LDS has room for them (32 B per patch): the compaction then completes its
+  // items without a round trip to memory per owner
+  TileItem* const ptmpl = (TileItem*)(plan_lds + ((nb + 3u * P + 1u + 3u) & ~3u));
+  const bool tmpl_in_lds = plan_tiles_lds_bytes(nb, P, true) <= lds_bytes;
   const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
+  // ONE round trip to memory for everything the frame's planning reads: the occupancy of the canvas blocks (rows of 4 samples
+  // — precision 4 — whose addresses are multiples of four come as whole words, eight blocks per thread in flight; anything
+  // else block by block, below) and the patch table, all loads issued before the first of them is waited for.
+  const uint32_t spb = f.prec >= 16u ? 1u : 16u / f.prec;                  // occupancy samples per block side
+  const bool words = spb == 4u && (((uint32_t)(uintptr_t)f.occ | f.occ_stride) & 3u) == 0u;
+  const uint32_t stride = f.occ_stride;
+  uint32_t v[8];
+  if (words) {
+#pragma unroll
+    for (uint32_t k = 0; k < 8u; ++k) {
+      const uint32_t cb = k * kPlanThreads + tid;
+      v[k] = 0;
+      if (cb < nb) {
+        const uint32_t by = div_by(cb, bw, bw_magic), bx = cb - by * bw;
+        const VPCC_GLOBAL uint8_t* row = gl(f.occ) + (by * 4u) * stride + bx * 4u;          // (the tile path's planes: 32-bit offsets)
+        v[k] = *(const VPCC_GLOBAL uint32_t*)row | *(const VPCC_GLOBAL uint32_t*)(row + stride) |
+               *(const VPCC_GLOBAL uint32_t*)(row + 2u * stride) | *(const VPCC_GLOBAL uint32_t*)(row + 3u * stride);
+      }
+    }
+  }
   for (uint32_t p = tid; p <= P; p += kPlanThreads) {
     pbase[p] = gl(f.vb_base)[p];
     if (p < P) {
       const TileItem t = gload(f.patch_items + p);
       porg[p] = (uint32_t)t.x0 | ((uint32_t)t.y0 << 16);
       pdim[p] = (uint32_t)t.patch | ((uint32_t)(t.flags & kTileSwap) << 16);
+      if (tmpl_in_lds) ptmpl[p] = t;
     }
   }
-  {
-    // occupancy of the canvas blocks.  Rows of 4 samples (precision 4) whose addresses are multiples of four come as whole
-    // words, eight blocks per thread in flight; anything else block by block (block_occupied).
-    const uint32_t spb = f.prec >= 16u ? 1u : 16u / f.prec;                // occupancy samples per block side
-    const bool words = spb == 4u && (((uint32_t)(uintptr_t)f.occ | f.occ_stride) & 3u) == 0u;
-    if (words) {
-      const uint32_t stride = f.occ_stride;
-      for (uint32_t c0 = 0; c0 < nb; c0 += 8u * kPlanThreads) {
-        uint32_t v[8];
+  if (words) {
 #pragma unroll
-        for (uint32_t k = 0; k < 8u; ++k) {
-          const uint32_t cb = c0 + k * kPlanThreads + tid;
-          v[k] = 0;
-          if (cb < nb) {
-            const uint32_t by = div_by(cb, bw, bw_magic), bx = cb - by * bw;
-            const VPCC_GLOBAL uint8_t* row = gl(f.occ) + (by * 4u) * stride + bx * 4u;      // (the tile path's planes: 32-bit offsets)
-            v[k] = *(const VPCC_GLOBAL uint32_t*)row | *(const VPCC_GLOBAL uint32_t*)(row + stride) |
-                   *(const VPCC_GLOBAL uint32_t*)(row + 2u * stride) | *(const VPCC_GLOBAL uint32_t*)(row + 3u * stride);
-          }
-        }
+    for (uint32_t k = 0; k < 8u; ++k) {
+      const uint32_t cb = k * kPlanThreads + tid;
+      if (cb < nb) b2p[cb] = v[k] ? 0u : kPlanEmpty;
+    }
+    for (uint32_t c0 = 8u * kPlanThreads; c0 < nb; c0 += 8u * kPlanThreads) {          // (frames beyond 8 192 blocks)
 #pragma unroll
-        for (uint32_t k = 0; k < 8u; ++k) {
-          const uint32_t cb = c0 + k * kPlanThreads + tid;
-          if (cb < nb) b2p[cb] = v[k] ? 0u : kPlanEmpty;
+      for (uint32_t k = 0; k < 8u; ++k) {
+        const uint32_t cb = c0 + k * kPlanThreads + tid;
+        v[k] = 0;
+        if (cb < nb) {
+          const uint32_t by = div_by(cb, bw, bw_magic), bx = cb - by * bw;
+          const VPCC_GLOBAL uint8_t* row = gl(f.occ) + (by * 4u) * stride + bx * 4u;
+          v[k] = *(const VPCC_GLOBAL uint32_t*)row | *(const VPCC_GLOBAL uint32_t*)(row + stride) |
+                 *(const VPCC_GLOBAL uint32_t*)(row + 2u * stride) | *(const VPCC_GLOBAL uint32_t*)(row + 3u * stride);
         }
       }
-    } else {
-      for (uint32_t cb = tid; cb < nb; cb += kPlanThreads) b2p[cb] = block_occupied(f, cb) ? 0u : kPlanEmpty;
+#pragma unroll
+      for (uint32_t k = 0; k < 8u; ++k) {
+        const uint32_t cb = c0 + k * kPlanThreads + tid;
+        if (cb < nb) b2p[cb] = v[k] ? 0u : kPlanEmpty;
+      }
     }
+  } else {
+    for (uint32_t cb = tid; cb < nb; cb += kPlanThreads) b2p[cb] = block_occupied(f, cb) ? 0u : kPlanEmpty;
   }
   __syncthreads();
   // Thread t walks the virtual blocks [t * per, (t + 1) * per): a CONTIGUOUS run of the emission order — located once (binary
@@ -208,7 +230,7 @@ __global__ __launch_bounds__(kPlanThreads) void k_plan_tiles(DevFrame* __restric
       const uint32_t cb = canvas_block(w);
       const bool own = vb - v_lo < 32u ? ((owners >> (vb - v_lo)) & 1u) != 0 : b2p[cb] == w.p + 1u;
       if (own) {
-        TileItem t = gload(f.patch_items + w.p);
+        TileItem t = tmpl_in_lds ? ptmpl[w.p] : gload(f.patch_items + w.p);
         const uint32_t bx = (w.org & 0xFFFFu) + (w.swap ? w.v0 : w.u0), by = (w.org >> 16) + (w.swap ? w.u0 : w.v0);
         t.x0 = (uint16_t)(bx * 16u);
         t.y0 = (uint16_t)(by * 16u);
@@ -290,8 +312,8 @@ void launch_plan_tiles(DevFrame* d_frames, uint32_t first, uint32_t count, size_
   // (a frame beyond 64 KB of LDS: the function's limit on the calling thread's device is raised first — a microsecond)
   if (lds_bytes > (size_t(60) << 10))
     (void)hipFuncSetAttribute((const void*)k_plan_tiles, hipFuncAttributeMaxDynamicSharedMemorySize,
-                              (int)plan_tiles_lds_bytes(kPlanLdsBlocks, kPlanLdsPatches));
-  hipLaunchKernelGGL(k_plan_tiles, dim3(count), dim3(kPlanThreads), lds_bytes, (hipStream_t)stream, d_frames, first);
+                              (int)kPlanLdsMax);
+  hipLaunchKernelGGL(k_plan_tiles, dim3(count), dim3(kPlanThreads), lds_bytes, (hipStream_t)stream, d_frames, first, (uint32_t)lds_bytes);
 }
 void launch_plan_tiles_global(DevFrame* d_frames, uint32_t first, uint32_t count, uint32_t max_vb, uint32_t* d_b2p, size_t b2p_words,
                               void* stream) {
