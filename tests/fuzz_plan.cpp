@@ -211,8 +211,9 @@ int main(int argc, char** argv) {
         arena.push_back({o.patches, o.patches + 64 * std::max<size_t>(P, 1), "patches"});
         if (o.patches + 64 * P > L.host_end) { std::fprintf(stderr, "layout: patches behind host_end\n"); return 1; }
         arena.push_back({o.vblocks, o.vblocks + 16 * vbn, "vblocks"});
-        arena.push_back({o.vb_count, o.vb_count + 4 * vbn, "vb_count"});
-        arena.push_back({o.vb_offset, o.vb_offset + 4 * vbn, "vb_offset"});
+        const size_t units = vpcc::general_units(fr[i].occupancy_resolution, sh[i].n_vblocks);      // status words: inside the control region
+        if (o.vb_count < L.scan || o.vb_count + 8 * units > L.ctrl_begin + L.ctrl_bytes || (o.vb_count & 7)) { std::fprintf(stderr, "layout: unit status words\n"); return 1; }
+        if (i + 1 < n && L.f[i + 1].vb_count != o.vb_count + 8 * units) { std::fprintf(stderr, "layout: unit status words overlap\n"); return 1; }
       }
       if (o.b2p != b2p_at) { std::fprintf(stderr, "layout: block_to_patch not contiguous\n"); return 1; }
       b2p_at += 4 * (size_t)sh[i].bw * sh[i].bh;

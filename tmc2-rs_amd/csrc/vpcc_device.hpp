@@ -107,8 +107,8 @@ struct DevFrame {
   VBlock* vblocks;            // ... every (patch, v0, u0) in emission order: written by k_plan_vblocks when the gof is created
   const uint32_t* vb_base;    // n_patches + 1: first virtual block of every patch, then the frame's number of them (host)
   uint32_t* block_to_patch;   // bw*bh, 0 = unowned else patch+1
-  uint32_t* vb_count;         // points per virtual block
-  uint32_t* vb_offset;        // exclusive prefix of vb_count
+  uint32_t* vb_count;         // general sequence: the units' status words, 64 bits each: {generation : 30 | status : 2 | value : 32}
+  uint32_t* vb_offset;        // (unused)
   vpcc_point3* out_xyz;
   vpcc_color3* out_rgb;
   uint16_t* out_patch;        // optional (partition), may be null
@@ -240,11 +240,18 @@ void launch_plan_tiles_global(DevFrame* d_frames, uint32_t first, uint32_t count
 // The virtual blocks of frames [first, first + count) from their patch tables (once per gof: they do not depend on the planes)
 void launch_plan_vblocks(DevFrame* d_frames, uint32_t first, uint32_t count, uint32_t max_vb, void* stream);
 // Kernel launchers (vpcc_kernels.hip).  All asynchronous on `stream`.
-void launch_block_owner(const DevFrame* d_frames, uint32_t first, uint32_t count, uint32_t max_vb,
+// max_samples: the largest rectangle of occupancy samples under a block of the launch's frames, (R / precision + 1)^2
+void launch_block_owner(const DevFrame* d_frames, uint32_t first, uint32_t count, uint32_t max_vb, uint32_t max_samples,
                         void* stream);
-void launch_count(const DevFrame* d_frames, uint32_t first, uint32_t count, uint32_t max_vb, void* stream);
-void launch_scan(const DevFrame* d_frames, uint32_t first, uint32_t count, void* stream);
-void launch_emit(const DevFrame* d_frames, uint32_t first, uint32_t count, uint32_t max_vb, void* stream);
+// The general sequence's single pass; a frame has general_units(R, virtual blocks) units of up to 256 pixels each, and one
+// 64-bit status word per unit (DevFrame::vb_count).  gen: the gof's launch counter (tags the status words).
+VPCC_HD inline uint32_t general_units(uint32_t R, uint32_t n_vblocks) {
+  const uint64_t RR = (uint64_t)R * R;
+  if (RR >= 256u) return (uint32_t)(n_vblocks * ((RR + 255u) / 256u));
+  const uint32_t per = (uint32_t)(256u / RR);
+  return (n_vblocks + per - 1u) / per;
+}
+void launch_general(const DevFrame* d_frames, uint32_t first, uint32_t count, uint32_t max_units, uint32_t gen, void* stream);
 // Where the workgroups of one tile-kernel launch start (kernel argument, by value).  A workgroup stays with its
 // frame; frames differ in size (S-longdress +-5 %, S-owlii +-11 % between the largest frame and the mean), so the
 // resident workgroups of an XCD are shared out among its frames in proportion to their tile counts instead of

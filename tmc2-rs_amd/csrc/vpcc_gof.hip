@@ -129,22 +129,23 @@ extern "C" int vpcc_gof_reconstruct(vpcc_gof* g, uint32_t first, uint32_t count,
     return VPCC_OK;
   }
 
-  // general sequence: owner -> count -> scan -> emit
+  // general sequence: block ownership, then ONE pass over the virtual blocks (count, look-back, emit)
   const size_t b2p_len = g->b2p_off[first + count] - g->b2p_off[first];
   if (b2p_len) HIP_TRY(ctx, hipMemsetAsync(g->d_b2p + g->b2p_off[first], 0, b2p_len * sizeof(uint32_t), s));
-  uint32_t max_vb = 0;
-  for (uint32_t i = first; i < first + count; ++i) max_vb = std::max(max_vb, g->shapes[i].n_vblocks);
+  uint32_t max_vb = 0, max_units = 0, max_samples = 0;
+  for (uint32_t i = first; i < first + count; ++i) {
+    const DevFrame& D = g->h_frames[i];
+    max_vb = std::max(max_vb, D.n_vblocks);
+    max_units = std::max(max_units, general_units(D.R, D.n_vblocks));
+    const uint32_t side = (D.R + D.prec - 1u) / D.prec + 1u; // samples under R pixels that start anywhere: at most ceil(R / precision) + 1
+    max_samples = std::max(max_samples, side * side);
+  }
+  g->generation = (g->generation % 0x3FFFFFFFu) + 1u;        // tags the units' status words: nothing is cleared between launches
   T.begin("k_block_owner");
-  launch_block_owner(g->d_frames, first, count, max_vb, s);
+  launch_block_owner(g->d_frames, first, count, max_vb, max_samples, s);
   T.end();
-  T.begin("k_count");
-  launch_count(g->d_frames, first, count, max_vb, s);
-  T.end();
-  T.begin("k_scan");
-  launch_scan(g->d_frames, first, count, s);
-  T.end();
-  T.begin("k_emit");
-  launch_emit(g->d_frames, first, count, max_vb, s);
+  T.begin("k_general");
+  launch_general(g->d_frames, first, count, max_units, g->generation, s);
   T.end();
   HIP_TRY(ctx, hipGetLastError());
   HIP_TRY(ctx, hipEventRecord(g->results_ready, s));

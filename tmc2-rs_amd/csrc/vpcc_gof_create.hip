@@ -119,8 +119,8 @@ void describe_frame(const GofBuild& b, uint32_t i, char* arena, char* const bloc
   D.patches = (b.g->general || !b.g->plan_in_lds) ? (const DevPatch*)(arena + o.patches) : nullptr;
   D.vblocks = D.patches ? (VBlock*)(arena + o.vblocks) : nullptr;
   D.block_to_patch = (uint32_t*)(arena + o.b2p);
-  D.vb_count = b.g->general ? (uint32_t*)(arena + o.vb_count) : nullptr;
-  D.vb_offset = b.g->general ? (uint32_t*)(arena + o.vb_offset) : nullptr;
+  D.vb_count = b.g->general ? (uint32_t*)(arena + o.vb_count) : nullptr;      // (the units' 64-bit status words)
+  D.vb_offset = nullptr;
   D.out_xyz = (vpcc_point3*)(outputs + o.xyz);
   D.out_rgb = F.attribute_count ? (vpcc_color3*)(outputs + o.rgb) : nullptr;
   D.out_patch = (b.flags & VPCC_GOF_WANT_PATCH_INDEX) ? (uint16_t*)(outputs + o.pidx) : nullptr;

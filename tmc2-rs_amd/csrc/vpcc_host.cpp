@@ -298,6 +298,12 @@ void layout_gof(const GofLayoutRequest& rq, GofLayout* Lp) {
   L.total = align_up(L.total, 8);
   G.scan = L.total;
   L.total += sizeof(uint64_t) * std::max<size_t>(scan_words, 1);
+  // ... and of the general sequence: one 64-bit status word per unit of up to 256 pixels (they carry the launch generation:
+  // zeroed once with the rest of the region, they read as "of no launch")
+  for (uint32_t i = 0; i < n; ++i) {
+    G.f[i].vb_count = L.total;
+    if (rq.general_records) L.total += sizeof(uint64_t) * general_units(rq.frames[i].occupancy_resolution, rq.shapes[i].n_vblocks);
+  }
   G.ctrl_bytes = L.total - G.ctrl_begin;
   L.total = align_up(L.total, 256);
   // block_to_patch of all frames contiguous: one memset per launch where it is cleared in global memory
@@ -315,8 +321,7 @@ void layout_gof(const GofLayoutRequest& rq, GofLayout* Lp) {
     const size_t vb = std::max<size_t>(S.n_vblocks, 1);
     o.items = rq.tile_records ? L.take(sizeof(TileItem) * (((S.tile_bound + kTileItemsPerGroup - 1) / kTileItemsPerGroup) * kTileItemsPerGroup + kTileItemsPerGroup)) : 0;
     o.vblocks = rq.general_records ? L.take(sizeof(VBlock) * vb) : 0;
-    o.vb_count = rq.general_records ? L.take(sizeof(uint32_t) * vb) : 0;
-    o.vb_offset = rq.general_records ? L.take(sizeof(uint32_t) * vb) : 0;
+    o.vb_offset = 0;
     // output block: positions, colours, partition; + 4: the smoothing kernels read whole quads of points, so a quad that
     // begins inside an array must end in memory
     ArenaLayout& B = G.block[2 * gof_part_of(i) + 1];

@@ -2,10 +2,10 @@
 //
 // GENERAL kernel sequence (any orientation, any block size):
 //   k_block_owner  : block -> patch index      (reference src/codec.rs:205-250)
-//   k_count        : points per virtual block  (enumeration of src/codec.rs:352-480, counting only)
-//   k_scan         : exclusive prefix per frame
-//   k_emit         : ordered emission of xyz (src/codec.rs:517-565, src/decoder.rs:871-888) fused with
-//                    the attribute gather (src/codec.rs:569-658) and YUV->RGB (src/codec.rs:661-687)
+//   k_general      : ONE pass over the virtual blocks in emission order (src/codec.rs:352-480): every pixel is evaluated once
+//                    (src/codec.rs:517-565, src/decoder.rs:871-888), counted, ranked by a decoupled look-back over units of up to
+//                    256 pixels, and emitted — fused with the attribute gather (src/codec.rs:569-658) and YUV->RGB
+//                    (src/codec.rs:661-687) — through LDS as whole 16-byte pieces of the output arrays
 // The W x H occupancy map of src/codec.rs:288-301, point_to_pixel and colors16bit are never
 // materialised: occupancy is read through the low-resolution plane, and colour is fetched by the
 // thread that emits the point.
@@ -24,23 +24,32 @@
 namespace vpcc {
 
 // ------------------------------------------------------------ k_block_owner
-// One wave per virtual block.  non_zero_pixel > 0  <=>  any occupancy sample under the block's
-// R*R mapped pixels is non-zero; ascending-patch overwrite == max over the patches that write.
+// non_zero_pixel > 0  <=>  any occupancy sample under the block's R*R mapped pixels is non-zero; ascending-patch overwrite ==
+// max over the patches that write.  patch_to_canvas (src/decoder.rs:841-867) maps the block's R x R pixels onto an axis-aligned
+// R x R square of the canvas (the coefficients are a signed permutation), so the samples under them are a RECTANGLE of the
+// occupancy plane between the images of two opposite corners: (R / precision + 1)^2 samples at most — 16-25 for 16 x 16
+// blocks at precision 4, where walking the 256 pixels read every sample sixteen times (0.28 ms per 128 S-longdress frames;
+// now 0.02).  kLanes = 1: a thread per virtual block (small rectangles); 64: a wave per virtual block.
+template <uint32_t kLanes>
 __global__ __launch_bounds__(256) void k_block_owner(const DevFrame* __restrict__ frames, uint32_t first) {
   const DevFrame& f = frames[first + blockIdx.y];
-  const uint32_t vb = blockIdx.x * 4 + (threadIdx.x >> 6);
+  const uint32_t vb = kLanes == 1u ? blockIdx.x * 256u + threadIdx.x : blockIdx.x * 4u + (threadIdx.x >> 6);
   if (vb >= f.n_vblocks) return;
   const VBlock b = gload(f.vblocks + vb);
   const DevPatch p = gload(f.patches + b.patch);
-  const uint32_t R = f.R, RR = R * R;
-  bool any = false;
-  for (uint32_t i = lane_id(); i < RR; i += 64) {
-    const uint32_t u = b.u0 * R + (i % R), v = b.v0 * R + (i / R);
-    const int32_t x = p.ax_u * (int32_t)u + p.ax_v * (int32_t)v + p.cx;
-    const int32_t y = p.ay_u * (int32_t)u + p.ay_v * (int32_t)v + p.cy;
-    any |= gl(f.occ)[((uint32_t)y / f.prec) * f.occ_stride + ((uint32_t)x / f.prec)] != 0;
+  const int32_t R = (int32_t)f.R, ulo = (int32_t)b.u0 * R, vlo = (int32_t)b.v0 * R, uhi = ulo + R - 1, vhi = vlo + R - 1;
+  const int32_t xa = p.ax_u * ulo + p.ax_v * vlo + p.cx, xb = p.ax_u * uhi + p.ax_v * vhi + p.cx;
+  const int32_t ya = p.ay_u * ulo + p.ay_v * vlo + p.cy, yb = p.ay_u * uhi + p.ay_v * vhi + p.cy;
+  const uint32_t sx0 = (uint32_t)min(xa, xb) / f.prec, sx1 = (uint32_t)max(xa, xb) / f.prec;     // (inside the canvas: validate_frame)
+  const uint32_t sy0 = (uint32_t)min(ya, yb) / f.prec, sy1 = (uint32_t)max(ya, yb) / f.prec;
+  const uint32_t nx = sx1 - sx0 + 1u, total = nx * (sy1 - sy0 + 1u);
+  uint32_t any = 0;
+  for (uint32_t i = kLanes == 1u ? 0u : lane_id(); i < total; i += kLanes) {
+    const uint32_t sy = sy0 + i / nx, sx = sx0 + i % nx;
+    any |= gl(f.occ)[(size_t)sy * f.occ_stride + sx];
   }
-  if (__ballot(any) != 0ull && lane_id() == 0) atomicMax(f.block_to_patch + b.canvas_block, (uint32_t)b.patch + 1u);
+  const bool hit = kLanes == 1u ? any != 0u : (__ballot(any != 0u) != 0ull && lane_id() == 0);
+  if (hit) atomicMax(f.block_to_patch + b.canvas_block, (uint32_t)b.patch + 1u);
 }
 
 // ------------------------------------------------------------------ planning
@@ -86,8 +95,11 @@ constexpr uint32_t kPlanThreads = 1024;
 __device__ __forceinline__ uint32_t magic_of(uint32_t d) { return d > 1u ? (uint32_t)(0x100000000ull / d) + ((0x100000000ull % d) ? 1u : 0u) : 0u; }
 __device__ __forceinline__ uint32_t div_by(uint32_t a, uint32_t d, uint32_t magic) { return d > 1u ? __umulhi(a, magic) : a; }
 
-__global__ __launch_bounds__(kPlanThreads) void k_plan_tiles(DevFrame* __restrict__ frames, uint32_t first, uint32_t lds_bytes) {
-  DevFrame& f = frames[first + blockIdx.x];
+__global__ __launch_bounds__(kPlanThreads) void k_plan_tiles(DevFrame* frames_rw, uint32_t first, uint32_t lds_bytes) {
+  // The descriptor is read through the constant address space, once: through a plain reference every field is a generic
+  // load that may alias the LDS and the items the kernel stores — reloaded (a round trip to the L2 each) after every store.
+  DevFrame f;
+  __builtin_memcpy(&f, (const __attribute__((address_space(4))) void*)(frames_rw + first + blockIdx.x), sizeof f);
   if (!f.patch_items) return;                                              // (a frame of the general sequence)
   extern __shared__ uint32_t plan_lds[];
   __shared__ uint32_t wave_total[kPlanThreads / 64];
@@ -243,8 +255,9 @@ __global__ __launch_bounds__(kPlanThreads) void k_plan_tiles(DevFrame* __restric
       if (vb + 1u < v_hi) step(w, vb + 1u);
     }
   }
-  if (tid == 0) f.n_tiles = total;
-  for (uint32_t cb = tid; cb < nb; cb += kPlanThreads) glw(f.block_to_patch)[cb] = b2p[cb] & ~kPlanEmpty;
+  if (tid == 0) *glw(&frames_rw[first + blockIdx.x].n_tiles) = total;
+  VPCC_GLOBAL uint32_t* const out_b2p = glw(f.block_to_patch);
+  for (uint32_t cb = tid; cb < nb; cb += kPlanThreads) out_b2p[cb] = b2p[cb] & ~kPlanEmpty;
 }
 
 // Frames beyond k_plan_tiles' LDS, and the general sequence: the virtual blocks written out once per gof ...
@@ -327,117 +340,151 @@ void launch_plan_vblocks(DevFrame* d_frames, uint32_t first, uint32_t count, uin
   hipLaunchKernelGGL(k_plan_vblocks, dim3((max_vb + 255u) / 256u, count), dim3(256), 0, (hipStream_t)stream, d_frames, first);
 }
 
-// ------------------------------------------------------------------ k_count
-__global__ __launch_bounds__(256) void k_count(const DevFrame* __restrict__ frames, uint32_t first) {
-  const DevFrame& f = frames[first + blockIdx.y];
-  const uint32_t vb = blockIdx.x;
-  if (vb >= f.n_vblocks) return;
-  const VBlock b = gload(f.vblocks + vb);
-  __shared__ uint32_t wave_sum[4];
-  uint32_t total = 0;
-  if (gl(f.block_to_patch)[b.canvas_block] == (uint32_t)b.patch + 1u) {       // codec.rs:379
-    const DevPatch p = gload(f.patches + b.patch);
-    const uint32_t R = f.R, RR = R * R;
-    uint32_t mine = 0;
-    for (uint32_t i = threadIdx.x; i < RR; i += 256) {
-      const PixelOut o = eval_pixel(f, p, b.u0 * R + (i % R), b.v0 * R + (i / R));
-      mine += o.n;
-    }
-    for (int off = 32; off > 0; off >>= 1) mine += __shfl_down(mine, off, 64);
-    if (lane_id() == 0) wave_sum[threadIdx.x >> 6] = mine;
-    __syncthreads();
-    total = wave_sum[0] + wave_sum[1] + wave_sum[2] + wave_sum[3];
-  }
-  if (threadIdx.x == 0) glw(f.vb_count)[vb] = total;
-}
+// ---------------------------------------------------------------- k_general
+// The general sequence's single pass.  A UNIT is up to 256 consecutive pixels of the emission order: a raster chunk of one
+// virtual block (R*R >= 256), or floor(256 / (R*R)) whole virtual blocks; one workgroup per unit, one pixel per thread:
+//   1. evaluate the pixel (ownership of its block, occupancy, both depths: at most two points) — ONCE: the points stay in
+//      registers (rounds 1-4 counted in one kernel and evaluated everything again in another);
+//   2. rank inside the unit (ballots + wave totals); the unit's total is published as {generation, AGGREGATE, total};
+//   3. attribute gather + colour conversion while the predecessors finish;
+//   4. decoupled look-back (wave 0, 64 predecessors per step) -> the unit's first point index; published as PREFIX;
+//   5. the unit's points are laid out in LDS exactly as they will lie in memory — at the output address modulo 16 — and leave
+//      as whole aligned 16-byte pieces (non-temporal), the ragged first and last piece byte by byte: ~190 + 95 store
+//      instructions per unit of ~450 points where k_emit issued six 2-byte / 1-byte stores per point.
+// Units are dispatched in emission order (blockIdx.x fastest), so a unit only ever waits for units that were dispatched before
+// it.  Status words carry the launch generation: nothing is cleared between launches.
+namespace {
+constexpr uint32_t kGenThreads = 256;
+constexpr uint64_t kGenStatusShift = 32, kGenGenShift = 34;
+constexpr uint64_t kGenAggregate = 1ull << kGenStatusShift, kGenPrefix = 2ull << kGenStatusShift;
+constexpr uint32_t kGenSpinLimit = 1u << 24;
+__device__ __forceinline__ uint32_t gen_status(uint64_t s, uint32_t gen) { return (uint32_t)(s >> kGenGenShift) == gen ? (uint32_t)(s >> kGenStatusShift) & 3u : 0u; }
 
-// ------------------------------------------------------------------- k_scan
-// One workgroup per frame: exclusive prefix of vb_count (<= a few 10^4 entries).
-__global__ __launch_bounds__(1024) void k_scan(const DevFrame* __restrict__ frames, uint32_t first) {
-  const DevFrame& f = frames[first + blockIdx.x];
-  __shared__ uint32_t wsum[16];
-  __shared__ uint32_t carry_s;
-  if (threadIdx.x == 0) carry_s = 0;
+// `n` elements of `esize` bytes staged in `lds` (at byte offset shift = address of element `first` modulo 16) -> out + first * esize
+__device__ __forceinline__ void copy_out(const unsigned char* lds, unsigned char* out, size_t first, uint32_t n, uint32_t esize) {
+  typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+  if (!n) return;
+  VPCC_GLOBAL unsigned char* dst = (VPCC_GLOBAL unsigned char*)out + first * esize;
+  const uint32_t shift = (uint32_t)((uintptr_t)dst & 15u), end = shift + n * esize;
+  VPCC_GLOBAL unsigned char* base = dst - shift;                            // 16-byte aligned
+  for (uint32_t c = threadIdx.x * 16u; c < end; c += kGenThreads * 16u) {
+    if (c >= shift && c + 16u <= end) {
+      __builtin_nontemporal_store(*(const u32x4*)(lds + c), (VPCC_GLOBAL u32x4*)(base + c));
+    } else {
+      for (uint32_t k = max(c, shift); k < min(c + 16u, end); ++k) base[k] = lds[k];
+    }
+  }
+}
+}  // namespace
+
+__global__ __launch_bounds__(kGenThreads) void k_general(const DevFrame* __restrict__ frames, uint32_t first, uint32_t gen) {
+  const DevFrame& f = frames[first + blockIdx.y];
+  const uint32_t R = f.R, RR = R * R, n_vb = f.n_vblocks;
+  const uint32_t per = RR >= kGenThreads ? 0u : kGenThreads / RR;           // whole virtual blocks per unit (small blocks)
+  const uint32_t chunks = per ? 1u : (RR + kGenThreads - 1u) / kGenThreads; // units per virtual block (large blocks)
+  const uint32_t n_units = per ? (n_vb + per - 1u) / per : n_vb * chunks;
+  const uint32_t unit = blockIdx.x;
+  if (unit >= n_units) return;
+  __shared__ uint32_t wave_sum[4];
+  __shared__ uint32_t prefix_s;
+  __shared__ __attribute__((aligned(16))) unsigned char stage_xyz[2 * kGenThreads * 6 + 32];
+  __shared__ __attribute__((aligned(16))) unsigned char stage_rgb[2 * kGenThreads * 3 + 32];
+  __shared__ __attribute__((aligned(16))) unsigned char stage_idx[2 * kGenThreads * 2 + 32];
+  const uint32_t tid = threadIdx.x, wave = tid >> 6, lane = tid & 63u;
+  // 1. the thread's pixel
+  uint32_t vb, i;
+  bool active;
+  if (per) {
+    const uint32_t q = tid / RR;
+    vb = unit * per + q; i = tid - q * RR; active = q < per && vb < n_vb;
+  } else {
+    vb = unit / chunks; i = (unit - vb * chunks) * kGenThreads + tid; active = i < RR;
+  }
+  PixelOut o;
+  o.n = 0;
+  uint32_t patch = 0;
+  if (active) {
+    const VBlock b = gload(f.vblocks + vb);
+    patch = b.patch;
+    if (gl(f.block_to_patch)[b.canvas_block] == patch + 1u) {              // src/codec.rs:379
+      const DevPatch p = gload(f.patches + patch);
+      const uint32_t pv = (R & (R - 1u)) == 0u ? i >> (31u - (uint32_t)__builtin_clz(R)) : i / R, pu = i - pv * R;
+      o = eval_pixel(f, p, b.u0 * R + pu, b.v0 * R + pv);
+    }
+  }
+  // 2. rank inside the unit
+  const uint64_t m1 = __ballot(o.n >= 1), m2 = __ballot(o.n == 2);
+  const uint32_t before = mbcnt(m1) + mbcnt(m2);
+  if (lane == 0) wave_sum[wave] = (uint32_t)__popcll(m1) + (uint32_t)__popcll(m2);
   __syncthreads();
-  const uint32_t n = f.n_vblocks;
-  for (uint32_t base = 0; base < n; base += 1024) {
-    const uint32_t i = base + threadIdx.x;
-    const uint32_t c = i < n ? gl(f.vb_count)[i] : 0u;
-    uint32_t incl = c;
-    for (int off = 1; off < 64; off <<= 1) {
-      const uint32_t t = __shfl_up(incl, off, 64);
-      if ((int)lane_id() >= off) incl += t;
-    }
-    if (lane_id() == 63) wsum[threadIdx.x >> 6] = incl;
-    __syncthreads();
-    uint32_t wbase = 0;
-    for (uint32_t w = 0; w < (threadIdx.x >> 6); ++w) wbase += wsum[w];
-    const uint32_t carry = carry_s;
-    if (i < n) glw(f.vb_offset)[i] = carry + wbase + incl - c;
-    __syncthreads();
-    if (threadIdx.x == 1023) carry_s = carry + wbase + incl;
-    __syncthreads();
-  }
-  if (threadIdx.x == 0) *glw(f.n_points) = carry_s;
-}
-
-// ------------------------------------------------------------------- k_emit
-__global__ __launch_bounds__(256) void k_emit(const DevFrame* __restrict__ frames, uint32_t first) {
-  const DevFrame& f = frames[first + blockIdx.y];
-  const uint32_t vb = blockIdx.x;
-  if (vb >= f.n_vblocks) return;
-  if (gl(f.vb_count)[vb] == 0) return;
-  const VBlock b = gload(f.vblocks + vb);
-  const DevPatch p = gload(f.patches + b.patch);
-  __shared__ uint32_t wave_sum[4];
-  uint32_t base = gl(f.vb_offset)[vb];
-  const uint32_t R = f.R, RR = R * R;
-  const uint32_t wave = threadIdx.x >> 6;
-  for (uint32_t i0 = 0; i0 < RR; i0 += 256) {                                  // raster chunks keep the order
-    const uint32_t i = i0 + threadIdx.x;
-    PixelOut o;
-    o.n = 0;
-    const uint32_t u = b.u0 * R + (i % R), v = b.v0 * R + (i / R);
-    if (i < RR) o = eval_pixel(f, p, u, v);
-    const uint64_t m1 = __ballot(o.n >= 1), m2 = __ballot(o.n == 2);
-    const uint32_t before = mbcnt(m1) + mbcnt(m2);
-    if (lane_id() == 0) wave_sum[wave] = (uint32_t)__popcll(m1) + (uint32_t)__popcll(m2);
-    __syncthreads();
-    uint32_t wbase = 0, tot = 0;
+  uint32_t wbase = 0, tot = 0;
 #pragma unroll
-    for (uint32_t w = 0; w < 4; ++w) {
-      const uint32_t s = wave_sum[w];
-      if (w < wave) wbase += s;
-      tot += s;
-    }
-    uint32_t k = base + wbase + before;
-    for (uint32_t j = 0; j < o.n; ++j, ++k) {
-      if (k >= f.capacity) break;                                               // never write past the caller's arrays
-      const Pt& pt = j == 0 ? o.p0 : o.p1;
-      vpcc_point3 q;
-      q.x = pt.c[0]; q.y = pt.c[1]; q.z = pt.c[2];
-      {   // non-temporal: the output stream must not evict the geometry k_count just pulled into the L2
-        VPCC_GLOBAL uint16_t* o = (VPCC_GLOBAL uint16_t*)(f.out_xyz + k);
-        __builtin_nontemporal_store(q.x, o);
-        __builtin_nontemporal_store(q.y, o + 1);
-        __builtin_nontemporal_store(q.z, o + 2);
-      }
-      if (f.out_patch) glw(f.out_patch)[k] = b.patch;                           // partition, codec.rs:452
-      if (f.has_attr) {                                                         // color_point_cloud, codec.rs:626-644
-        const uint32_t cidx = (o.y >> 1) * f.attr_cstride[j] + (o.x >> 1);     // chroma nearest neighbour
-        const uint16_t Y = gl(f.attr_y[j])[o.y * f.attr_stride[j] + o.x];
-        const uint16_t U = gl(f.attr_u[j])[cidx];
-        const uint16_t V = gl(f.attr_v[j])[cidx];
-        const vpcc_color3 c = yuv10_to_rgb8_fast(Y, U, V);
-        VPCC_GLOBAL uint8_t* oc = (VPCC_GLOBAL uint8_t*)(f.out_rgb + k);
-        __builtin_nontemporal_store(c.r, oc);
-        __builtin_nontemporal_store(c.g, oc + 1);
-        __builtin_nontemporal_store(c.b, oc + 2);
-      }
-    }
-    base += tot;
-    __syncthreads();
+  for (uint32_t w = 0; w < 4; ++w) {
+    const uint32_t t = wave_sum[w];
+    if (w < wave) wbase += t;
+    tot += t;
   }
+  uint64_t* const state = reinterpret_cast<uint64_t*>(f.vb_count);          // one {generation | status | value} word per unit
+  if (tid == 0)
+    __hip_atomic_store(glw(state) + unit, ((uint64_t)gen << kGenGenShift) | (unit ? kGenAggregate : kGenPrefix) | tot, __ATOMIC_RELAXED,
+                       __HIP_MEMORY_SCOPE_AGENT);
+  // 3. colours of the thread's points (color_point_cloud, src/codec.rs:626-644: layer j of the attribute video for point j)
+  vpcc_color3 col[2] = {};
+  if (f.has_attr)
+    for (uint32_t j = 0; j < o.n; ++j) {
+      const uint32_t cidx = (o.y >> 1) * f.attr_cstride[j] + (o.x >> 1);                          // chroma nearest neighbour
+      col[j] = yuv10_to_rgb8_fast(gl(f.attr_y[j])[o.y * f.attr_stride[j] + o.x], gl(f.attr_u[j])[cidx], gl(f.attr_v[j])[cidx]);
+    }
+  // 4. look-back
+  if (wave == 0 && unit) {
+    uint32_t excl = 0, spins = 0;
+    for (int32_t hi = (int32_t)unit - 1; hi >= 0;) {                        // predecessors hi, hi - 1, ..., 64 at a time
+      const int32_t u = hi - (int32_t)lane;
+      uint64_t s = u >= 0 ? __hip_atomic_load(gl(state) + u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : (((uint64_t)gen << kGenGenShift) | kGenPrefix);
+      uint32_t st = gen_status(s, gen);
+      const uint64_t pending = __ballot(st == 0u), prefix = __ballot(st == 2u);
+      const uint32_t first_prefix = prefix ? (uint32_t)__builtin_ctzll(prefix) : 64u;
+      // everything in front of the nearest PREFIX must have arrived
+      const uint64_t needed = first_prefix >= 63u ? ~0ull : ((2ull << first_prefix) - 1ull);
+      if (pending & needed) {
+        if (++spins > kGenSpinLimit) { if (lane == 0) atomicOr(f.error_flag, kErrorSpinLimit); break; }      // never in a healthy run
+        __builtin_amdgcn_s_sleep(1);
+        continue;
+      }
+      uint32_t v = lane <= first_prefix ? (uint32_t)s : 0u;
+      for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+      excl += v;
+      if (prefix) break;
+      hi -= 64;
+    }
+    if (lane == 0) {
+      prefix_s = excl;
+      __hip_atomic_store(glw(state) + unit, ((uint64_t)gen << kGenGenShift) | kGenPrefix | (uint64_t)(excl + tot), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+  } else if (tid == 0 && unit == 0) {
+    prefix_s = 0;
+  }
+  __syncthreads();
+  const uint32_t base = prefix_s;
+  if (unit == n_units - 1u && tid == 0) *glw(f.n_points) = base + tot;
+  // 5. the unit's points [base, base + tot), clipped to the caller's capacity, laid out in LDS as they will lie in memory
+  const uint32_t lo = min(base, f.capacity), hi_pt = min(base + tot, f.capacity), n_out = hi_pt - lo;
+  const uint32_t sx = (uint32_t)((uintptr_t)((const unsigned char*)f.out_xyz + (size_t)lo * 6u) & 15u);
+  const uint32_t sc = (uint32_t)((uintptr_t)((const unsigned char*)f.out_rgb + (size_t)lo * 3u) & 15u);
+  const uint32_t si = (uint32_t)((uintptr_t)((const unsigned char*)f.out_patch + (size_t)lo * 2u) & 15u);
+  uint32_t k = wbase + before;                                             // rank inside the unit
+  for (uint32_t j = 0; j < o.n; ++j, ++k) {
+    if (k >= n_out) break;                                                 // (capacity)
+    const Pt& pt = j == 0 ? o.p0 : o.p1;
+    uint16_t* q = (uint16_t*)(stage_xyz + sx + 6u * k);                    // (2-byte aligned: arrays are 256-byte aligned, elements 6 bytes)
+    q[0] = pt.c[0]; q[1] = pt.c[1]; q[2] = pt.c[2];
+    if (f.has_attr) { unsigned char* c = stage_rgb + sc + 3u * k; c[0] = col[j].r; c[1] = col[j].g; c[2] = col[j].b; }
+    if (f.out_patch) *(uint16_t*)(stage_idx + si + 2u * k) = (uint16_t)patch;                      // partition, codec.rs:452
+  }
+  __syncthreads();
+  copy_out(stage_xyz, (unsigned char*)f.out_xyz, lo, n_out, 6u);
+  if (f.has_attr) copy_out(stage_rgb, (unsigned char*)f.out_rgb, lo, n_out, 3u);
+  if (f.out_patch) copy_out(stage_idx, (unsigned char*)f.out_patch, lo, n_out, 2u);
 }
 
 // ---------------------------------------------------- k_upsample_occupancy
@@ -450,21 +497,16 @@ __global__ __launch_bounds__(256) void k_upsample_occupancy(const DevFrame* __re
 }
 
 // ----------------------------------------------------------------- launchers
-void launch_block_owner(const DevFrame* d_frames, uint32_t first, uint32_t count, uint32_t max_vb, void* stream) {
+void launch_block_owner(const DevFrame* d_frames, uint32_t first, uint32_t count, uint32_t max_vb, uint32_t max_samples, void* stream) {
   if (!count || !max_vb) return;
-  hipLaunchKernelGGL(k_block_owner, dim3((max_vb + 3) / 4, count), dim3(256), 0, (hipStream_t)stream, d_frames, first);
+  if (max_samples <= 32u)
+    hipLaunchKernelGGL(k_block_owner<1>, dim3((max_vb + 255u) / 256u, count), dim3(256), 0, (hipStream_t)stream, d_frames, first);
+  else
+    hipLaunchKernelGGL(k_block_owner<64>, dim3((max_vb + 3) / 4, count), dim3(256), 0, (hipStream_t)stream, d_frames, first);
 }
-void launch_count(const DevFrame* d_frames, uint32_t first, uint32_t count, uint32_t max_vb, void* stream) {
-  if (!count || !max_vb) return;
-  hipLaunchKernelGGL(k_count, dim3(max_vb, count), dim3(256), 0, (hipStream_t)stream, d_frames, first);
-}
-void launch_scan(const DevFrame* d_frames, uint32_t first, uint32_t count, void* stream) {
-  if (!count) return;
-  hipLaunchKernelGGL(k_scan, dim3(count), dim3(1024), 0, (hipStream_t)stream, d_frames, first);
-}
-void launch_emit(const DevFrame* d_frames, uint32_t first, uint32_t count, uint32_t max_vb, void* stream) {
-  if (!count || !max_vb) return;
-  hipLaunchKernelGGL(k_emit, dim3(max_vb, count), dim3(256), 0, (hipStream_t)stream, d_frames, first);
+void launch_general(const DevFrame* d_frames, uint32_t first, uint32_t count, uint32_t max_units, uint32_t gen, void* stream) {
+  if (!count || !max_units) return;
+  hipLaunchKernelGGL(k_general, dim3(max_units, count), dim3(kGenThreads), 0, (hipStream_t)stream, d_frames, first, gen);
 }
 // Plane ingest by the GPU itself: every workgroup pulls 64-KB pieces of page-locked HOST memory over PCIe (zero-copy
 // reads, 16 B per lane, coalesced) and stores them in HBM.  One launch moves all planes of a gof: 57 GB/s with 64

@@ -227,7 +227,7 @@ extern "C" int vpcc_generate_block_to_patch(vpcc_ctx* ctx, const vpcc_frame_desc
   const size_t n = (size_t)g->shapes[0].bw * g->shapes[0].bh;
   if (n == 0) return VPCC_OK;
   HIP_TRY(ctx, hipMemsetAsync(g->d_b2p, 0, n * sizeof(uint32_t), s));
-  launch_block_owner(g->d_frames, 0, 1, g->shapes[0].n_vblocks, s);
+  launch_block_owner(g->d_frames, 0, 1, g->shapes[0].n_vblocks, 0xFFFFFFFFu, s);
   HIP_TRY(ctx, hipGetLastError());
   HIP_TRY(ctx, hipMemcpyAsync(block_to_patch_out, g->d_b2p, n * sizeof(uint32_t), hipMemcpyDeviceToHost, s));
   HIP_TRY(ctx, hipStreamSynchronize(s));
