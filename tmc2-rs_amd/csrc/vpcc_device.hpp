@@ -245,13 +245,15 @@ void launch_block_owner(const DevFrame* d_frames, uint32_t first, uint32_t count
                         void* stream);
 // The general sequence's single pass; a frame has general_units(R, virtual blocks) units of up to 256 pixels each, and one
 // 64-bit status word per unit (DevFrame::vb_count).  gen: the gof's launch counter (tags the status words).
+constexpr uint32_t kGenUnitsPerGroup = 8;          // units a workgroup of k_general takes: one status word per group
 VPCC_HD inline uint32_t general_units(uint32_t R, uint32_t n_vblocks) {
   const uint64_t RR = (uint64_t)R * R;
   if (RR >= 256u) return (uint32_t)(n_vblocks * ((RR + 255u) / 256u));
   const uint32_t per = (uint32_t)(256u / RR);
   return (n_vblocks + per - 1u) / per;
 }
-void launch_general(const DevFrame* d_frames, uint32_t first, uint32_t count, uint32_t max_units, uint32_t gen, void* stream);
+// resident_wgs: workgroups of k_general the device holds at a time (4 per CU)
+void launch_general(const DevFrame* d_frames, uint32_t first, uint32_t count, uint32_t max_units, uint32_t gen, uint32_t resident_wgs, void* stream);
 // Where the workgroups of one tile-kernel launch start (kernel argument, by value).  A workgroup stays with its
 // frame; frames differ in size (S-longdress +-5 %, S-owlii +-11 % between the largest frame and the mean), so the
 // resident workgroups of an XCD are shared out among its frames in proportion to their tile counts instead of

@@ -145,7 +145,7 @@ extern "C" int vpcc_gof_reconstruct(vpcc_gof* g, uint32_t first, uint32_t count,
   launch_block_owner(g->d_frames, first, count, max_vb, max_samples, s);
   T.end();
   T.begin("k_general");
-  launch_general(g->d_frames, first, count, max_units, g->generation, s);
+  launch_general(g->d_frames, first, count, max_units, g->generation, ctx->resident_tile_wgs_per_xcd * 8u, s);
   T.end();
   HIP_TRY(ctx, hipGetLastError());
   HIP_TRY(ctx, hipEventRecord(g->results_ready, s));

@@ -89,6 +89,12 @@ __device__ __forceinline__ bool block_occupied(const DevFrame& f, uint32_t cb) {
 //      block_to_patch goes to global memory for whoever asks (vpcc_gof_block_to_patch).
 constexpr uint32_t kPlanEmpty = 0x80000000u;
 constexpr uint32_t kPlanThreads = 1024;
+#ifdef VPCC_PLAN_STAMPS                                   // tools/exp_plan_stamps.py: where k_plan_tiles' time goes (never in the product)
+__device__ unsigned long long g_plan_stamps[16];
+#define VPCC_STAMP(k) do { if (blockIdx.x == 0 && threadIdx.x == 0) g_plan_stamps[k] = __builtin_amdgcn_s_memtime(); } while (0)
+#else
+#define VPCC_STAMP(k) do { } while (0)
+#endif
 // floor(a / d) for a * d < 2^32 by one multiply-high with m = ceil(2^32 / d) (d >= 2; d == 1: the caller's business): the
 // kernel is ONE workgroup per frame, and the ~40 instructions of a 32-bit division per block and per virtual block were most
 // of its time.  Here a < 32768 (canvas blocks of a frame that fits the LDS) and d <= 2048.
@@ -98,6 +104,7 @@ __device__ __forceinline__ uint32_t div_by(uint32_t a, uint32_t d, uint32_t magi
 __global__ __launch_bounds__(kPlanThreads) void k_plan_tiles(DevFrame* frames_rw, uint32_t first, uint32_t lds_bytes) {
   // The descriptor is read through the constant address space, once: through a plain reference every field is a generic
   // load that may alias the LDS and the items the kernel stores — reloaded (a round trip to the L2 each) after every store.
+  VPCC_STAMP(0);
   DevFrame f;
   __builtin_memcpy(&f, (const __attribute__((address_space(4))) void*)(frames_rw + first + blockIdx.x), sizeof f);
   if (!f.patch_items) return;                                              // (a frame of the general sequence)
@@ -170,7 +177,9 @@ __global__ __launch_bounds__(kPlanThreads) void k_plan_tiles(DevFrame* frames_rw
   } else {
     for (uint32_t cb = tid; cb < nb; cb += kPlanThreads) b2p[cb] = block_occupied(f, cb) ? 0u : kPlanEmpty;
   }
+  VPCC_STAMP(1);
   __syncthreads();
+  VPCC_STAMP(2);
   // Thread t walks the virtual blocks [t * per, (t + 1) * per): a CONTIGUOUS run of the emission order — located once (binary
   // search of vb_base, one division), then stepped: u0, v0, the patch.
   struct Walk {
@@ -210,7 +219,9 @@ __global__ __launch_bounds__(kPlanThreads) void k_plan_tiles(DevFrame* frames_rw
       if (vb + 1u < v_hi) step(w, vb + 1u);
     }
   }
+  VPCC_STAMP(3);
   __syncthreads();
+  VPCC_STAMP(4);
   // ordered compaction: the owners of a thread's run follow those of all threads before it
   uint32_t owners = 0, mine = 0;                                           // (a bit per virtual block of the run, up to 32 of them)
   {
@@ -229,7 +240,9 @@ __global__ __launch_bounds__(kPlanThreads) void k_plan_tiles(DevFrame* frames_rw
     if ((int)lane >= off) incl += t;
   }
   if (lane == 63u) wave_total[wave] = incl;
+  VPCC_STAMP(5);
   __syncthreads();
+  VPCC_STAMP(6);
   uint32_t at = incl - mine, total = 0;
   for (uint32_t w = 0; w < kPlanThreads / 64; ++w) {
     const uint32_t t = wave_total[w];
@@ -255,10 +268,17 @@ __global__ __launch_bounds__(kPlanThreads) void k_plan_tiles(DevFrame* frames_rw
       if (vb + 1u < v_hi) step(w, vb + 1u);
     }
   }
+  VPCC_STAMP(7);
   if (tid == 0) *glw(&frames_rw[first + blockIdx.x].n_tiles) = total;
   VPCC_GLOBAL uint32_t* const out_b2p = glw(f.block_to_patch);
   for (uint32_t cb = tid; cb < nb; cb += kPlanThreads) out_b2p[cb] = b2p[cb] & ~kPlanEmpty;
+  VPCC_STAMP(8);
 }
+#ifdef VPCC_PLAN_STAMPS
+extern "C" int vpcc_debug_plan_stamps(unsigned long long* out) {
+  return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_plan_stamps), sizeof(unsigned long long) * 16) == hipSuccess ? 0 : 1;
+}
+#endif
 
 // Frames beyond k_plan_tiles' LDS, and the general sequence: the virtual blocks written out once per gof ...
 __global__ __launch_bounds__(256) void k_plan_vblocks(DevFrame* __restrict__ frames, uint32_t first) {
@@ -342,7 +362,9 @@ void launch_plan_vblocks(DevFrame* d_frames, uint32_t first, uint32_t count, uin
 
 // ---------------------------------------------------------------- k_general
 // The general sequence's single pass.  A UNIT is up to 256 consecutive pixels of the emission order: a raster chunk of one
-// virtual block (R*R >= 256), or floor(256 / (R*R)) whole virtual blocks; one workgroup per unit, one pixel per thread:
+// virtual block (R*R >= 256), or floor(256 / (R*R)) whole virtual blocks; a workgroup takes a GROUP of kGenUnitsPerGroup
+// consecutive units, a pixel of each per thread (with one unit per workgroup the chain of dependent round trips — virtual
+// block, ownership, patch, occupancy, depths, look-back — was paid per 256 pixels: 2.5 ms per 128 S-longdress frames):
 //   1. evaluate the pixel (ownership of its block, occupancy, both depths: at most two points) — ONCE: the points stay in
 //      registers (rounds 1-4 counted in one kernel and evaluated everything again in another);
 //   2. rank inside the unit (ballots + wave totals); the unit's total is published as {generation, AGGREGATE, total};
@@ -383,65 +405,102 @@ __global__ __launch_bounds__(kGenThreads) void k_general(const DevFrame* __restr
   const uint32_t per = RR >= kGenThreads ? 0u : kGenThreads / RR;           // whole virtual blocks per unit (small blocks)
   const uint32_t chunks = per ? 1u : (RR + kGenThreads - 1u) / kGenThreads; // units per virtual block (large blocks)
   const uint32_t n_units = per ? (n_vb + per - 1u) / per : n_vb * chunks;
-  const uint32_t unit = blockIdx.x;
-  if (unit >= n_units) return;
-  __shared__ uint32_t wave_sum[4];
+  const uint32_t n_groups = (n_units + kGenUnitsPerGroup - 1u) / kGenUnitsPerGroup;
+  constexpr uint32_t kU = kGenUnitsPerGroup;
+  __shared__ uint32_t wave_sum[kU][4];
   __shared__ uint32_t prefix_s;
   __shared__ __attribute__((aligned(16))) unsigned char stage_xyz[2 * kGenThreads * 6 + 32];
   __shared__ __attribute__((aligned(16))) unsigned char stage_rgb[2 * kGenThreads * 3 + 32];
   __shared__ __attribute__((aligned(16))) unsigned char stage_idx[2 * kGenThreads * 2 + 32];
   const uint32_t tid = threadIdx.x, wave = tid >> 6, lane = tid & 63u;
-  // 1. the thread's pixel
-  uint32_t vb, i;
-  bool active;
-  if (per) {
-    const uint32_t q = tid / RR;
-    vb = unit * per + q; i = tid - q * RR; active = q < per && vb < n_vb;
-  } else {
-    vb = unit / chunks; i = (unit - vb * chunks) * kGenThreads + tid; active = i < RR;
-  }
-  PixelOut o;
-  o.n = 0;
-  uint32_t patch = 0;
-  if (active) {
-    const VBlock b = gload(f.vblocks + vb);
-    patch = b.patch;
-    if (gl(f.block_to_patch)[b.canvas_block] == patch + 1u) {              // src/codec.rs:379
-      const DevPatch p = gload(f.patches + patch);
-      const uint32_t pv = (R & (R - 1u)) == 0u ? i >> (31u - (uint32_t)__builtin_clz(R)) : i / R, pu = i - pv * R;
-      o = eval_pixel(f, p, b.u0 * R + pu, b.v0 * R + pv);
-    }
-  }
-  // 2. rank inside the unit
-  const uint64_t m1 = __ballot(o.n >= 1), m2 = __ballot(o.n == 2);
-  const uint32_t before = mbcnt(m1) + mbcnt(m2);
-  if (lane == 0) wave_sum[wave] = (uint32_t)__popcll(m1) + (uint32_t)__popcll(m2);
-  __syncthreads();
-  uint32_t wbase = 0, tot = 0;
+  const uint32_t log2R = (R & (R - 1u)) == 0u ? 31u - (uint32_t)__builtin_clz(R) : 0xFFu;
+  // The frame's workgroups take its groups in turn, each in ascending order (group g waits for groups before it only: they
+  // belong to workgroups that are resident — the frame's workgroups are dispatched together, blockIdx.x fastest — and that
+  // publish their totals before they wait for anything).  One workgroup per group left the chip two thirds empty: a group's
+  // 10 us were over before the dispatcher had placed the next workgroups (66 000 of them per 128 S-longdress frames).
+  for (uint32_t group = blockIdx.x; group < n_groups; group += gridDim.x) {
+  // 1. the thread's pixel of each of the group's units: all of them evaluated before anything is waited for
+  // (packed: a unit costs a thread 7 registers until it is emitted — x | y << 16 of each point, z0 | z1 << 16, the canvas pixel,
+  // patch | points << 16 — and two for its colours)
+  uint32_t pxy[kU][2], pz[kU], cxy[kU], patch_n[kU];
 #pragma unroll
-  for (uint32_t w = 0; w < 4; ++w) {
-    const uint32_t t = wave_sum[w];
-    if (w < wave) wbase += t;
-    tot += t;
-  }
-  uint64_t* const state = reinterpret_cast<uint64_t*>(f.vb_count);          // one {generation | status | value} word per unit
-  if (tid == 0)
-    __hip_atomic_store(glw(state) + unit, ((uint64_t)gen << kGenGenShift) | (unit ? kGenAggregate : kGenPrefix) | tot, __ATOMIC_RELAXED,
-                       __HIP_MEMORY_SCOPE_AGENT);
-  // 3. colours of the thread's points (color_point_cloud, src/codec.rs:626-644: layer j of the attribute video for point j)
-  vpcc_color3 col[2] = {};
-  if (f.has_attr)
-    for (uint32_t j = 0; j < o.n; ++j) {
-      const uint32_t cidx = (o.y >> 1) * f.attr_cstride[j] + (o.x >> 1);                          // chroma nearest neighbour
-      col[j] = yuv10_to_rgb8_fast(gl(f.attr_y[j])[o.y * f.attr_stride[j] + o.x], gl(f.attr_u[j])[cidx], gl(f.attr_v[j])[cidx]);
+  for (uint32_t j = 0; j < kU; ++j) {
+    const uint32_t unit = group * kU + j;
+    uint32_t vb, i;
+    bool active;
+    if (per) {
+      const uint32_t q = tid / RR;
+      vb = unit * per + q; i = tid - q * RR; active = q < per && vb < n_vb;
+    } else {
+      vb = unit / chunks; i = (unit - vb * chunks) * kGenThreads + tid; active = i < RR && vb < n_vb;
     }
+    pxy[j][0] = pxy[j][1] = pz[j] = cxy[j] = patch_n[j] = 0;
+    if (active && unit < n_units) {
+      const VBlock b = gload(f.vblocks + vb);
+      patch_n[j] = b.patch;
+      if (gl(f.block_to_patch)[b.canvas_block] == (uint32_t)b.patch + 1u) { // src/codec.rs:379
+        const DevPatch p = gload(f.patches + b.patch);
+        const uint32_t pv = log2R != 0xFFu ? i >> log2R : i / R, pu = i - pv * R;
+        const PixelOut o = eval_pixel(f, p, b.u0 * R + pu, b.v0 * R + pv);
+        if (o.n) {
+          pxy[j][0] = (uint32_t)o.p0.c[0] | ((uint32_t)o.p0.c[1] << 16);
+          pz[j] = o.p0.c[2];
+          cxy[j] = o.x | (o.y << 16);                                       // (canvas sides <= 32768)
+          if (o.n > 1u) { pxy[j][1] = (uint32_t)o.p1.c[0] | ((uint32_t)o.p1.c[1] << 16); pz[j] |= (uint32_t)o.p1.c[2] << 16; }
+          patch_n[j] |= o.n << 16;
+        }
+      }
+    }
+  }
+  // 2. ranks inside the units
+  uint32_t before[kU];
+#pragma unroll
+  for (uint32_t j = 0; j < kU; ++j) {
+    const uint64_t m1 = __ballot((patch_n[j] >> 16) >= 1u), m2 = __ballot((patch_n[j] >> 16) == 2u);
+    before[j] = mbcnt(m1) + mbcnt(m2);
+    if (lane == 0) wave_sum[j][wave] = (uint32_t)__popcll(m1) + (uint32_t)__popcll(m2);
+  }
+  __syncthreads();
+  uint32_t ubase[kU], utot[kU], total = 0;                                   // a unit's first rank in the group, its points
+#pragma unroll
+  for (uint32_t j = 0; j < kU; ++j) {
+    uint32_t wb = 0, t = 0;
+#pragma unroll
+    for (uint32_t w = 0; w < 4; ++w) {
+      const uint32_t x = wave_sum[j][w];
+      if (w < wave) wb += x;
+      t += x;
+    }
+    ubase[j] = total;
+    utot[j] = t;
+    before[j] += wb;
+    total += t;
+  }
+  uint64_t* const state = reinterpret_cast<uint64_t*>(f.vb_count);          // one {generation | status | value} word per group
+  if (tid == 0)
+    __hip_atomic_store(glw(state) + group, ((uint64_t)gen << kGenGenShift) | (group ? kGenAggregate : kGenPrefix) | total, __ATOMIC_RELAXED,
+                       __HIP_MEMORY_SCOPE_AGENT);
+  // 3. colours of the thread's points (color_point_cloud, src/codec.rs:626-644: layer l of the attribute video for point l),
+  // r | g << 8 | b << 16
+  uint32_t col[kU][2];
+#pragma unroll
+  for (uint32_t j = 0; j < kU; ++j) {
+    col[j][0] = col[j][1] = 0;
+    if (f.has_attr)
+      for (uint32_t l = 0; l < (patch_n[j] >> 16); ++l) {
+        const uint32_t x = cxy[j] & 0xFFFFu, y = cxy[j] >> 16;
+        const uint32_t cidx = (y >> 1) * f.attr_cstride[l] + (x >> 1);                            // chroma nearest neighbour
+        const vpcc_color3 c = yuv10_to_rgb8_fast(gl(f.attr_y[l])[y * f.attr_stride[l] + x], gl(f.attr_u[l])[cidx], gl(f.attr_v[l])[cidx]);
+        col[j][l] = (uint32_t)c.r | ((uint32_t)c.g << 8) | ((uint32_t)c.b << 16);
+      }
+  }
   // 4. look-back
-  if (wave == 0 && unit) {
+  if (wave == 0 && group) {
     uint32_t excl = 0, spins = 0;
-    for (int32_t hi = (int32_t)unit - 1; hi >= 0;) {                        // predecessors hi, hi - 1, ..., 64 at a time
+    for (int32_t hi = (int32_t)group - 1; hi >= 0;) {                       // predecessors hi, hi - 1, ..., 64 at a time
       const int32_t u = hi - (int32_t)lane;
-      uint64_t s = u >= 0 ? __hip_atomic_load(gl(state) + u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : (((uint64_t)gen << kGenGenShift) | kGenPrefix);
-      uint32_t st = gen_status(s, gen);
+      const uint64_t s = u >= 0 ? __hip_atomic_load(gl(state) + u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : (((uint64_t)gen << kGenGenShift) | kGenPrefix);
+      const uint32_t st = gen_status(s, gen);
       const uint64_t pending = __ballot(st == 0u), prefix = __ballot(st == 2u);
       const uint32_t first_prefix = prefix ? (uint32_t)__builtin_ctzll(prefix) : 64u;
       // everything in front of the nearest PREFIX must have arrived
@@ -459,32 +518,39 @@ __global__ __launch_bounds__(kGenThreads) void k_general(const DevFrame* __restr
     }
     if (lane == 0) {
       prefix_s = excl;
-      __hip_atomic_store(glw(state) + unit, ((uint64_t)gen << kGenGenShift) | kGenPrefix | (uint64_t)(excl + tot), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      __hip_atomic_store(glw(state) + group, ((uint64_t)gen << kGenGenShift) | kGenPrefix | (uint64_t)(excl + total), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
-  } else if (tid == 0 && unit == 0) {
+  } else if (tid == 0 && group == 0) {
     prefix_s = 0;
   }
   __syncthreads();
   const uint32_t base = prefix_s;
-  if (unit == n_units - 1u && tid == 0) *glw(f.n_points) = base + tot;
-  // 5. the unit's points [base, base + tot), clipped to the caller's capacity, laid out in LDS as they will lie in memory
-  const uint32_t lo = min(base, f.capacity), hi_pt = min(base + tot, f.capacity), n_out = hi_pt - lo;
-  const uint32_t sx = (uint32_t)((uintptr_t)((const unsigned char*)f.out_xyz + (size_t)lo * 6u) & 15u);
-  const uint32_t sc = (uint32_t)((uintptr_t)((const unsigned char*)f.out_rgb + (size_t)lo * 3u) & 15u);
-  const uint32_t si = (uint32_t)((uintptr_t)((const unsigned char*)f.out_patch + (size_t)lo * 2u) & 15u);
-  uint32_t k = wbase + before;                                             // rank inside the unit
-  for (uint32_t j = 0; j < o.n; ++j, ++k) {
-    if (k >= n_out) break;                                                 // (capacity)
-    const Pt& pt = j == 0 ? o.p0 : o.p1;
-    uint16_t* q = (uint16_t*)(stage_xyz + sx + 6u * k);                    // (2-byte aligned: arrays are 256-byte aligned, elements 6 bytes)
-    q[0] = pt.c[0]; q[1] = pt.c[1]; q[2] = pt.c[2];
-    if (f.has_attr) { unsigned char* c = stage_rgb + sc + 3u * k; c[0] = col[j].r; c[1] = col[j].g; c[2] = col[j].b; }
-    if (f.out_patch) *(uint16_t*)(stage_idx + si + 2u * k) = (uint16_t)patch;                      // partition, codec.rs:452
+  if (group == n_groups - 1u && tid == 0) *glw(f.n_points) = base + total;
+  // 5. unit by unit: its points [first, first + utot), clipped to the caller's capacity, laid out in LDS as they will lie in memory
+#pragma unroll
+  for (uint32_t j = 0; j < kU; ++j) {
+    if (!utot[j]) continue;                                                 // (uniform: nothing to stage, no barrier)
+    const uint32_t u_first = base + ubase[j];
+    const uint32_t lo = min(u_first, f.capacity), n_out = min(u_first + utot[j], f.capacity) - lo;
+    const uint32_t sx = (uint32_t)((uintptr_t)((const unsigned char*)f.out_xyz + (size_t)lo * 6u) & 15u);
+    const uint32_t sc = (uint32_t)((uintptr_t)((const unsigned char*)f.out_rgb + (size_t)lo * 3u) & 15u);
+    const uint32_t si = (uint32_t)((uintptr_t)((const unsigned char*)f.out_patch + (size_t)lo * 2u) & 15u);
+    uint32_t k = before[j];                                                 // rank inside the unit
+    for (uint32_t l = 0; l < (patch_n[j] >> 16); ++l, ++k) {
+      if (k >= n_out) break;                                                // (capacity)
+      uint16_t* q = (uint16_t*)(stage_xyz + sx + 6u * k);                   // (2-byte aligned: arrays are 256-byte aligned, elements 6 bytes)
+      q[0] = (uint16_t)pxy[j][l]; q[1] = (uint16_t)(pxy[j][l] >> 16); q[2] = (uint16_t)(l ? pz[j] >> 16 : pz[j]);
+      if (f.has_attr) { unsigned char* c = stage_rgb + sc + 3u * k; c[0] = (unsigned char)col[j][l]; c[1] = (unsigned char)(col[j][l] >> 8); c[2] = (unsigned char)(col[j][l] >> 16); }
+      if (f.out_patch) *(uint16_t*)(stage_idx + si + 2u * k) = (uint16_t)patch_n[j];                 // partition, codec.rs:452
+    }
+    __syncthreads();
+    copy_out(stage_xyz, (unsigned char*)f.out_xyz, lo, n_out, 6u);
+    if (f.has_attr) copy_out(stage_rgb, (unsigned char*)f.out_rgb, lo, n_out, 3u);
+    if (f.out_patch) copy_out(stage_idx, (unsigned char*)f.out_patch, lo, n_out, 2u);
+    __syncthreads();                                                        // (the stage is the next unit's)
   }
-  __syncthreads();
-  copy_out(stage_xyz, (unsigned char*)f.out_xyz, lo, n_out, 6u);
-  if (f.has_attr) copy_out(stage_rgb, (unsigned char*)f.out_rgb, lo, n_out, 3u);
-  if (f.out_patch) copy_out(stage_idx, (unsigned char*)f.out_patch, lo, n_out, 2u);
+  __syncthreads();                                                          // (wave_sum and prefix_s are the next group's)
+  }
 }
 
 // ---------------------------------------------------- k_upsample_occupancy
@@ -504,9 +570,12 @@ void launch_block_owner(const DevFrame* d_frames, uint32_t first, uint32_t count
   else
     hipLaunchKernelGGL(k_block_owner<64>, dim3((max_vb + 3) / 4, count), dim3(256), 0, (hipStream_t)stream, d_frames, first);
 }
-void launch_general(const DevFrame* d_frames, uint32_t first, uint32_t count, uint32_t max_units, uint32_t gen, void* stream) {
+void launch_general(const DevFrame* d_frames, uint32_t first, uint32_t count, uint32_t max_units, uint32_t gen, uint32_t resident_wgs, void* stream) {
   if (!count || !max_units) return;
-  hipLaunchKernelGGL(k_general, dim3(max_units, count), dim3(kGenThreads), 0, (hipStream_t)stream, d_frames, first, gen);
+  // as many workgroups per frame as stay resident together over all frames of the launch (at least one, at most a group each)
+  const uint32_t groups = (max_units + kGenUnitsPerGroup - 1u) / kGenUnitsPerGroup;
+  const uint32_t per_frame = std::max(1u, std::min(groups, resident_wgs / count));
+  hipLaunchKernelGGL(k_general, dim3(per_frame, count), dim3(kGenThreads), 0, (hipStream_t)stream, d_frames, first, gen);
 }
 // Plane ingest by the GPU itself: every workgroup pulls 64-KB pieces of page-locked HOST memory over PCIe (zero-copy
 // reads, 16 B per lane, coalesced) and stores them in HBM.  One launch moves all planes of a gof: 57 GB/s with 64
