@@ -130,7 +130,11 @@ __device__ __forceinline__ PixelOut eval_pixel(const DevFrame& f, const DevPatch
   const int32_t y = p.ay_u * (int32_t)u + p.ay_v * (int32_t)v + p.cy;
   o.x = (uint32_t)x;
   o.y = (uint32_t)y;
-  const uint8_t occ = gl(f.occ)[(o.y / f.prec) * f.occ_stride + (o.x / f.prec)];   // src/codec.rs:288-301, 393
+  // (a precision that is a power of two — every stream's — by shift: the two 32-bit divisions were a quarter of the
+  // general sequence's vector instructions)
+  const bool pow2 = (1u << f.prec_shift) == f.prec;
+  const uint32_t oy = pow2 ? o.y >> f.prec_shift : o.y / f.prec, ox = pow2 ? o.x >> f.prec_shift : o.x / f.prec;
+  const uint8_t occ = gl(f.occ)[oy * f.occ_stride + ox];                             // src/codec.rs:288-301, 393
   if (occ == 0) return o;
   const uint32_t d0 = (uint32_t)(gl(f.geo[0])[o.y * f.geo_stride[0] + o.x] >> 2);  // depth / 4, codec.rs:534
   o.p0 = make_point(p, u, v, d0);

@@ -432,7 +432,7 @@ __global__ __launch_bounds__(kGenThreads) void k_general(const DevFrame* __restr
       const uint32_t q = tid / RR;
       vb = unit * per + q; i = tid - q * RR; active = q < per && vb < n_vb;
     } else {
-      vb = unit / chunks; i = (unit - vb * chunks) * kGenThreads + tid; active = i < RR && vb < n_vb;
+      vb = chunks == 1u ? unit : unit / chunks; i = (unit - vb * chunks) * kGenThreads + tid; active = i < RR && vb < n_vb;
     }
     pxy[j][0] = pxy[j][1] = pz[j] = cxy[j] = patch_n[j] = 0;
     if (active && unit < n_units) {
@@ -574,7 +574,8 @@ void launch_general(const DevFrame* d_frames, uint32_t first, uint32_t count, ui
   if (!count || !max_units) return;
   // as many workgroups per frame as stay resident together over all frames of the launch (at least one, at most a group each)
   const uint32_t groups = (max_units + kGenUnitsPerGroup - 1u) / kGenUnitsPerGroup;
-  const uint32_t per_frame = std::max(1u, std::min(groups, resident_wgs / count));
+  static const bool persistent = getenv("VPCC_GENERAL_PERSISTENT") != nullptr;      // (measured: 2.02 ms against 1.89 with a workgroup per group)
+  const uint32_t per_frame = persistent ? std::max(1u, std::min(groups, resident_wgs / count)) : groups;
   hipLaunchKernelGGL(k_general, dim3(per_frame, count), dim3(kGenThreads), 0, (hipStream_t)stream, d_frames, first, gen);
 }
 // Plane ingest by the GPU itself: every workgroup pulls 64-KB pieces of page-locked HOST memory over PCIe (zero-copy
