@@ -12,9 +12,9 @@ out=$1; shift
 mkdir -p "$out"; out=$(cd "$out" && pwd)
 R=$GRAFT_REPO_ROOT
 cd /tmp; export TMPDIR=/tmp
-rocprofv3 --kernel-trace --stats --output-format csv -d "$out/stats" -- python3 $R/bench.py --min-seconds 1.5 --no-cpu-baseline --no-end-to-end --no-other-configs --no-gpu-state --no-compare "$@" > "$out/stats.log" 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d "$out/stats" -- python3 $R/bench.py --min-seconds 1.5 --no-cpu-baseline --no-end-to-end --no-other-configs --no-gpu-state --no-compare --no-fresh-gof "$@" > "$out/stats.log" 2>&1
 pass() { name=$1; shift
-  rocprofv3 --kernel-trace --pmc "$@" --output-format csv -d "$out/pmc_$name" -- python3 $R/bench.py --steps 3 --warmup 1 --ramp-ms 0 --min-seconds 0 --no-cpu-baseline --no-verify --no-end-to-end --no-other-configs --no-gpu-state --no-compare $BENCH_PMC_ARGS > "$out/pmc_$name.log" 2>&1 || echo "pass $name failed"; }
+  rocprofv3 --kernel-trace --pmc "$@" --output-format csv -d "$out/pmc_$name" -- python3 $R/bench.py --steps 3 --warmup 1 --ramp-ms 0 --min-seconds 0 --no-cpu-baseline --no-verify --no-end-to-end --no-other-configs --no-gpu-state --no-compare --no-fresh-gof $BENCH_PMC_ARGS > "$out/pmc_$name.log" 2>&1 || echo "pass $name failed"; }
 BENCH_PMC_ARGS="$*"
 pass FETCH_SIZE FETCH_SIZE
 pass WRITE_SIZE WRITE_SIZE
