@@ -235,7 +235,9 @@ inline size_t plan_tiles_lds_launch_bytes(uint32_t blocks, uint32_t patches) {
   const size_t with = plan_tiles_lds_bytes(blocks, patches, true);
   return with <= kPlanLdsMax ? with : plan_tiles_lds_bytes(blocks, patches, false);
 }
-void launch_plan_tiles(DevFrame* d_frames, uint32_t first, uint32_t count, size_t lds_bytes, void* stream);
+// write_block_to_patch: the frames' block_to_patch leaves the LDS for global memory too (vpcc_gof_block_to_patch asks for it;
+// a launch does not: the tile kernel works from the items)
+void launch_plan_tiles(DevFrame* d_frames, uint32_t first, uint32_t count, size_t lds_bytes, bool write_block_to_patch, void* stream);
 void launch_plan_tiles_global(DevFrame* d_frames, uint32_t first, uint32_t count, uint32_t max_vb, uint32_t* d_b2p, size_t b2p_words, void* stream);
 // The virtual blocks of frames [first, first + count) from their patch tables (once per gof: they do not depend on the planes)
 void launch_plan_vblocks(DevFrame* d_frames, uint32_t first, uint32_t count, uint32_t max_vb, void* stream);

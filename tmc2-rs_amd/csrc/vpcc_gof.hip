@@ -103,7 +103,7 @@ extern "C" int vpcc_gof_reconstruct(vpcc_gof* g, uint32_t first, uint32_t count,
     }
     if (g->plan_in_lds) {
       T.begin("k_plan_tiles");
-      launch_plan_tiles(g->d_frames, first, count, plan_tiles_lds_launch_bytes(max_blocks, max_patches), s);
+      launch_plan_tiles(g->d_frames, first, count, plan_tiles_lds_launch_bytes(max_blocks, max_patches), false, s);
       T.end();
     } else {
       T.begin("k_plan_cover+items");
@@ -213,12 +213,21 @@ extern "C" int vpcc_gof_block_to_patch(vpcc_gof* g, uint32_t frame, uint32_t* bl
   if (!g->launched) return fail(ctx, VPCC_ERR_STATE, "no reconstruct issued: block_to_patch is built by every launch, from the planes as they are then");
   HIP_TRY(ctx, hipStreamWaitEvent(s, g->results_ready, 0));
   const size_t n = (size_t)g->shapes[frame].bw * g->shapes[frame].bh;
+  if (!g->general && g->plan_in_lds) {
+    // a launch keeps block_to_patch in the planning kernel's LDS (the tile kernel works from the items): planned once more
+    // for this frame, from the planes as they are now, with the map written out (the items it rewrites are the same)
+    launch_plan_tiles(g->d_frames, frame, 1, plan_tiles_lds_launch_bytes((uint32_t)n, g->shapes[frame].n_patches), true, s);
+    HIP_TRY(ctx, hipGetLastError());
+  }
   if (block_to_patch_out && n)
     HIP_TRY(ctx, hipMemcpyAsync(block_to_patch_out, g->h_frames[frame].block_to_patch, n * sizeof(uint32_t), hipMemcpyDeviceToHost, s));
   DevFrame d{};
   if (work_items_out) HIP_TRY(ctx, hipMemcpyAsync(&d, g->d_frames + frame, sizeof d, hipMemcpyDeviceToHost, s));
   HIP_TRY(ctx, hipStreamSynchronize(s));
   if (work_items_out) *work_items_out = g->general ? 0u : d.n_tiles;
+  // (the gof's next launch is ordered behind this: it shares the items the planning kernel rewrote)
+  HIP_TRY(ctx, hipEventRecord(g->results_ready, s));
+  g->last_stream = s;
   return VPCC_OK;
 }
 

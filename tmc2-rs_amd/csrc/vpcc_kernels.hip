@@ -98,10 +98,10 @@ __device__ unsigned long long g_plan_stamps[16];
 // floor(a / d) for a * d < 2^32 by one multiply-high with m = ceil(2^32 / d) (d >= 2; d == 1: the caller's business): the
 // kernel is ONE workgroup per frame, and the ~40 instructions of a 32-bit division per block and per virtual block were most
 // of its time.  Here a < 32768 (canvas blocks of a frame that fits the LDS) and d <= 2048.
-__device__ __forceinline__ uint32_t magic_of(uint32_t d) { return d > 1u ? (uint32_t)(0x100000000ull / d) + ((0x100000000ull % d) ? 1u : 0u) : 0u; }
+__device__ __forceinline__ uint32_t magic_of(uint32_t d) { return d > 1u ? 0xFFFFFFFFu / d + 1u : 0u; }      // ceil(2^32 / d), in 32 bits
 __device__ __forceinline__ uint32_t div_by(uint32_t a, uint32_t d, uint32_t magic) { return d > 1u ? __umulhi(a, magic) : a; }
 
-__global__ __launch_bounds__(kPlanThreads) void k_plan_tiles(DevFrame* frames_rw, uint32_t first, uint32_t lds_bytes) {
+__global__ __launch_bounds__(kPlanThreads) void k_plan_tiles(DevFrame* frames_rw, uint32_t first, uint32_t lds_bytes, uint32_t write_b2p) {
   // The descriptor is read through the constant address space, once: through a plain reference every field is a generic
   // load that may alias the LDS and the items the kernel stores — reloaded (a round trip to the L2 each) after every store.
   VPCC_STAMP(0);
@@ -180,8 +180,8 @@ __global__ __launch_bounds__(kPlanThreads) void k_plan_tiles(DevFrame* frames_rw
   VPCC_STAMP(1);
   __syncthreads();
   VPCC_STAMP(2);
-  // Thread t walks the virtual blocks [t * per, (t + 1) * per): a CONTIGUOUS run of the emission order — located once (binary
-  // search of vb_base, one division), then stepped: u0, v0, the patch.
+  // A thread walks a CONTIGUOUS run of the emission order: located once (binary search of vb_base, one division), then
+  // stepped: u0, v0, the patch.
   struct Walk {
     uint32_t p, u0, v0, su, org, next;       // patch, block of it, its size_u0, origin u0 | v0 << 16, first virtual block of the patch after it
     bool swap;
@@ -193,7 +193,7 @@ __global__ __launch_bounds__(kPlanThreads) void k_plan_tiles(DevFrame* frames_rw
   auto locate = [&](Walk& w, uint32_t vb) {
     enter(w, patch_of_vblock(pbase, P, vb));
     const uint32_t r = vb - pbase[w.p];
-    w.v0 = w.su > 1u ? r / w.su : r;           // (once per thread)
+    w.v0 = w.su > 1u ? r / w.su : r;           // (once per thread and round)
     w.u0 = r - w.v0 * w.su;
   };
   auto step = [&](Walk& w, uint32_t vb_next) { // to virtual block vb_next = the current one + 1 (< n)
@@ -207,12 +207,16 @@ __global__ __launch_bounds__(kPlanThreads) void k_plan_tiles(DevFrame* frames_rw
     const uint32_t bx = (w.org & 0xFFFFu) + (w.swap ? w.v0 : w.u0), by = (w.org >> 16) + (w.swap ? w.u0 : w.v0);
     return by * bw + bx;
   };
-  const uint32_t per = (n + kPlanThreads - 1u) / kPlanThreads;
-  const uint32_t v_lo = min(tid * per, n), v_hi = min(v_lo + per, n);
-  Walk w0{};
-  if (v_lo < v_hi) locate(w0, v_lo);
-  {
-    Walk w = w0;
+  // The virtual blocks in ROUNDS of up to 8 192: a thread's run in a round is at most eight blocks long, so that what the
+  // compaction learns of them fits its registers.
+  constexpr uint32_t kRun = 8u, kRound = kRun * kPlanThreads;
+  // 2. cover: LDS max(word, patch + 1) where the block is occupied
+  for (uint32_t r0 = 0; r0 < n; r0 += kRound) {
+    const uint32_t in_round = min(n - r0, kRound), per = (in_round + kPlanThreads - 1u) / kPlanThreads;
+    const uint32_t v_lo = r0 + min(tid * per, in_round), v_hi = r0 + min(tid * per + per, in_round);
+    if (v_lo >= v_hi) continue;
+    Walk w;
+    locate(w, v_lo);
     for (uint32_t vb = v_lo; vb < v_hi; ++vb) {
       const uint32_t cb = canvas_block(w);
       if (b2p[cb] != kPlanEmpty) atomicMax(&b2p[cb], w.p + 1u);           // (an empty block's word never changes)
@@ -222,56 +226,69 @@ __global__ __launch_bounds__(kPlanThreads) void k_plan_tiles(DevFrame* frames_rw
   VPCC_STAMP(3);
   __syncthreads();
   VPCC_STAMP(4);
-  // ordered compaction: the owners of a thread's run follow those of all threads before it
-  uint32_t owners = 0, mine = 0;                                           // (a bit per virtual block of the run, up to 32 of them)
-  {
-    Walk w = w0;
-    for (uint32_t vb = v_lo; vb < v_hi; ++vb) {
-      const bool own = b2p[canvas_block(w)] == w.p + 1u;
-      mine += own ? 1u : 0u;
-      if (vb - v_lo < 32u) owners |= (own ? 1u : 0u) << (vb - v_lo);
-      if (vb + 1u < v_hi) step(w, vb + 1u);
-    }
-  }
-  uint32_t incl = mine;                                                    // inclusive scan inside the wave, then over the waves
+  // 3. ordered compaction, round by round: the owners of a thread's run follow those of all threads before it
+  uint32_t base_items = 0;
+  for (uint32_t r0 = 0; r0 < n; r0 += kRound) {
+    const uint32_t in_round = min(n - r0, kRound), per = (in_round + kPlanThreads - 1u) / kPlanThreads;
+    const uint32_t v_lo = r0 + min(tid * per, in_round), v_hi = r0 + min(tid * per + per, in_round);
+    uint32_t own_pu[kRun], own_cv[kRun], mine = 0;                         // the run's owners: patch | u0 << 16, canvas block | v0 << 16
+    if (v_lo < v_hi) {
+      Walk w;
+      locate(w, v_lo);
 #pragma unroll
-  for (int off = 1; off < 64; off <<= 1) {
-    const uint32_t t = __shfl_up(incl, off, 64);
-    if ((int)lane >= off) incl += t;
-  }
-  if (lane == 63u) wave_total[wave] = incl;
-  VPCC_STAMP(5);
-  __syncthreads();
-  VPCC_STAMP(6);
-  uint32_t at = incl - mine, total = 0;
-  for (uint32_t w = 0; w < kPlanThreads / 64; ++w) {
-    const uint32_t t = wave_total[w];
-    if (w < wave) at += t;
-    total += t;
-  }
-  if (mine) {
-    Walk w = w0;
-    for (uint32_t vb = v_lo; vb < v_hi; ++vb) {
-      const uint32_t cb = canvas_block(w);
-      const bool own = vb - v_lo < 32u ? ((owners >> (vb - v_lo)) & 1u) != 0 : b2p[cb] == w.p + 1u;
-      if (own) {
-        TileItem t = tmpl_in_lds ? ptmpl[w.p] : gload(f.patch_items + w.p);
-        const uint32_t bx = (w.org & 0xFFFFu) + (w.swap ? w.v0 : w.u0), by = (w.org >> 16) + (w.swap ? w.u0 : w.v0);
+      for (uint32_t k = 0; k < kRun; ++k) {
+        const uint32_t vb = v_lo + k;
+        if (vb < v_hi) {
+          const uint32_t cb = canvas_block(w);
+          if (b2p[cb] == w.p + 1u) {
+            // (a compile-time index: the owners are kept in order by shifting the two short arrays, not by indexing them)
+#pragma unroll
+            for (uint32_t q = 0; q < kRun; ++q) if (q == mine) { own_pu[q] = w.p | (w.u0 << 16); own_cv[q] = cb | (w.v0 << 16); }
+            ++mine;
+          }
+          if (vb + 1u < v_hi) step(w, vb + 1u);
+        }
+      }
+    }
+    uint32_t incl = mine;                                                  // inclusive scan inside the wave, then over the waves
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+      const uint32_t t = __shfl_up(incl, off, 64);
+      if ((int)lane >= off) incl += t;
+    }
+    if (r0) __syncthreads();                                               // (wave_total is read by the round before)
+    if (lane == 63u) wave_total[wave] = incl;
+    VPCC_STAMP(5);
+    __syncthreads();
+    VPCC_STAMP(6);
+    uint32_t at = base_items + incl - mine;
+    for (uint32_t w = 0; w < kPlanThreads / 64; ++w) {
+      const uint32_t t = wave_total[w];
+      if (w < wave) at += t;
+      base_items += t;
+    }
+#pragma unroll
+    for (uint32_t q = 0; q < kRun; ++q) {
+      if (q < mine) {
+        const uint32_t pp = own_pu[q] & 0xFFFFu, u0 = own_pu[q] >> 16, cb = own_cv[q] & 0xFFFFu, v0 = own_cv[q] >> 16;
+        TileItem t = tmpl_in_lds ? ptmpl[pp] : gload(f.patch_items + pp);
+        const uint32_t by = div_by(cb, bw, bw_magic), bx = cb - by * bw;
         t.x0 = (uint16_t)(bx * 16u);
         t.y0 = (uint16_t)(by * 16u);
-        t.patch = (uint16_t)w.p;
-        t.tb += w.u0 * 16u * t.lod_x;
-        t.bb += w.v0 * 16u * t.lod_y;
-        gstore(f.tiles + at, t);
-        ++at;
+        t.patch = (uint16_t)pp;
+        t.tb += u0 * 16u * t.lod_x;
+        t.bb += v0 * 16u * t.lod_y;
+        gstore(f.tiles + at + q, t);
       }
-      if (vb + 1u < v_hi) step(w, vb + 1u);
     }
   }
   VPCC_STAMP(7);
-  if (tid == 0) *glw(&frames_rw[first + blockIdx.x].n_tiles) = total;
-  VPCC_GLOBAL uint32_t* const out_b2p = glw(f.block_to_patch);
-  for (uint32_t cb = tid; cb < nb; cb += kPlanThreads) out_b2p[cb] = b2p[cb] & ~kPlanEmpty;
+  if (tid == 0) *glw(&frames_rw[first + blockIdx.x].n_tiles) = base_items;
+  // block_to_patch leaves the LDS for whoever asked (vpcc_gof_block_to_patch plans once more for it)
+  if (write_b2p) {
+    VPCC_GLOBAL uint32_t* const out_b2p = glw(f.block_to_patch);
+    for (uint32_t cb = tid; cb < nb; cb += kPlanThreads) out_b2p[cb] = b2p[cb] & ~kPlanEmpty;
+  }
   VPCC_STAMP(8);
 }
 #ifdef VPCC_PLAN_STAMPS
@@ -340,13 +357,14 @@ __global__ __launch_bounds__(1024) void k_plan_items(DevFrame* __restrict__ fram
   }
   if (threadIdx.x == 0) f.n_tiles = base_s;
 }
-void launch_plan_tiles(DevFrame* d_frames, uint32_t first, uint32_t count, size_t lds_bytes, void* stream) {
+void launch_plan_tiles(DevFrame* d_frames, uint32_t first, uint32_t count, size_t lds_bytes, bool write_block_to_patch, void* stream) {
   if (!count) return;
   // (a frame beyond 64 KB of LDS: the function's limit on the calling thread's device is raised first — a microsecond)
   if (lds_bytes > (size_t(60) << 10))
     (void)hipFuncSetAttribute((const void*)k_plan_tiles, hipFuncAttributeMaxDynamicSharedMemorySize,
                               (int)kPlanLdsMax);
-  hipLaunchKernelGGL(k_plan_tiles, dim3(count), dim3(kPlanThreads), lds_bytes, (hipStream_t)stream, d_frames, first, (uint32_t)lds_bytes);
+  hipLaunchKernelGGL(k_plan_tiles, dim3(count), dim3(kPlanThreads), lds_bytes, (hipStream_t)stream, d_frames, first, (uint32_t)lds_bytes,
+                     write_block_to_patch ? 1u : 0u);
 }
 void launch_plan_tiles_global(DevFrame* d_frames, uint32_t first, uint32_t count, uint32_t max_vb, uint32_t* d_b2p, size_t b2p_words,
                               void* stream) {
