@@ -338,10 +338,11 @@ void Decoder::worker() {
     bool lock(const unsigned char* p, size_t bytes, size_t chunk) {
       const uintptr_t lo = (uintptr_t)p & ~uintptr_t(4095), hi = ((uintptr_t)p + bytes + 4095) & ~uintptr_t(4095);   // whole pages
       if (!chunk) chunk = hi - lo;
+      const size_t before = locked.size();
       for (uintptr_t at = lo; at < hi; at += chunk) {
         if (vpcc_host_pin(ctx, (const void*)at, (size_t)(std::min<uintptr_t>(at + chunk, hi) - at)) != VPCC_OK) {
-          for (const void* q : locked) (void)vpcc_host_unpin(ctx, q);      // all or nothing: a half page-locked input is of no use
-          locked.clear();
+          // all of this call or nothing (a half page-locked range is of no use); what earlier calls locked stays: uploads may run from it
+          while (locked.size() > before) { (void)vpcc_host_unpin(ctx, locked.back()); locked.pop_back(); }
           return false;
         }
         locked.push_back((const void*)at);
@@ -351,13 +352,47 @@ void Decoder::worker() {
     ~InputPins() { for (const void* q : locked) (void)vpcc_host_unpin(ctx, q); }
   } pins;
   lanes[0]->post([&pins](vpcc_ctx* c) { pins.ctx = c; return 0; }).get();
+  // Round 5: only the HEAD of the input — the first GOF's planes, when they lie at its start (a container; the raw videos of a
+  // V3C stream hold a GOF's planes in three places) — is page-locked in front of the first unit; the rest follows on the lane
+  // right behind that unit's launch, while its planes travel: the first frame no longer waits for 16-20 ms of page-locking, and
+  // the second unit's upload starts that much earlier (VPCC_DECODER_PIN_AT_ONCE=1: everything first, as before).
   bool pinned = false;
+  const unsigned char* rest = nullptr;                // where the part of the input that is page-locked later begins (null: none)
+  std::future<int> rest_locked;
+  struct WaitRest {                                   // the task works on `pins`: it has run before this scope is left, on every path
+    std::future<int>& f;
+    ~WaitRest() { if (f.valid()) f.wait(); }
+  } wait_rest{rest_locked};
   if (!file_.empty()) {
     const char* e = std::getenv("VPCC_DECODER_PIN_CHUNK_MB");
     const size_t chunk = e ? (size_t)std::strtoull(e, nullptr, 10) << 20 : 0;
-    pinned = lanes[0]->post([&](vpcc_ctx*) { return pins.lock(file_.data(), file_.size(), chunk) ? 0 : 1; }).get() == 0;
+    if (!chunk && gofs_.size() > 1 && !std::getenv("VPCC_DECODER_PIN_AT_ONCE")) {
+      const unsigned char* end0 = file_.data();
+      bool inside = true;
+      auto plane = [&](const void* ptr, size_t bytes) {
+        const unsigned char* q = (const unsigned char*)ptr;
+        inside = inside && q >= file_.data() && q + bytes <= file_.data() + file_.size();
+        end0 = std::max(end0, q + bytes);
+      };
+      for (const vpcc_frame_desc& fr : gofs_[0].frames) {
+        plane(fr.occupancy.y, (size_t)fr.occupancy.stride * fr.occupancy.height);
+        for (uint32_t m = 0; m < fr.map_count; ++m) {
+          plane(fr.geometry[m].y, (size_t)fr.geometry[m].stride * fr.geometry[m].height * 2);
+          if (fr.attribute_count) {
+            plane(fr.attribute[m].y, (size_t)fr.attribute[m].stride * fr.attribute[m].height * 2);
+            plane(fr.attribute[m].u, (size_t)fr.attribute[m].cstride * ((fr.attribute[m].height + 1) / 2) * 2);
+            plane(fr.attribute[m].v, (size_t)fr.attribute[m].cstride * ((fr.attribute[m].height + 1) / 2) * 2);
+          }
+        }
+      }
+      const uintptr_t cut = ((uintptr_t)end0 + (size_t(2) << 20) - 1) & ~((uintptr_t(2) << 20) - 1);      // a huge-page boundary
+      if (inside && cut < (uintptr_t)file_.data() + file_.size() / 4) rest = (const unsigned char*)cut;   // a small head: worth it
+    }
+    const size_t head = rest ? (size_t)(rest - file_.data()) : file_.size();
+    pinned = lanes[0]->post([&, head, chunk](vpcc_ctx*) { return pins.lock(file_.data(), head, chunk) ? 0 : 1; }).get() == 0;
+    if (!pinned) rest = nullptr;
   }
-  step("input page-locked");
+  step(rest ? "head of the input page-locked" : "input page-locked");
   struct Part {                                       // one device's share of one unit
     std::vector<vpcc_frame_desc> frames;
     vpcc_gof* g = nullptr;
@@ -506,6 +541,7 @@ void Decoder::worker() {
   // two units (first frame after 190 ms instead of 110, of which 50-130 are the page-locking of the input).
   auto launch_upto = [&](size_t last) {
     while (launched < units.size() && launched <= last) {
+      if (launched == 1 && rest_locked.valid() && rest_locked.get() != 0) pinned = false;   // (the rest could not be page-locked: plain uploads)
       inflight.emplace_back();
       inflight.back().smooth = smoothing_of(gofs_[units[launched].first]);
       for (size_t q = units[launched].first; q < units[launched].second; ++q)
@@ -517,6 +553,11 @@ void Decoder::worker() {
   for (size_t k = 0; k < units.size(); ++k) {         // while ssvu.get_v3c_unit_count() > 0, src/lib.rs:118
     if (pool_gib >= 2 && reservers.t.empty() && k == 3 && units.size() - k >= 8) reserve_pools();   // (never waited for)
     launch_upto(k);
+    if (k == 0 && rest) {                               // the rest of the input, on the lane, right behind the first unit's launch
+      const unsigned char* from = rest;
+      const size_t bytes = (size_t)(file_.data() + file_.size() - rest);
+      rest_locked = lanes[0]->post([&pins, from, bytes](vpcc_ctx*) { return pins.lock(from, bytes, 0) ? 0 : 1; });
+    }
     InFlight& cur = inflight.front();
     const size_t n = cur.frames.size();
     double slowest = 0;

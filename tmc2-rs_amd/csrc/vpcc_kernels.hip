@@ -90,8 +90,8 @@ __device__ __forceinline__ bool block_occupied(const DevFrame& f, uint32_t cb) {
 constexpr uint32_t kPlanEmpty = 0x80000000u;
 constexpr uint32_t kPlanThreads = 1024;
 #ifdef VPCC_PLAN_STAMPS                                   // tools/exp_plan_stamps.py: where k_plan_tiles' time goes (never in the product)
-__device__ unsigned long long g_plan_stamps[16];
-#define VPCC_STAMP(k) do { if (blockIdx.x == 0 && threadIdx.x == 0) g_plan_stamps[k] = __builtin_amdgcn_s_memtime(); } while (0)
+__device__ unsigned long long g_plan_stamps[32];       // [0, 16): workgroup 0, [16, 32): the launch's last workgroup; thread 0 of each
+#define VPCC_STAMP(k) do { if ((blockIdx.x == 0 || blockIdx.x == gridDim.x - 1) && threadIdx.x == 0) g_plan_stamps[(blockIdx.x ? 16 : 0) + (k)] = __builtin_amdgcn_s_memrealtime(); } while (0)
 #else
 #define VPCC_STAMP(k) do { } while (0)
 #endif
@@ -111,6 +111,7 @@ __global__ __launch_bounds__(kPlanThreads) void k_plan_tiles(DevFrame* frames_rw
   extern __shared__ uint32_t plan_lds[];
   __shared__ uint32_t wave_total[kPlanThreads / 64];
   const uint32_t bw = f.bw, nb = bw * f.bh, P = f.n_patches, n = f.n_vblocks;
+  VPCC_STAMP(9);
   const uint32_t bw_magic = magic_of(bw);
   uint32_t* const b2p = plan_lds;                                          // [nb]
   uint32_t* const pbase = plan_lds + nb;                                   // [P + 1]
@@ -141,6 +142,7 @@ __global__ __launch_bounds__(kPlanThreads) void k_plan_tiles(DevFrame* frames_rw
       }
     }
   }
+  VPCC_STAMP(10);
   for (uint32_t p = tid; p <= P; p += kPlanThreads) {
     pbase[p] = gl(f.vb_base)[p];
     if (p < P) {
@@ -150,6 +152,7 @@ __global__ __launch_bounds__(kPlanThreads) void k_plan_tiles(DevFrame* frames_rw
       if (tmpl_in_lds) ptmpl[p] = t;
     }
   }
+  VPCC_STAMP(11);
   if (words) {
 #pragma unroll
     for (uint32_t k = 0; k < 8u; ++k) {
@@ -293,7 +296,7 @@ __global__ __launch_bounds__(kPlanThreads) void k_plan_tiles(DevFrame* frames_rw
 }
 #ifdef VPCC_PLAN_STAMPS
 extern "C" int vpcc_debug_plan_stamps(unsigned long long* out) {
-  return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_plan_stamps), sizeof(unsigned long long) * 16) == hipSuccess ? 0 : 1;
+  return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_plan_stamps), sizeof(unsigned long long) * 32) == hipSuccess ? 0 : 1;
 }
 #endif
 
