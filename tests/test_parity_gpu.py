@@ -327,6 +327,60 @@ def test_pool_homes_hold_the_blocks_not_the_results():
     c.close()
 
 
+def test_pool_lends_memory_to_a_producer_of_device_planes():
+    """vpcc_ctx_pool_alloc / _free: a GPU video decoder's frame pool in the context's pool (frames 0-7 of a launch from home 0,
+    8-15 from home 1), handed to vpcc_gof_create as VPCC_MEM_DEVICE planes — what bench.py's `fresh_gof` leg does; the pool's
+    accounts follow, a pointer that is not the pool's is refused, memory still lent goes with the context.  And
+    vpcc_ctx_reserve_within (a budget for the search for a second home), vpcc_release_kept_pools."""
+    hip = C.CDLL("libamdhip64.so.7")
+    hip.hipMemcpy.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int]
+    c = recon.Context(0)
+    info = c.reserve(4, budget_ms=1.0)                              # (the budget is spent by the first allocation: no second home is looked for)
+    assert info["GiB"] >= 4 and info["kinds"] in (1, 2), info
+    frames = [cases.medium_frame(i) for i in range(10)]
+    refs = [ob.reconstruct(f)[1] for f in frames]
+    held, descs, keep = [], [], []
+    for r0 in (0, 8):
+        run = frames[r0:r0 + 8]
+        planes = [[f["occupancy"]] + [f["geometry"][m] for m in range(2)] + [pl for m in range(2) for pl in f["attribute"][m]] for f in run]
+        total = sum((pl.nbytes + 255) // 256 * 256 for fr in planes for pl in fr)
+        base = c.pool_alloc((r0 // 8) % 2, total)
+        assert base and base % 256 == 0
+        held.append(base)
+        at = base
+        for f, pls in zip(run, planes):
+            d, k = _abi.host_frame_desc(f)
+            keep.append(k)
+            ptrs = []
+            for pl in pls:
+                a = np.ascontiguousarray(pl)
+                assert hip.hipMemcpy(at, a.ctypes.data, a.nbytes, 1) == 0
+                ptrs.append(at)
+                at += (a.nbytes + 255) // 256 * 256
+            d.occupancy.y, d.occupancy.stride = ptrs[0], d.occupancy.width
+            for m in range(2):
+                d.geometry[m].y = ptrs[1 + m]
+                d.attribute[m].y, d.attribute[m].u, d.attribute[m].v = ptrs[3 + 3 * m], ptrs[4 + 3 * m], ptrs[5 + 3 * m]
+            descs.append(d)
+    lent = sum(c.pool_info()["in_use_MB"])
+    assert lent >= 2                                                 # (blocks are whole 2-MB pieces)
+    g = c.gof(None, capacity=200_000, memory=_abi.VPCC_MEM_DEVICE, descs=descs, flags=_abi.VPCC_GOF_PROFILE)
+    g.reconstruct()
+    assert [k for k, _ in g.kernel_times()] == ["k_plan_tiles", "k_recon_tiles"]
+    for i in (0, 7, 8, 9):
+        _check(g.download(i), refs[i])
+    assert sum(c.pool_info()["in_use_MB"]) > lent                    # the gof's outputs lie in the pool too
+    g.close()
+    assert sum(c.pool_info()["in_use_MB"]) == lent
+    with pytest.raises(recon.VpccError):
+        c.pool_free(held[0] + 256)                                   # not a pointer of vpcc_ctx_pool_alloc
+    c.pool_free(held[0])
+    assert 0 < sum(c.pool_info()["in_use_MB"]) < lent
+    c.close()                                                        # (held[1] goes with the context; the pool is whole again and kept)
+    assert c.lib.vpcc_release_kept_pools(0) == 1                     # ... until somebody gives it back to the driver
+    assert c.lib.vpcc_release_kept_pools(0) == 0
+
+
 def test_pool_too_small_falls_back():
     c = recon.Context(0)
     gib = c.reserve(2)["GiB"]                                       # (2; up to 6 with a second slab or a pool taken over)

@@ -141,22 +141,25 @@ class Lane {
   // point counts, destroy: whatever the runtime does at the first call of a kind (memory pools, copy queues, events: 8 ms
   // in front of a cold process's first unit) happens here, while start() reads the input.
   static void warm_up(vpcc_ctx* c) {
-    // (planes in page-locked memory, uploaded asynchronously as one stretch: the copy engine's queue for such copies is the
-    // slowest thing to come up)
+    // (planes in page-locked memory, uploaded asynchronously as one stretch of a few MB: the copy engine's queue for such
+    // copies is the slowest thing to come up — a stretch of a few hundred bytes goes another way and left 8 ms in front of a
+    // cold process's first unit)
+    constexpr uint32_t W = 1024, H = 512;
+    constexpr size_t kOcc = (size_t)(W / 4) * (H / 4), kLuma = (size_t)W * H * 2, kBytes = 4096 + kOcc + kLuma;
     void* mem = nullptr;
-    if (vpcc_host_alloc(c, 4096, &mem) != VPCC_OK) return;
-    std::memset(mem, 0, 4096);
+    if (vpcc_host_alloc(c, kBytes, &mem) != VPCC_OK) return;
+    std::memset(mem, 0, kBytes);
     uint8_t* occ = (uint8_t*)mem;
     occ[0] = 1;
-    const uint16_t* plane = (const uint16_t*)((char*)mem + 256);          // 16 x 16 samples, shared by every plane of the frame
+    const uint16_t* plane = (const uint16_t*)((char*)mem + ((kOcc + 4095) & ~size_t(4095)));   // W x H samples, shared by every plane of the frame
     vpcc_patch p{};
     p.size_u0 = p.size_v0 = 1; p.lod_x = p.lod_y = 1; p.tangent_axis = 1; p.bitangent_axis = 2;
     vpcc_frame_desc f{};
-    f.width = f.height = 16; f.occupancy_resolution = 16; f.occupancy_precision = 4; f.map_count = 2; f.absolute_d1 = 1; f.attribute_count = 1;
-    f.occupancy = vpcc_image_u8{occ, 4, 4, 4};
+    f.width = W; f.height = H; f.occupancy_resolution = 16; f.occupancy_precision = 4; f.map_count = 2; f.absolute_d1 = 1; f.attribute_count = 1;
+    f.occupancy = vpcc_image_u8{occ, W / 4, H / 4, W / 4};
     for (int m = 0; m < 2; ++m) {
-      f.geometry[m] = vpcc_image_u16{plane, nullptr, nullptr, 16, 16, 16, 8};
-      f.attribute[m] = vpcc_image_u16{plane, plane, plane, 16, 16, 16, 8};
+      f.geometry[m] = vpcc_image_u16{plane, nullptr, nullptr, W, H, W, W / 2};
+      f.attribute[m] = vpcc_image_u16{plane, plane, plane, W, H, W, W / 2};
     }
     f.patches = &p; f.patch_count = 1;
     vpcc_gof* g = nullptr;
