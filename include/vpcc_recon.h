@@ -298,12 +298,13 @@ int vpcc_gof_sync(vpcc_gof* gof);
 /* Per-frame point counts of the last reconstruct (synchronises). */
 int vpcc_gof_point_counts(vpcc_gof* gof, uint32_t* counts_out /* n_frames */);
 
-/* block_to_patch of frame `frame` as the last launch that covered the frame built it (src/codec.rs:205-250: 0 = unowned,
- * else patch index + 1; (width / R) x (height / R) entries) and the number of work items the single-pass kernel had for the
- * frame (0 for a gof of the general sequence).  Every vpcc_gof_reconstruct builds both on the device, on its stream, from
- * the occupancy plane as it is then (k_plan_tiles) — a gof that borrows the caller's device planes may be launched again
- * after new frames have been decoded into them.  VPCC_ERR_STATE before the first launch.  Synchronises; either out-pointer
- * may be NULL. */
+/* block_to_patch of frame `frame` (src/codec.rs:205-250: 0 = unowned, else patch index + 1; (width / R) x (height / R)
+ * entries) and the number of work items the single-pass kernel has for the frame (0 for a gof of the general sequence).
+ * Every vpcc_gof_reconstruct builds both on the device, on its stream, from the occupancy plane as it is then — a gof
+ * that borrows the caller's device planes may be launched again after new frames have been decoded into them.  A launch
+ * of the single-pass kernel keeps the map in its planning kernel's LDS (k_plan_tiles); this call plans the frame once
+ * more, from the planes as they are NOW, with the map written out (general sequence: the map of the last launch that
+ * covered the frame).  VPCC_ERR_STATE before the first launch.  Synchronises; either out-pointer may be NULL. */
 int vpcc_gof_block_to_patch(vpcc_gof* gof, uint32_t frame, uint32_t* block_to_patch_out, uint32_t* work_items_out);
 
 /* Device pointers of frame `frame`'s outputs (vpcc_point3[capacity],
