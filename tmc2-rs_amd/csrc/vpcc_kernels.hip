@@ -403,19 +403,34 @@ constexpr uint64_t kGenAggregate = 1ull << kGenStatusShift, kGenPrefix = 2ull <<
 constexpr uint32_t kGenSpinLimit = 1u << 24;
 __device__ __forceinline__ uint32_t gen_status(uint64_t s, uint32_t gen) { return (uint32_t)(s >> kGenGenShift) == gen ? (uint32_t)(s >> kGenStatusShift) & 3u : 0u; }
 
-// `n` elements of `esize` bytes staged in `lds` (at byte offset shift = address of element `first` modulo 16) -> out + first * esize
+// Workgroup barrier that orders LDS only: the waves of a workgroup hand each other nothing through global memory here, and
+// __syncthreads() — a fence over ALL address spaces — makes every wave wait for its outstanding output stores (s_waitcnt
+// vmcnt(0): a round trip to HBM) at each of a group's up to nineteen barriers.
+__device__ __forceinline__ void gen_sync_lds() {
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
+  __builtin_amdgcn_s_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
+}
+
+// `n` elements of `esize` bytes staged in `lds` (at byte offset shift = address of element `first` modulo 16) -> out + first * esize:
+// the whole 16-byte pieces by threads in turn, the ragged piece in front and the one behind a byte per thread (threads 0-15 /
+// 16-31) — no loop over bytes: with one, every wave that held an edge piece walked sixteen iterations per array and unit, and
+// that was most of the kernel's vector instructions.
 __device__ __forceinline__ void copy_out(const unsigned char* lds, unsigned char* out, size_t first, uint32_t n, uint32_t esize) {
   typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
   if (!n) return;
   VPCC_GLOBAL unsigned char* dst = (VPCC_GLOBAL unsigned char*)out + first * esize;
   const uint32_t shift = (uint32_t)((uintptr_t)dst & 15u), end = shift + n * esize;
   VPCC_GLOBAL unsigned char* base = dst - shift;                            // 16-byte aligned
-  for (uint32_t c = threadIdx.x * 16u; c < end; c += kGenThreads * 16u) {
-    if (c >= shift && c + 16u <= end) {
-      __builtin_nontemporal_store(*(const u32x4*)(lds + c), (VPCC_GLOBAL u32x4*)(base + c));
-    } else {
-      for (uint32_t k = max(c, shift); k < min(c + 16u, end); ++k) base[k] = lds[k];
-    }
+  const uint32_t full_lo = (shift + 15u) & ~15u, full_hi = end & ~15u;      // the whole pieces: [full_lo, full_hi)
+  for (uint32_t c = full_lo + threadIdx.x * 16u; c < full_hi; c += kGenThreads * 16u)
+    __builtin_nontemporal_store(*(const u32x4*)(lds + c), (VPCC_GLOBAL u32x4*)(base + c));
+  if (threadIdx.x < 16u) {                                                  // in front: [shift, min(full_lo, end))
+    const uint32_t k = full_lo - 16u + threadIdx.x;
+    if ((shift & 15u) && k >= shift && k < min(full_lo, end)) base[k] = lds[k];
+  } else if (threadIdx.x < 32u) {                                           // behind: [full_hi, end), unless the piece in front holds it
+    const uint32_t k = full_hi + (threadIdx.x - 16u);
+    if (full_hi >= full_lo && k < end) base[k] = lds[k];
   }
 }
 }  // namespace
@@ -481,7 +496,7 @@ __global__ __launch_bounds__(kGenThreads) void k_general(const DevFrame* __restr
     before[j] = mbcnt(m1) + mbcnt(m2);
     if (lane == 0) wave_sum[j][wave] = (uint32_t)__popcll(m1) + (uint32_t)__popcll(m2);
   }
-  __syncthreads();
+  gen_sync_lds();
   uint32_t ubase[kU], utot[kU], total = 0;                                   // a unit's first rank in the group, its points
 #pragma unroll
   for (uint32_t j = 0; j < kU; ++j) {
@@ -544,7 +559,7 @@ __global__ __launch_bounds__(kGenThreads) void k_general(const DevFrame* __restr
   } else if (tid == 0 && group == 0) {
     prefix_s = 0;
   }
-  __syncthreads();
+  gen_sync_lds();
   const uint32_t base = prefix_s;
   if (group == n_groups - 1u && tid == 0) *glw(f.n_points) = base + total;
   // 5. unit by unit: its points [first, first + utot), clipped to the caller's capacity, laid out in LDS as they will lie in memory
@@ -564,13 +579,13 @@ __global__ __launch_bounds__(kGenThreads) void k_general(const DevFrame* __restr
       if (f.has_attr) { unsigned char* c = stage_rgb + sc + 3u * k; c[0] = (unsigned char)col[j][l]; c[1] = (unsigned char)(col[j][l] >> 8); c[2] = (unsigned char)(col[j][l] >> 16); }
       if (f.out_patch) *(uint16_t*)(stage_idx + si + 2u * k) = (uint16_t)patch_n[j];                 // partition, codec.rs:452
     }
-    __syncthreads();
+    gen_sync_lds();
     copy_out(stage_xyz, (unsigned char*)f.out_xyz, lo, n_out, 6u);
     if (f.has_attr) copy_out(stage_rgb, (unsigned char*)f.out_rgb, lo, n_out, 3u);
     if (f.out_patch) copy_out(stage_idx, (unsigned char*)f.out_patch, lo, n_out, 2u);
-    __syncthreads();                                                        // (the stage is the next unit's)
+    gen_sync_lds();                                                        // (the stage is the next unit's)
   }
-  __syncthreads();                                                          // (wave_sum and prefix_s are the next group's)
+  gen_sync_lds();                                                          // (wave_sum and prefix_s are the next group's)
   }
 }
 
