@@ -518,17 +518,27 @@ __global__ __launch_bounds__(kGenThreads) void k_general(const DevFrame* __restr
                        __HIP_MEMORY_SCOPE_AGENT);
   // 3. colours of the thread's points (color_point_cloud, src/codec.rs:626-644: layer l of the attribute video for point l),
   // r | g << 8 | b << 16
+  // (the two layers written out, not a loop over a layer index: indexing the descriptor's arrays by a per-lane loop
+  // counter made the compiler fetch their fields with scalar loads inside a waterfall loop, per unit and layer)
   uint32_t col[kU][2];
+  const uint16_t* const ay0 = f.attr_y[0]; const uint16_t* const au0 = f.attr_u[0]; const uint16_t* const av0 = f.attr_v[0];
+  const uint16_t* const ay1 = f.attr_y[1]; const uint16_t* const au1 = f.attr_u[1]; const uint16_t* const av1 = f.attr_v[1];
+  const uint32_t as0 = f.attr_stride[0], as1 = f.attr_stride[1], ac0 = f.attr_cstride[0], ac1 = f.attr_cstride[1];
+  const bool has_attr = f.has_attr != 0;
 #pragma unroll
   for (uint32_t j = 0; j < kU; ++j) {
     col[j][0] = col[j][1] = 0;
-    if (f.has_attr)
-      for (uint32_t l = 0; l < (patch_n[j] >> 16); ++l) {
-        const uint32_t x = cxy[j] & 0xFFFFu, y = cxy[j] >> 16;
-        const uint32_t cidx = (y >> 1) * f.attr_cstride[l] + (x >> 1);                            // chroma nearest neighbour
-        const vpcc_color3 c = yuv10_to_rgb8_fast(gl(f.attr_y[l])[y * f.attr_stride[l] + x], gl(f.attr_u[l])[cidx], gl(f.attr_v[l])[cidx]);
-        col[j][l] = (uint32_t)c.r | ((uint32_t)c.g << 8) | ((uint32_t)c.b << 16);
-      }
+    const uint32_t np = patch_n[j] >> 16, x = cxy[j] & 0xFFFFu, y = cxy[j] >> 16;
+    if (has_attr && np >= 1u) {
+      const uint32_t cidx = (y >> 1) * ac0 + (x >> 1);                                            // chroma nearest neighbour
+      const vpcc_color3 c = yuv10_to_rgb8_fast(gl(ay0)[y * as0 + x], gl(au0)[cidx], gl(av0)[cidx]);
+      col[j][0] = (uint32_t)c.r | ((uint32_t)c.g << 8) | ((uint32_t)c.b << 16);
+    }
+    if (has_attr && np == 2u) {
+      const uint32_t cidx = (y >> 1) * ac1 + (x >> 1);
+      const vpcc_color3 c = yuv10_to_rgb8_fast(gl(ay1)[y * as1 + x], gl(au1)[cidx], gl(av1)[cidx]);
+      col[j][1] = (uint32_t)c.r | ((uint32_t)c.g << 8) | ((uint32_t)c.b << 16);
+    }
   }
   // 4. look-back
   if (wave == 0 && group) {
@@ -571,14 +581,15 @@ __global__ __launch_bounds__(kGenThreads) void k_general(const DevFrame* __restr
     const uint32_t sx = (uint32_t)((uintptr_t)((const unsigned char*)f.out_xyz + (size_t)lo * 6u) & 15u);
     const uint32_t sc = (uint32_t)((uintptr_t)((const unsigned char*)f.out_rgb + (size_t)lo * 3u) & 15u);
     const uint32_t si = (uint32_t)((uintptr_t)((const unsigned char*)f.out_patch + (size_t)lo * 2u) & 15u);
-    uint32_t k = before[j];                                                 // rank inside the unit
-    for (uint32_t l = 0; l < (patch_n[j] >> 16); ++l, ++k) {
-      if (k >= n_out) break;                                                // (capacity)
+    const uint32_t k0 = before[j], np = patch_n[j] >> 16;                   // rank inside the unit
+    auto put = [&](uint32_t k, uint32_t xy, uint32_t z, uint32_t c) {
       uint16_t* q = (uint16_t*)(stage_xyz + sx + 6u * k);                   // (2-byte aligned: arrays are 256-byte aligned, elements 6 bytes)
-      q[0] = (uint16_t)pxy[j][l]; q[1] = (uint16_t)(pxy[j][l] >> 16); q[2] = (uint16_t)(l ? pz[j] >> 16 : pz[j]);
-      if (f.has_attr) { unsigned char* c = stage_rgb + sc + 3u * k; c[0] = (unsigned char)col[j][l]; c[1] = (unsigned char)(col[j][l] >> 8); c[2] = (unsigned char)(col[j][l] >> 16); }
+      q[0] = (uint16_t)xy; q[1] = (uint16_t)(xy >> 16); q[2] = (uint16_t)z;
+      if (has_attr) { unsigned char* o = stage_rgb + sc + 3u * k; o[0] = (unsigned char)c; o[1] = (unsigned char)(c >> 8); o[2] = (unsigned char)(c >> 16); }
       if (f.out_patch) *(uint16_t*)(stage_idx + si + 2u * k) = (uint16_t)patch_n[j];                 // partition, codec.rs:452
-    }
+    };
+    if (np >= 1u && k0 < n_out) put(k0, pxy[j][0], pz[j], col[j][0]);      // (n_out: the caller's capacity)
+    if (np == 2u && k0 + 1u < n_out) put(k0 + 1u, pxy[j][1], pz[j] >> 16, col[j][1]);
     gen_sync_lds();
     copy_out(stage_xyz, (unsigned char*)f.out_xyz, lo, n_out, 6u);
     if (f.has_attr) copy_out(stage_rgb, (unsigned char*)f.out_rgb, lo, n_out, 3u);
