@@ -134,16 +134,20 @@ __device__ __forceinline__ PixelOut eval_pixel(const DevFrame& f, const DevPatch
   // general sequence's vector instructions)
   const bool pow2 = (1u << f.prec_shift) == f.prec;
   const uint32_t oy = pow2 ? o.y >> f.prec_shift : o.y / f.prec, ox = pow2 ? o.x >> f.prec_shift : o.x / f.prec;
+  // Occupancy and both depths are requested TOGETHER (the pixel lies inside the canvas and the planes cover it: validate_frame),
+  // and the pixel's points are built without a branch: with the depths behind `if (occ == 0) return` every occupied pixel paid
+  // two dependent round trips to memory, one per plane kind.
   const uint8_t occ = gl(f.occ)[oy * f.occ_stride + ox];                             // src/codec.rs:288-301, 393
-  if (occ == 0) return o;
   const uint32_t d0 = (uint32_t)(gl(f.geo[0])[o.y * f.geo_stride[0] + o.x] >> 2);  // depth / 4, codec.rs:534
+  const uint32_t d1 = (uint32_t)(gl(f.geo[1])[o.y * f.geo_stride[1] + o.x] >> 2);  // (one map: the descriptor's alias of layer 0)
   o.p0 = make_point(p, u, v, d0);
-  o.n = 1;
-  if (f.map_count > 1) {
-    const uint32_t d1 = (uint32_t)(gl(f.geo[1])[o.y * f.geo_stride[1] + o.x] >> 2);
+  o.p1 = o.p0;
+  uint32_t n = 1;
+  if (f.map_count > 1) {                                                           // (uniform)
     o.p1 = make_point1(f, p, u, v, o.p0, d1);
-    if (!same_point(o.p0, o.p1)) o.n = 2;                                      // codec.rs:422-427
+    n = same_point(o.p0, o.p1) ? 1u : 2u;                                          // codec.rs:422-427
   }
+  o.n = occ ? n : 0u;
   return o;
 }
 
