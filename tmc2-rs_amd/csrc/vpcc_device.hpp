@@ -247,7 +247,10 @@ void launch_block_owner(const DevFrame* d_frames, uint32_t first, uint32_t count
                         void* stream);
 // The general sequence's single pass; a frame has general_units(R, virtual blocks) units of up to 256 pixels each, and one
 // 64-bit status word per unit (DevFrame::vb_count).  gen: the gof's launch counter (tags the status words).
-constexpr uint32_t kGenUnitsPerGroup = 8;          // units a workgroup of k_general takes: one status word per group
+#ifndef VPCC_GEN_UNITS
+#define VPCC_GEN_UNITS 4
+#endif
+constexpr uint32_t kGenUnitsPerGroup = VPCC_GEN_UNITS;   // units a workgroup of k_general takes: one status word per group
 VPCC_HD inline uint32_t general_units(uint32_t R, uint32_t n_vblocks) {
   const uint64_t RR = (uint64_t)R * R;
   if (RR >= 256u) return (uint32_t)(n_vblocks * ((RR + 255u) / 256u));

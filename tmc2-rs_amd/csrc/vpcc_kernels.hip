@@ -108,7 +108,7 @@ __global__ __launch_bounds__(kPlanThreads) void k_plan_tiles(DevFrame* frames_rw
   DevFrame f;
   __builtin_memcpy(&f, (const __attribute__((address_space(4))) void*)(frames_rw + first + blockIdx.x), sizeof f);
   if (!f.patch_items) return;                                              // (a frame of the general sequence)
-  extern __shared__ uint32_t plan_lds[];
+  extern __shared__ __attribute__((aligned(16))) uint32_t plan_lds[];
   __shared__ uint32_t wave_total[kPlanThreads / 64];
   const uint32_t bw = f.bw, nb = bw * f.bh, P = f.n_patches, n = f.n_vblocks;
   VPCC_STAMP(9);
@@ -128,8 +128,27 @@ __global__ __launch_bounds__(kPlanThreads) void k_plan_tiles(DevFrame* frames_rw
   const uint32_t spb = f.prec >= 16u ? 1u : 16u / f.prec;                  // occupancy samples per block side
   const bool words = spb == 4u && (((uint32_t)(uintptr_t)f.occ | f.occ_stride) & 3u) == 0u;
   const uint32_t stride = f.occ_stride;
+  // ... four blocks of a block row per thread where rows are multiples of 16 bytes: four 16-byte loads for four blocks.
+  // (The four-byte loads are 448 wave-instructions through ONE CU's address unit per frame: 4.4 of the kernel's 18 us went
+  // into ISSUING them, profiles/r05/plan_stamps.txt.)
+  typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+  const bool quads = words && (bw & 3u) == 0u && (((uint32_t)(uintptr_t)f.occ | stride) & 15u) == 0u;
+  const uint32_t bw4 = bw >> 2, nq = nb >> 2, bw4_magic = magic_of(bw4);
+  u32x4 v4[2] = {};
+  if (quads) {
+#pragma unroll
+    for (uint32_t k = 0; k < 2u; ++k) {
+      const uint32_t qd = k * kPlanThreads + tid;
+      if (qd < nq) {
+        const uint32_t by = div_by(qd, bw4, bw4_magic), qx = qd - by * bw4;
+        const VPCC_GLOBAL uint8_t* row = gl(f.occ) + (by * 4u) * stride + qx * 16u;
+        v4[k] = *(const VPCC_GLOBAL u32x4*)row | *(const VPCC_GLOBAL u32x4*)(row + stride) |
+                *(const VPCC_GLOBAL u32x4*)(row + 2u * stride) | *(const VPCC_GLOBAL u32x4*)(row + 3u * stride);
+      }
+    }
+  }
   uint32_t v[8];
-  if (words) {
+  if (words && !quads) {
 #pragma unroll
     for (uint32_t k = 0; k < 8u; ++k) {
       const uint32_t cb = k * kPlanThreads + tid;
@@ -153,7 +172,32 @@ __global__ __launch_bounds__(kPlanThreads) void k_plan_tiles(DevFrame* frames_rw
     }
   }
   VPCC_STAMP(11);
-  if (words) {
+  if (quads) {
+    auto flags_of = [](u32x4 w) { return u32x4{w.x ? 0u : kPlanEmpty, w.y ? 0u : kPlanEmpty, w.z ? 0u : kPlanEmpty, w.w ? 0u : kPlanEmpty}; };
+#pragma unroll
+    for (uint32_t k = 0; k < 2u; ++k) {
+      const uint32_t qd = k * kPlanThreads + tid;
+      if (qd < nq) *(u32x4*)(b2p + 4u * qd) = flags_of(v4[k]);               // (block row by, blocks 4 qx .. + 3: by * bw + 4 qx = 4 qd)
+    }
+    for (uint32_t q0 = 2u * kPlanThreads; q0 < nq; q0 += 2u * kPlanThreads) {   // (frames beyond 8 192 blocks)
+#pragma unroll
+      for (uint32_t k = 0; k < 2u; ++k) {
+        const uint32_t qd = q0 + k * kPlanThreads + tid;
+        v4[k] = u32x4{0u, 0u, 0u, 0u};
+        if (qd < nq) {
+          const uint32_t by = div_by(qd, bw4, bw4_magic), qx = qd - by * bw4;
+          const VPCC_GLOBAL uint8_t* row = gl(f.occ) + (by * 4u) * stride + qx * 16u;
+          v4[k] = *(const VPCC_GLOBAL u32x4*)row | *(const VPCC_GLOBAL u32x4*)(row + stride) |
+                  *(const VPCC_GLOBAL u32x4*)(row + 2u * stride) | *(const VPCC_GLOBAL u32x4*)(row + 3u * stride);
+        }
+      }
+#pragma unroll
+      for (uint32_t k = 0; k < 2u; ++k) {
+        const uint32_t qd = q0 + k * kPlanThreads + tid;
+        if (qd < nq) *(u32x4*)(b2p + 4u * qd) = flags_of(v4[k]);
+      }
+    }
+  } else if (words) {
 #pragma unroll
     for (uint32_t k = 0; k < 8u; ++k) {
       const uint32_t cb = k * kPlanThreads + tid;
@@ -435,7 +479,7 @@ __device__ __forceinline__ void copy_out(const unsigned char* lds, unsigned char
 }
 }  // namespace
 
-__global__ __launch_bounds__(kGenThreads) void k_general(const DevFrame* __restrict__ frames, uint32_t first, uint32_t gen) {
+__global__ __launch_bounds__(kGenThreads) __attribute__((amdgpu_waves_per_eu(8, 8))) void k_general(const DevFrame* __restrict__ frames, uint32_t first, uint32_t gen) {
   const DevFrame& f = frames[first + blockIdx.y];
   const uint32_t R = f.R, RR = R * R, n_vb = f.n_vblocks;
   const uint32_t per = RR >= kGenThreads ? 0u : kGenThreads / RR;           // whole virtual blocks per unit (small blocks)
