@@ -461,6 +461,51 @@ def test_work_lists_are_planned_on_the_device(ctx):
     g.close()
 
 
+def test_planning_in_rounds_and_beyond_the_lds(ctx):
+    """k_plan_tiles compacts a frame's virtual blocks in rounds of 8 192 (a thread's run in a round fits its registers): a 2048 x 2048
+    frame whose patch table is repeated three times — 846 patches, 23 397 virtual blocks over 16 384 canvas blocks, three rounds;
+    every block owned by a patch of the LAST copy — through the planning kernel in LDS and through the kernels that work in
+    global memory (VPCC_NO_LDS_PLANNING); and a table of 2 049 patches, one more than the LDS form takes, which must choose the
+    other form by itself.  Points, colours, partition, block_to_patch and the number of work items against the oracle."""
+    base = synth.owlii_frame(1)
+    f = dict(base)
+    f["patches"] = np.concatenate([base["patches"]] * 3)
+    n_vb = int((f["patches"]["size_u0"].astype(np.int64) * f["patches"]["size_v0"]).sum())
+    assert n_vb > 2 * 8192 and len(f["patches"]) <= 2048
+    st, ref = ob.reconstruct(f)
+    assert st == 0 and ref["n"] > 1_500_000
+    assert int(ref["partition"].min()) >= 2 * len(base["patches"])          # the last copy owns everything
+    nb = (f["width"] // 16) * (f["height"] // 16)
+    for env, kernels in ((None, ["k_plan_tiles", "k_recon_tiles"]), ("1", ["k_plan_cover+items", "k_recon_tiles"])):
+        if env:
+            os.environ["VPCC_NO_LDS_PLANNING"] = env
+        try:
+            g = ctx.gof([f], capacity=2_400_000, flags=_abi.VPCC_GOF_PROFILE | _abi.VPCC_GOF_WANT_PATCH_INDEX)
+            g.reconstruct()
+            assert [k for k, _ in g.kernel_times()] == kernels
+            _check(g.download(0, want_patch_index=True), ref)
+            b2p, items = g.block_to_patch(0, nb)
+            assert np.array_equal(b2p.astype(np.uint64), ref["block_to_patch"].astype(np.uint64))
+            assert items == int(np.count_nonzero(ref["block_to_patch"]))
+            g.reconstruct()                                                  # (and again, behind the re-planning of the query)
+            _check(g.download(0, want_patch_index=True), ref)
+            g.close()
+        finally:
+            os.environ.pop("VPCC_NO_LDS_PLANNING", None)
+    # 2 049 patches: beyond the LDS form's table
+    small = cases.medium_frame(7)
+    many = dict(small)
+    reps = 2049 // len(small["patches"]) + 1
+    many["patches"] = np.concatenate([small["patches"]] * reps)[:2049]
+    st, ref2 = ob.reconstruct(many)
+    assert st == 0
+    g = ctx.gof([many], flags=_abi.VPCC_GOF_PROFILE | _abi.VPCC_GOF_WANT_PATCH_INDEX)
+    g.reconstruct()
+    assert [k for k, _ in g.kernel_times()] == ["k_plan_cover+items", "k_recon_tiles"]
+    _check(g.download(0, want_patch_index=True), ref2)
+    g.close()
+
+
 def test_borrowed_planes_may_change_between_launches(ctx):
     """A gof that borrows the caller's device planes (VPCC_MEM_DEVICE) reads them at vpcc_gof_reconstruct, on the launch's
     stream, and nowhere else: block_to_patch and the work lists are planned by every launch from the occupancy as it is
