@@ -175,13 +175,13 @@ def test_eight_lanes_deal_and_resequence(monkeypatch):
     assert st["lanes"] == 8 and st["frames"] == len(expect)
 
 
-@pytest.mark.parametrize("switch", ["VPCC_NO_EXTENT_INGEST", "VPCC_NO_STAGED_DESCRIPTORS", "VPCC_NO_PULL_INGEST", "VPCC_DECODER_NO_HUGEPAGES"])
+@pytest.mark.parametrize("switch", ["VPCC_NO_EXTENT_INGEST", "VPCC_DECODER_PIN_AT_ONCE", "VPCC_NO_PULL_INGEST", "VPCC_DECODER_NO_HUGEPAGES"])
 def test_decoder_ingest_paths(monkeypatch, longdress32, switch):
     """The Decoder's planes reach the device as whole stretches of its page-locked container by default (one copy per
-    eight frames; descriptors through a page-locked staging buffer).  The paths behind it — planes pulled by kernel,
-    descriptors from pageable memory on a set-up stream, plane-by-plane copies — serve callers whose planes are not
-    laid out like that: each must give the same frames.  (The last switch: the container is read into 4-KB pages
-    instead of the huge pages the Decoder asks for.)"""
+    eight frames; descriptors through a page-locked staging buffer), and only the first GOF's planes are page-locked in
+    front of the first unit.  The paths behind it — planes pulled by kernel, plane-by-plane copies, the whole input
+    page-locked at once — serve callers whose planes are not laid out like that: each must give the same frames.  (The
+    last switch: the container is read into 4-KB pages instead of the huge pages the Decoder asks for.)"""
     frames, ref = longdress32
     if switch == "VPCC_NO_PULL_INGEST":
         monkeypatch.setenv("VPCC_NO_EXTENT_INGEST", "1")            # neither stretches nor the kernel: the copy engine, plane by plane

@@ -17,7 +17,7 @@ from .synth import canvas_bbox_blocks
 
 def cover_map(fr):
     """cover[by, bx] = highest patch index whose bounding box covers the block, -1 if none
-    (vpcc_host.cpp::plan_frame; Default/Swap patches)."""
+    (as k_plan_tiles finds them: Default/Swap patches)."""
     R = fr["occupancy_resolution"]
     bw, bh = fr["width"] // R, fr["height"] // R
     cover = np.full((bh, bw), -1, dtype=np.int32)

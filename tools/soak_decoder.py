@@ -43,7 +43,7 @@ def expected(k, sm):
         smoothed[(k, sm)] = (len(xyz), crc(xyz, rgb))
         changed[0] += int(smoothed[(k, sm)] != pool[k][1])
     return smoothed[(k, sm)]
-switches = ["VPCC_NO_EXTENT_INGEST", "VPCC_NO_STAGED_DESCRIPTORS", "VPCC_NO_PULL_INGEST", "VPCC_NO_PUSH_DOWNLOAD", "VPCC_DECODER_NO_TAIL_SPLIT",
+switches = ["VPCC_NO_EXTENT_INGEST", "VPCC_DECODER_PIN_AT_ONCE", "VPCC_NO_PULL_INGEST", "VPCC_NO_PUSH_DOWNLOAD", "VPCC_DECODER_NO_TAIL_SPLIT",
             "VPCC_DECODER_NO_HUGEPAGES"]
 bad = frames = 0
 t0 = time.time()
