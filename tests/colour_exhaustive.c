@@ -14,6 +14,7 @@ int main(){ uint64_t bad=0, slow=0, total=0, exact_unflagged=0;
     const int du=u-512, dv=v-512;
     for (int y=0;y<1024;++y){
       uint32_t fmin=0xFFFFFFFFu; const uint32_t rgb=vpcc_colour_luma(y,c,&fmin); const int amb = fmin==0; uint8_t o[3]; ref(y,u,v,o); total++;
+      { uint32_t f1=0xFFFFFFFFu; const uint32_t one=vpcc_colour_one(y,u,v,VPCC_K_R,VPCC_K_G,VPCC_K_B,&f1); if (one!=rgb || (f1==0)!=amb) { if (bad<5) printf("vpcc_colour_one differs at %d %d %d\n",y,u,v); bad++; } }
       const int64_t nr=17ll*(2500ll*y+3937ll*dv), ng=17ll*(100000ll*y-18733ll*du-46813ll*dv), nb=17ll*(100000ll*y+185563ll*du);
       const int exact = (nr>0&&nr%170500==0)||(ng>0&&ng%6820000==0)||(nb>0&&nb%6820000==0);
       if (amb){ slow++; continue; }

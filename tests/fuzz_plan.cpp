@@ -84,7 +84,24 @@ int main(int argc, char** argv) {
           const uint64_t cb = (uint64_t)(by * bw + bx);
           if (cb >= (uint64_t)bw * bh) { std::fprintf(stderr, "canvas block out of range\n"); return 1; }
           const uint32_t q = vpcc::patch_of_vblock(vb_base.data(), (uint32_t)patches.size(), vb);
-          const vpcc::VBlock b = vpcc::vblock_of(dev[q], q, vb, bw);
+          const vpcc::VBlock b = vpcc::vblock_of(dev[q], q, vb, bw, R);
+          {
+            // what the record says of the block's pixels: patch_to_canvas of its corners (src/decoder.rs:841-867), the tangent /
+            // bitangent coordinates of its first pixel (src/decoder.rs:875-876), the patch's axes
+            const vpcc::Affine px = vpcc::patch_affine(p, R);
+            const int cux = (b.coef & 3) - 1, cvx = ((b.coef >> 2) & 3) - 1, cuy = ((b.coef >> 4) & 3) - 1, cvy = (b.coef >> 6) - 1;
+            for (int c = 0; c < 4; ++c) {
+              const int64_t pu = (c & 1) ? R - 1 : 0, pv = (c & 2) ? R - 1 : 0, u = (int64_t)u0 * R + pu, v = (int64_t)v0 * R + pv;
+              const int64_t x = px.ax_u * u + px.ax_v * v + px.cx, y = px.ay_u * u + px.ay_v * v + px.cy;
+              if (x != (int64_t)b.x0 + cux * pu + cvx * pv || y != (int64_t)b.y0 + cuy * pu + cvy * pv || x < 0 || y < 0 || x >= f.width || y >= f.height) {
+                std::fprintf(stderr, "block record: pixel map\n"); return 1;
+              }
+            }
+            if (b.t0 != u0 * R * p.lod_x + p.u1 || b.b0 != v0 * R * p.lod_y + p.v1 || b.lod_x != (uint16_t)p.lod_x || b.lod_y != (uint16_t)p.lod_y || b.d1 != p.d1 ||
+                b.axes_mode != (p.normal_axis | (p.tangent_axis << 2) | (p.bitangent_axis << 4) | (p.projection_mode << 6))) {
+              std::fprintf(stderr, "block record: coordinates\n"); return 1;
+            }
+          }
           if (q != i || b.patch != i || b.u0 != u0 || b.v0 != v0 || b.canvas_block != cb) { std::fprintf(stderr, "derived virtual block %u: patch %u (%u) block (%u, %u) canvas block %u (%llu)\n", vb, q, i, b.u0, b.v0, b.canvas_block, (unsigned long long)cb); return 1; }
           if (shape.tile_eligible) {                     // k_plan_tiles' route: the template's origin, size_u0 and Swap flag
             const vpcc::TileItem& t = templates[q];

@@ -85,6 +85,54 @@ def test_general_and_fast_paths_agree(ctx):
     b.close()
 
 
+def test_both_kernels_of_the_general_sequence(ctx):
+    """The general sequence's pass has two kernels: k_general_blocks for frames whose block side is a power of two in [16, 256]
+    with an occupancy precision that is a power of two and patches whose three axes differ, k_general for any frame.  The named
+    cases (all orientations, relative D1, one map, no attribute, strided planes, blocks of 32) and a batch of medium frames go
+    through each — VPCC_GENERAL_ANY_FRAME sends eligible frames to k_general too — and must equal the oracle; a patch whose
+    tangent axis is its normal axis (the reference never builds one; the interface takes it) sends its gof to k_general."""
+    named = [cases.exotic_frame(), cases.relative_d1_frame(), cases.overlap_frame(), cases.block32_frame(),
+             cases.single_map_frame(), cases.no_attribute_frame(), cases.strided_frame(), cases.wide_samples_frame()]
+    batch = [cases.medium_frame(i) for i in range(11)]                     # (not a multiple of the eight XCDs)
+    odd = cases.medium_frame(3)
+    odd["patches"] = odd["patches"].copy()
+    odd["patches"]["tangent_axis"][::3] = odd["patches"]["normal_axis"][::3]
+    flags = _abi.VPCC_GOF_FORCE_GENERAL | _abi.VPCC_GOF_PROFILE | _abi.VPCC_GOF_WANT_PATCH_INDEX
+    try:
+        for env, kernel in ((None, "k_general_blocks"), ("1", "k_general")):
+            if env:
+                os.environ["VPCC_GENERAL_ANY_FRAME"] = env
+            for frames in ([f] for f in named):
+                g = ctx.gof(frames, flags=flags)
+                g.reconstruct()
+                assert [k for k, _ in g.kernel_times()] == ["k_block_owner", kernel], g.kernel_times()
+                st, ref = ob.reconstruct(frames[0])
+                assert st == 0
+                # (without an attribute the reference's PointSet3 carries no colours at all: codec.rs:47-50, 274-276)
+                _check(g.download(0, want_patch_index=True), ref, colour=frames[0].get("attribute_count", 1) > 0)
+                g.close()
+            g = ctx.gof(batch, flags=flags)
+            for first, count in ((0, 11), (3, 5), (10, 1)):
+                g.reconstruct(first, count)
+                assert [k for k, _ in g.kernel_times()] == ["k_block_owner", kernel]
+            for i, f in enumerate(batch):
+                st, ref = ob.reconstruct(f)
+                assert st == 0
+                _check(g.download(i, want_patch_index=True), ref)
+            g.close()
+    finally:
+        os.environ.pop("VPCC_GENERAL_ANY_FRAME", None)
+    mixed = [batch[0], odd, batch[1], cases.truncation_frame(), cases.block8_frame()]      # (coinciding axes; blocks of 8)
+    g = ctx.gof(mixed, flags=flags)
+    g.reconstruct()
+    assert [k for k, _ in g.kernel_times()] == ["k_block_owner", "k_general"]
+    for i, f in enumerate(mixed):
+        st, ref = ob.reconstruct(f)
+        assert st == 0
+        _check(g.download(i, want_patch_index=True), ref)
+    g.close()
+
+
 def test_every_block_size_and_occupancy_precision(ctx):
     """occupancy_resolution 1 .. 128 (log2_patch_packing_block_size 0 .. 7) x occupancy_precision 1, 2, 4, 8 — blocks smaller than an
     occupancy sample included — on the path gof creation chooses (the tile kernel for blocks of 16) and on the general sequence:

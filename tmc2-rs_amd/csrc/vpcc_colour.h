@@ -74,4 +74,18 @@ VPCC_COLOUR_FN uint32_t vpcc_colour_luma(uint32_t Y, vpcc_chroma_part c, uint32_
          ((uint32_t)vpcc_colour_clamp(ib >> 20) << 16);
 }
 
+/* The same arithmetic for ONE triplet, with the three values the accumulations start from passed in (VPCC_K_R, _G, _B: the
+ * general sequence keeps them in registers).  *fraction_min as in vpcc_colour_luma. */
+VPCC_COLOUR_FN uint32_t vpcc_colour_one(uint32_t Y, uint32_t U, uint32_t V, double kr, double kg, double kb, uint32_t* fraction_min) {
+  const double y = (double)Y, u = (double)U, v = (double)V;
+  const int32_t ir = vpcc_colour_lo(fma(y, VPCC_C_AY, fma(v, VPCC_C_RV, kr)));
+  const int32_t ig = vpcc_colour_lo(fma(y, VPCC_C_AY, fma(v, VPCC_C_GV, fma(u, VPCC_C_GU, kg))));
+  const int32_t ib = vpcc_colour_lo(fma(y, VPCC_C_AY, fma(u, VPCC_C_BU, kb)));
+  const uint32_t fr = (uint32_t)ir & 0xFFFF8u, fg = (uint32_t)ig & 0xFFFF8u, fb = (uint32_t)ib & 0xFFFF8u;
+  const uint32_t m = fr < fg ? (fr < fb ? fr : fb) : (fg < fb ? fg : fb);
+  if (m < *fraction_min) *fraction_min = m;
+  return (uint32_t)vpcc_colour_clamp(ir >> 20) | ((uint32_t)vpcc_colour_clamp(ig >> 20) << 8) |
+         ((uint32_t)vpcc_colour_clamp(ib >> 20) << 16);
+}
+
 #endif /* VPCC_COLOUR_H_ */

@@ -30,6 +30,27 @@ __device__ __forceinline__ T gload(const T* p) {
   return r;
 }
 
+// ... and one whose address is the same in every lane: through the constant address space, i.e. scalar loads into SGPRs (for
+// memory no kernel of the same launch writes: the scalar cache is not coherent with vector stores)
+#define VPCC_CONST __attribute__((address_space(4)))
+template <class T>
+__device__ __forceinline__ T cload(const T* p) {
+  static_assert(sizeof(T) % 4 == 0, "whole dwords");
+  const VPCC_CONST uint32_t* q = (const VPCC_CONST uint32_t*)p;            // (dword by dword: a memcpy from this address space is
+  uint32_t w[sizeof(T) / 4];                                               // lowered to vector loads + v_readfirstlane)
+#pragma unroll
+  for (uint32_t k = 0; k < sizeof(T) / 4; ++k) w[k] = q[k];
+  T r;
+  __builtin_memcpy(&r, w, sizeof(T));
+  return r;
+}
+// Element at a BYTE offset below 2^32 from a base every lane shares: the address is {scalar base, 32-bit lane offset}, no 64-bit
+// vector arithmetic (the general sequence spent a quarter of its vector instructions on v_mad_u64_u32 / v_lshl_add_u64).
+template <class T>
+__device__ __forceinline__ T ld32(const T* base, uint32_t byte_offset) {
+  return *(const VPCC_GLOBAL T*)((const VPCC_GLOBAL unsigned char*)base + byte_offset);
+}
+
 template <class T>
 __device__ __forceinline__ void gstore(T* p, const T& v) {
   __builtin_memcpy((VPCC_GLOBAL void*)p, &v, sizeof(T));
@@ -45,38 +66,38 @@ __device__ __forceinline__ uint32_t mbcnt(uint64_t mask) {
 
 struct Pt { uint16_t c[3]; };
 
-// Patch::generate_point, src/decoder.rs:871-888.  Assignment order normal, tangent, bitangent
-// as in the reference; `as u16` truncation.
-__device__ __forceinline__ uint32_t normal_coord(const DevPatch& p, uint32_t depth) {
-  return p.projection_mode == 0 ? depth + p.d1 : (p.d1 > depth ? p.d1 : depth) - depth;
+// Patch::generate_point, src/decoder.rs:871-888, from the virtual block's record (pu, pv: the pixel's offsets inside the
+// block).  Assignment order normal, tangent, bitangent as in the reference; `as u16` truncation.
+__device__ __forceinline__ uint32_t normal_coord(const VBlock& b, uint32_t depth) {
+  return (b.axes_mode >> 6) == 0 ? depth + b.d1 : (b.d1 > depth ? b.d1 : depth) - depth;
 }
 
-__device__ __forceinline__ Pt make_point(const DevPatch& p, uint32_t u, uint32_t v, uint32_t depth) {
+__device__ __forceinline__ Pt make_point(const VBlock& b, uint32_t pu, uint32_t pv, uint32_t depth) {
   Pt r;
   r.c[0] = r.c[1] = r.c[2] = 0;
-  const uint16_t n = (uint16_t)normal_coord(p, depth);
-  const uint16_t t = (uint16_t)(u * p.lod_x + p.u1);
-  const uint16_t b = (uint16_t)(v * p.lod_y + p.v1);
+  const uint16_t n = (uint16_t)normal_coord(b, depth);
+  const uint16_t t = (uint16_t)(pu * b.lod_x + b.t0);
+  const uint16_t bt = (uint16_t)(pv * b.lod_y + b.b0);
+  const uint32_t na = b.axes_mode & 3u, ta = (b.axes_mode >> 2) & 3u, ba = (b.axes_mode >> 4) & 3u;
 #pragma unroll
-  for (int a = 0; a < 3; ++a) {           // select instead of a runtime-indexed array (no scratch)
+  for (uint32_t a = 0; a < 3; ++a) {      // select instead of a runtime-indexed array (no scratch)
     uint16_t val = r.c[a];
-    if (p.normal_axis == a) val = n;
-    if (p.tangent_axis == a) val = t;
-    if (p.bitangent_axis == a) val = b;
+    if (na == a) val = n;
+    if (ta == a) val = t;
+    if (ba == a) val = bt;
     r.c[a] = val;
   }
   return r;
 }
 
 // generate_points, src/codec.rs:517-565: D1 point from D0 point / second geometry sample.
-__device__ __forceinline__ Pt make_point1(const DevFrame& f, const DevPatch& p, uint32_t u, uint32_t v,
-                                          const Pt& p0, uint32_t d1) {
-  if (f.absolute_d1) return make_point(p, u, v, d1);
+__device__ __forceinline__ Pt make_point1(const DevFrame& f, const VBlock& b, uint32_t pu, uint32_t pv, const Pt& p0, uint32_t d1) {
+  if (f.absolute_d1) return make_point(b, pu, pv, d1);
   Pt r = p0;
+  const uint32_t na = b.axes_mode & 3u;
 #pragma unroll
-  for (int a = 0; a < 3; ++a)
-    if (p.normal_axis == a)
-      r.c[a] = p.projection_mode == 0 ? (uint16_t)(r.c[a] + d1) : (uint16_t)(r.c[a] - d1);
+  for (uint32_t a = 0; a < 3; ++a)
+    if (na == a) r.c[a] = (b.axes_mode >> 6) == 0 ? (uint16_t)(r.c[a] + d1) : (uint16_t)(r.c[a] - d1);
   return r;
 }
 
@@ -116,6 +137,25 @@ __device__ __forceinline__ vpcc_color3 yuv10_to_rgb8_fast(uint16_t y16, uint16_t
   return c;
 }
 
+// ... with the samples as the 32-bit values a 16-bit load leaves (no zero extension: saves three instructions), and the three
+// constants that the FMAs start from held in registers by the caller (vpcc_colour_keys: the compiler otherwise rebuilds each
+// 64-bit constant with two moves in front of every FMA that accumulates into it — six moves per conversion).
+struct ColourKeys { double r, g, b; };
+__device__ __forceinline__ ColourKeys vpcc_colour_keys() {
+  ColourKeys k = {VPCC_K_R, VPCC_K_G, VPCC_K_B};
+  asm volatile("" : "+v"(k.r), "+v"(k.g), "+v"(k.b));                       // opaque: not a literal any more
+  return k;
+}
+__device__ __forceinline__ uint32_t yuv10_to_rgb8_packed(uint32_t y, uint32_t u, uint32_t v, const ColourKeys& k) {
+  uint32_t fmin = (y | u | v) > 1023u ? 0u : 0xFFFFFFFFu;                   // a sample above 10 bits: the reference formula
+  const uint32_t rgb = vpcc_colour_one(y, u, v, k.r, k.g, k.b, &fmin);
+  if (fmin == 0u) {                                                         // ... or a fraction field that could hide an exact integer (rare)
+    const vpcc_color3 c = yuv10_to_rgb8((uint16_t)y, (uint16_t)u, (uint16_t)v);
+    return (uint32_t)c.r | ((uint32_t)c.g << 8) | ((uint32_t)c.b << 16);
+  }
+  return rgb;
+}
+
 // Per-pixel work of the enumeration: returns the number of points (0,1,2) and the points.
 struct PixelOut {
   Pt p0, p1;
@@ -123,13 +163,14 @@ struct PixelOut {
   uint32_t n;
 };
 
-__device__ __forceinline__ PixelOut eval_pixel(const DevFrame& f, const DevPatch& p, uint32_t u, uint32_t v) {
+__device__ __forceinline__ PixelOut eval_pixel(const DevFrame& f, const VBlock& b, uint32_t pu, uint32_t pv) {
   PixelOut o;
   o.n = 0;
-  const int32_t x = p.ax_u * (int32_t)u + p.ax_v * (int32_t)v + p.cx;   // host validated: inside the canvas
-  const int32_t y = p.ay_u * (int32_t)u + p.ay_v * (int32_t)v + p.cy;
-  o.x = (uint32_t)x;
-  o.y = (uint32_t)y;
+  // patch_to_canvas (src/decoder.rs:841-867) of the block's pixel (pu, pv); host validated: inside the canvas
+  const int32_t cux = (int32_t)(b.coef & 3u) - 1, cvx = (int32_t)((b.coef >> 2) & 3u) - 1;
+  const int32_t cuy = (int32_t)((b.coef >> 4) & 3u) - 1, cvy = (int32_t)(b.coef >> 6) - 1;
+  o.x = (uint32_t)((int32_t)b.x0 + cux * (int32_t)pu + cvx * (int32_t)pv);
+  o.y = (uint32_t)((int32_t)b.y0 + cuy * (int32_t)pu + cvy * (int32_t)pv);
   // (a precision that is a power of two — every stream's — by shift: the two 32-bit divisions were a quarter of the
   // general sequence's vector instructions)
   const bool pow2 = (1u << f.prec_shift) == f.prec;
@@ -140,11 +181,11 @@ __device__ __forceinline__ PixelOut eval_pixel(const DevFrame& f, const DevPatch
   const uint8_t occ = gl(f.occ)[oy * f.occ_stride + ox];                             // src/codec.rs:288-301, 393
   const uint32_t d0 = (uint32_t)(gl(f.geo[0])[o.y * f.geo_stride[0] + o.x] >> 2);  // depth / 4, codec.rs:534
   const uint32_t d1 = (uint32_t)(gl(f.geo[1])[o.y * f.geo_stride[1] + o.x] >> 2);  // (one map: the descriptor's alias of layer 0)
-  o.p0 = make_point(p, u, v, d0);
+  o.p0 = make_point(b, pu, pv, d0);
   o.p1 = o.p0;
   uint32_t n = 1;
   if (f.map_count > 1) {                                                           // (uniform)
-    o.p1 = make_point1(f, p, u, v, o.p0, d1);
+    o.p1 = make_point1(f, b, pu, pv, o.p0, d1);
     n = same_point(o.p0, o.p1) ? 1u : 2u;                                          // codec.rs:422-427
   }
   o.n = occ ? n : 0u;

@@ -27,15 +27,22 @@ struct DevPatch {
 static_assert(sizeof(DevPatch) == 64, "DevPatch is one 64-B record");
 
 // One virtual block = (patch, v0, u0) in the reference's emission order
-// (src/codec.rs:352-385): patch ascending, v0 outer, u0 inner.
-struct VBlock {
-  uint16_t patch;
-  uint16_t u0, v0;
-  uint16_t flags;
+// (src/codec.rs:352-385): patch ascending, v0 outer, u0 inner — with everything of its patch that the evaluation of its
+// pixels needs folded in (round 5): the general sequence reads ONE 32-byte record per block where it read a 16-byte block,
+// then — a dependent round trip later — the 64-byte patch.
+struct alignas(16) VBlock {
   uint32_t canvas_block;  // patch_block_to_canvas_block(u0, v0)
-  uint32_t pad;
+  uint16_t patch;
+  uint8_t coef;           // patch_to_canvas (src/decoder.rs:853-867) is x = cu_x * u + cv_x * v + ..., coefficients in {-1, 0, 1}:
+                          //   (cu_x + 1) | (cv_x + 1) << 2 | (cu_y + 1) << 4 | (cv_y + 1) << 6
+  uint8_t axes_mode;      // normal | tangent << 2 | bitangent << 4 | projection_mode << 6
+  uint16_t x0, y0;        // canvas pixel of the block's first pixel (u, v) = (u0 * R, v0 * R): inside the canvas (validate_frame)
+  uint32_t t0, b0;        // its tangent / bitangent coordinate: u0 * R * lod_x + u1, v0 * R * lod_y + v1 (mod 2^32; src/decoder.rs:875-876)
+  uint16_t lod_x, lod_y;  // level of detail mod 2^16 (the coordinates are truncated to u16)
+  uint32_t d1;
+  uint16_t u0, v0;        // the block of its patch
 };
-static_assert(sizeof(VBlock) == 16, "VBlock is 16 B");
+static_assert(sizeof(VBlock) == 32, "VBlock is 32 B");
 
 #if defined(__HIPCC__)
 #define VPCC_HD __host__ __device__
@@ -56,9 +63,9 @@ VPCC_HD inline uint32_t patch_of_vblock(const uint32_t* vb_base, uint32_t n_patc
   }
   return lo;
 }
-// (patch, v0, u0) of a virtual block and its canvas block, from the patch's record: src/codec.rs:352-385 (v0 outer, u0
-// inner) and patch_block_to_canvas_block, src/decoder.rs:827-838.
-VPCC_HD inline VBlock vblock_of(const DevPatch& p, uint32_t patch, uint32_t vb, uint32_t bw) {
+// (patch, v0, u0) of a virtual block, its canvas block and the patch's part of its pixels' arithmetic, from the patch's record:
+// src/codec.rs:352-385 (v0 outer, u0 inner), patch_block_to_canvas_block and patch_to_canvas, src/decoder.rs:827-867.
+VPCC_HD inline VBlock vblock_of(const DevPatch& p, uint32_t patch, uint32_t vb, uint32_t bw, uint32_t R) {
   const uint32_t r = vb - p.vb_base, v0 = r / p.size_u0, u0 = r - v0 * p.size_u0;
   const int32_t bx = p.ax_u * (int32_t)u0 + p.ax_v * (int32_t)v0 + (int32_t)(p.bc & 0xFFFFu);
   const int32_t by = p.ay_u * (int32_t)u0 + p.ay_v * (int32_t)v0 + (int32_t)(p.bc >> 16);
@@ -67,6 +74,16 @@ VPCC_HD inline VBlock vblock_of(const DevPatch& p, uint32_t patch, uint32_t vb, 
   b.u0 = (uint16_t)u0;
   b.v0 = (uint16_t)v0;
   b.canvas_block = (uint32_t)by * bw + (uint32_t)bx;
+  b.coef = (uint8_t)((p.ax_u + 1) | ((p.ax_v + 1) << 2) | ((p.ay_u + 1) << 4) | ((p.ay_v + 1) << 6));
+  b.axes_mode = (uint8_t)(p.normal_axis | (p.tangent_axis << 2) | (p.bitangent_axis << 4) | (p.projection_mode << 6));
+  const int32_t pu = (int32_t)(u0 * R), pv = (int32_t)(v0 * R);
+  b.x0 = (uint16_t)(p.ax_u * pu + p.ax_v * pv + p.cx);
+  b.y0 = (uint16_t)(p.ay_u * pu + p.ay_v * pv + p.cy);
+  b.t0 = u0 * R * p.lod_x + p.u1;
+  b.b0 = v0 * R * p.lod_y + p.v1;
+  b.lod_x = (uint16_t)p.lod_x;
+  b.lod_y = (uint16_t)p.lod_y;
+  b.d1 = p.d1;
   return b;
 }
 
@@ -248,17 +265,26 @@ void launch_block_owner(const DevFrame* d_frames, uint32_t first, uint32_t count
 // The general sequence's single pass; a frame has general_units(R, virtual blocks) units of up to 256 pixels each, and one
 // 64-bit status word per unit (DevFrame::vb_count).  gen: the gof's launch counter (tags the status words).
 #ifndef VPCC_GEN_UNITS
-#define VPCC_GEN_UNITS 4
+#define VPCC_GEN_UNITS 5
+#endif
+#ifndef VPCC_GENB_UNITS
+#define VPCC_GENB_UNITS 4
 #endif
 constexpr uint32_t kGenUnitsPerGroup = VPCC_GEN_UNITS;   // units a workgroup of k_general takes: one status word per group
+constexpr uint32_t kGenBlockUnits = VPCC_GENB_UNITS;     // ... and of k_general_blocks
+#ifndef VPCC_GENB_STAGE
+#define VPCC_GENB_STAGE 2
+#endif
+constexpr uint32_t kGenBlockStage = VPCC_GENB_STAGE;     // units of a group that pass through the LDS together on their way out
 VPCC_HD inline uint32_t general_units(uint32_t R, uint32_t n_vblocks) {
   const uint64_t RR = (uint64_t)R * R;
   if (RR >= 256u) return (uint32_t)(n_vblocks * ((RR + 255u) / 256u));
   const uint32_t per = (uint32_t)(256u / RR);
   return (n_vblocks + per - 1u) / per;
 }
-// resident_wgs: workgroups of k_general the device holds at a time (4 per CU)
-void launch_general(const DevFrame* d_frames, uint32_t first, uint32_t count, uint32_t max_units, uint32_t gen, uint32_t resident_wgs, void* stream);
+// block_units: every frame of the launch has FrameShape::block_units (vpcc_host.hpp) — k_general_blocks, whose units are chunks
+// of ONE virtual block each, so that everything a block decides is scalar work; else k_general, which takes any frame.
+void launch_general(const DevFrame* d_frames, uint32_t first, uint32_t count, uint32_t max_units, uint32_t gen, bool block_units, void* stream);
 // Where the workgroups of one tile-kernel launch start (kernel argument, by value).  A workgroup stays with its
 // frame; frames differ in size (S-longdress +-5 %, S-owlii +-11 % between the largest frame and the mean), so the
 // resident workgroups of an XCD are shared out among its frames in proportion to their tile counts instead of

@@ -133,8 +133,10 @@ extern "C" int vpcc_gof_reconstruct(vpcc_gof* g, uint32_t first, uint32_t count,
   const size_t b2p_len = g->b2p_off[first + count] - g->b2p_off[first];
   if (b2p_len) HIP_TRY(ctx, hipMemsetAsync(g->d_b2p + g->b2p_off[first], 0, b2p_len * sizeof(uint32_t), s));
   uint32_t max_vb = 0, max_units = 0, max_samples = 0;
+  bool block_units = getenv("VPCC_GENERAL_ANY_FRAME") == nullptr;       // (tests: k_general on frames k_general_blocks would take)
   for (uint32_t i = first; i < first + count; ++i) {
     const DevFrame& D = g->h_frames[i];
+    block_units = block_units && g->shapes[i].block_units;
     max_vb = std::max(max_vb, D.n_vblocks);
     max_units = std::max(max_units, general_units(D.R, D.n_vblocks));
     const uint32_t side = (D.R + D.prec - 1u) / D.prec + 1u; // samples under R pixels that start anywhere: at most ceil(R / precision) + 1
@@ -144,8 +146,8 @@ extern "C" int vpcc_gof_reconstruct(vpcc_gof* g, uint32_t first, uint32_t count,
   T.begin("k_block_owner");
   launch_block_owner(g->d_frames, first, count, max_vb, max_samples, s);
   T.end();
-  T.begin("k_general");
-  launch_general(g->d_frames, first, count, max_units, g->generation, ctx->resident_tile_wgs_per_xcd * 8u, s);
+  T.begin(block_units ? "k_general_blocks" : "k_general");
+  launch_general(g->d_frames, first, count, max_units, g->generation, block_units, s);
   T.end();
   HIP_TRY(ctx, hipGetLastError());
   HIP_TRY(ctx, hipEventRecord(g->results_ready, s));

@@ -84,6 +84,7 @@ int validate_frame(const vpcc_frame_desc* f, FrameShape* shape) {
 
   uint64_t n_vb = 0;
   bool simple = true;                 // Default / Swap (/ MRot270 == Swap) patches with levels of detail that fit a tile item
+  bool distinct_axes = true;          // (the reference's axes are a permutation; the interface takes any three)
   for (uint32_t i = 0; i < f->patch_count; ++i) {
     const vpcc_patch& p = f->patches[i];
     if (p.axis_of_additional_plane != 0) return VPCC_ERR_UNSUPPORTED;           // src/codec.rs:437
@@ -91,6 +92,7 @@ int validate_frame(const vpcc_frame_desc* f, FrameShape* shape) {
     if (p.projection_mode > 1) return VPCC_ERR_INVALID_ARG;                     // unreachable!() decoder.rs:886
     if (p.orientation > VPCC_ORIENT_MROT270) return VPCC_ERR_INVALID_ARG;
     if (p.lod_x > 65535u || p.lod_y > 65535u) simple = false;
+    if (p.normal_axis == p.tangent_axis || p.normal_axis == p.bitangent_axis || p.tangent_axis == p.bitangent_axis) distinct_axes = false;
     if (p.size_u0 == 0 || p.size_v0 == 0) continue;
     if (p.size_u0 > 65535 || p.size_v0 > 65535) return VPCC_ERR_PATCH_OUT_OF_CANVAS;
     if (p.orientation == VPCC_ORIENT_DEFAULT || p.orientation == VPCC_ORIENT_SWAP || p.orientation == VPCC_ORIENT_MROT270) {
@@ -121,6 +123,12 @@ int validate_frame(const vpcc_frame_desc* f, FrameShape* shape) {
     // leaves "highest covering patch, if any occupancy"
     shape->tile_eligible = simple && R == 16 && prec <= 16 && (prec & (prec - 1)) == 0;
     shape->tile_bound = shape->tile_eligible ? (uint32_t)std::min<uint64_t>(n_vb, (uint64_t)bw * bh) : 0u;
+    uint32_t max_stride = f->occupancy.stride;
+    for (uint32_t m = 0; m < f->map_count; ++m) {
+      max_stride = std::max(max_stride, f->geometry[m].stride);
+      if (f->attribute_count) max_stride = std::max(max_stride, std::max(f->attribute[m].stride, f->attribute[m].cstride));
+    }
+    shape->block_units = R >= 16 && R <= 256 && (R & (R - 1)) == 0 && (prec & (prec - 1)) == 0 && max_stride <= 65536u && distinct_axes;
     shape->plane_bytes = plane_bytes;
   }
   return VPCC_OK;

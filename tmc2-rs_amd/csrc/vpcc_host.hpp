@@ -31,6 +31,8 @@ struct FrameShape {
   uint32_t n_vblocks = 0;            // sum of size_u0 * size_v0: every (patch, v0, u0) the reference's loops visit
   uint32_t tile_bound = 0;           // upper bound of the frame's work items: min(virtual blocks, canvas blocks); 0: not eligible
   bool tile_eligible = false;        // R == 16, Default/Swap (/MRot270 == Swap) patches only, occupancy precision a power of two <= 16
+  bool block_units = false;          // general sequence: k_general_blocks may take the frame — block side a power of two in [16, 256], occupancy
+                                     // precision a power of two, plane strides <= 65536 elements, every patch's three axes distinct
   uint64_t plane_bytes = 0;          // occupancy + geometry luma + attribute Y,U,V planes
 };
 

@@ -36,10 +36,10 @@ __global__ __launch_bounds__(256) void k_block_owner(const DevFrame* __restrict_
   const uint32_t vb = kLanes == 1u ? blockIdx.x * 256u + threadIdx.x : blockIdx.x * 4u + (threadIdx.x >> 6);
   if (vb >= f.n_vblocks) return;
   const VBlock b = gload(f.vblocks + vb);
-  const DevPatch p = gload(f.patches + b.patch);
-  const int32_t R = (int32_t)f.R, ulo = (int32_t)b.u0 * R, vlo = (int32_t)b.v0 * R, uhi = ulo + R - 1, vhi = vlo + R - 1;
-  const int32_t xa = p.ax_u * ulo + p.ax_v * vlo + p.cx, xb = p.ax_u * uhi + p.ax_v * vhi + p.cx;
-  const int32_t ya = p.ay_u * ulo + p.ay_v * vlo + p.cy, yb = p.ay_u * uhi + p.ay_v * vhi + p.cy;
+  const int32_t e = (int32_t)f.R - 1;                                       // the block's pixels (0, 0) and (R - 1, R - 1)
+  const int32_t cux = (int32_t)(b.coef & 3u) - 1, cvx = (int32_t)((b.coef >> 2) & 3u) - 1;
+  const int32_t cuy = (int32_t)((b.coef >> 4) & 3u) - 1, cvy = (int32_t)(b.coef >> 6) - 1;
+  const int32_t xa = (int32_t)b.x0, xb = xa + (cux + cvx) * e, ya = (int32_t)b.y0, yb = ya + (cuy + cvy) * e;
   const uint32_t sx0 = (uint32_t)min(xa, xb) / f.prec, sx1 = (uint32_t)max(xa, xb) / f.prec;     // (inside the canvas: validate_frame)
   const uint32_t sy0 = (uint32_t)min(ya, yb) / f.prec, sy1 = (uint32_t)max(ya, yb) / f.prec;
   const uint32_t nx = sx1 - sx0 + 1u, total = nx * (sy1 - sy0 + 1u);
@@ -350,7 +350,7 @@ __global__ __launch_bounds__(256) void k_plan_vblocks(DevFrame* __restrict__ fra
   const uint32_t vb = blockIdx.x * 256u + threadIdx.x;
   if (!f.patches || vb >= f.n_vblocks) return;
   const uint32_t p = patch_of_vblock(f.vb_base, f.n_patches, vb);
-  gstore(f.vblocks + vb, vblock_of(gload(f.patches + p), p, vb, f.bw));
+  gstore(f.vblocks + vb, vblock_of(gload(f.patches + p), p, vb, f.bw, f.R));
 }
 // ... and, per launch, over block_to_patch zeroed in global memory:
 //   k_plan_cover: a thread per virtual block: atomicMax(block_to_patch[canvas block], patch + 1) if the block is occupied;
@@ -479,8 +479,40 @@ __device__ __forceinline__ void copy_out(const unsigned char* lds, unsigned char
 }
 }  // namespace
 
-__global__ __launch_bounds__(kGenThreads) __attribute__((amdgpu_waves_per_eu(8, 8))) void k_general(const DevFrame* __restrict__ frames, uint32_t first, uint32_t gen) {
-  const DevFrame& f = frames[first + blockIdx.y];
+// Which (frame, group) a workgroup of the general sequence's pass takes.  Workgroups go to the eight XCDs in turn (workgroup L to
+// XCD L % 8), and each XCD has its own L2: with the frame = blockIdx.y the groups of one frame were spread over all eight, and a
+// 128-byte line of a plane — the rows of four neighbouring blocks — was fetched from memory by up to four L2s (TCC_EA0_RDREQ:
+// 2.2 GB per 128 S-longdress frames where the tile kernel, whose frames stay on one XCD, reads 1.3; now 0.94).  Here XCD x takes
+// frames x, x + 8, ..., kGenInterleave of them at a time with their groups in turn, every frame's groups in ascending order: a
+// group's predecessors still precede it in dispatch order.  Why several frames at a time: a group cannot finish before ALL its
+// predecessors have published their totals, so one slow group holds up every later group of its frame that is resident — with one
+// frame per XCD that is the whole XCD (1.30 ms per 128 S-longdress frames; two frames 1.07, four 0.84, eight 0.77, sixteen 0.78).
+#ifndef VPCC_GEN_INTERLEAVE
+#define VPCC_GEN_INTERLEAVE 8
+#endif
+constexpr uint32_t kGenInterleave = VPCC_GEN_INTERLEAVE;
+struct GenWork { uint32_t frame, group; bool any; };
+__device__ __forceinline__ GenWork gen_work(uint32_t first, uint32_t count, uint32_t groups_per_frame, uint32_t interleave) {
+  const uint32_t xcd = blockIdx.x & 7u, slot = blockIdx.x >> 3, per_round = interleave * groups_per_frame;
+  const uint32_t round = slot / per_round, r = slot - round * per_round, group = r / interleave, fi = r - group * interleave;
+  GenWork w;
+  w.group = group;
+  w.frame = first + (round * interleave + fi) * 8u + xcd;
+  w.any = (round * interleave + fi) * 8u + xcd < count;
+  return w;
+}
+inline uint32_t gen_grid(uint32_t count, uint32_t groups_per_frame, uint32_t interleave) {
+  const uint32_t per_xcd = (count + 7u) / 8u;
+  return 8u * ((per_xcd + interleave - 1u) / interleave) * interleave * groups_per_frame;
+}
+
+#ifndef VPCC_GEN_WAVES
+#define VPCC_GEN_WAVES 7
+#endif
+__global__ __launch_bounds__(kGenThreads) __attribute__((amdgpu_waves_per_eu(VPCC_GEN_WAVES, 8))) void k_general(const DevFrame* __restrict__ frames, uint32_t first, uint32_t count, uint32_t groups_per_frame, uint32_t interleave, uint32_t gen) {
+  const GenWork work = gen_work(first, count, groups_per_frame, interleave);
+  if (!work.any) return;
+  const DevFrame& f = frames[work.frame];
   const uint32_t R = f.R, RR = R * R, n_vb = f.n_vblocks;
   const uint32_t per = RR >= kGenThreads ? 0u : kGenThreads / RR;           // whole virtual blocks per unit (small blocks)
   const uint32_t chunks = per ? 1u : (RR + kGenThreads - 1u) / kGenThreads; // units per virtual block (large blocks)
@@ -494,11 +526,10 @@ __global__ __launch_bounds__(kGenThreads) __attribute__((amdgpu_waves_per_eu(8, 
   __shared__ __attribute__((aligned(16))) unsigned char stage_idx[2 * kGenThreads * 2 + 32];
   const uint32_t tid = threadIdx.x, wave = tid >> 6, lane = tid & 63u;
   const uint32_t log2R = (R & (R - 1u)) == 0u ? 31u - (uint32_t)__builtin_clz(R) : 0xFFu;
-  // The frame's workgroups take its groups in turn, each in ascending order (group g waits for groups before it only: they
-  // belong to workgroups that are resident — the frame's workgroups are dispatched together, blockIdx.x fastest — and that
-  // publish their totals before they wait for anything).  One workgroup per group left the chip two thirds empty: a group's
-  // 10 us were over before the dispatcher had placed the next workgroups (66 000 of them per 128 S-longdress frames).
-  for (uint32_t group = blockIdx.x; group < n_groups; group += gridDim.x) {
+  // One group per workgroup (group g waits for groups before it only: they were dispatched before it, and publish their totals
+  // before they wait for anything).
+  const uint32_t group = work.group;
+  if (group >= n_groups) return;
   // 1. the thread's pixel of each of the group's units: all of them evaluated before anything is waited for
   // (packed: a unit costs a thread 7 registers until it is emitted — x | y << 16 of each point, z0 | z1 << 16, the canvas pixel,
   // patch | points << 16 — and two for its colours)
@@ -516,12 +547,14 @@ __global__ __launch_bounds__(kGenThreads) __attribute__((amdgpu_waves_per_eu(8, 
     }
     pxy[j][0] = pxy[j][1] = pz[j] = cxy[j] = patch_n[j] = 0;
     if (active && unit < n_units) {
+      // ONE record says where the block's pixels lie and how they become points; the ownership of the block (src/codec.rs:379) and
+      // the pixel's samples are then requested together — the samples of a block that turns out to be somebody else's are not used
       const VBlock b = gload(f.vblocks + vb);
       patch_n[j] = b.patch;
-      if (gl(f.block_to_patch)[b.canvas_block] == (uint32_t)b.patch + 1u) { // src/codec.rs:379
-        const DevPatch p = gload(f.patches + b.patch);
-        const uint32_t pv = log2R != 0xFFu ? i >> log2R : i / R, pu = i - pv * R;
-        const PixelOut o = eval_pixel(f, p, b.u0 * R + pu, b.v0 * R + pv);
+      const uint32_t pv = log2R != 0xFFu ? i >> log2R : i / R, pu = i - pv * R;
+      const uint32_t owner = gl(f.block_to_patch)[b.canvas_block];
+      const PixelOut o = eval_pixel(f, b, pu, pv);
+      if (owner == (uint32_t)b.patch + 1u) {
         if (o.n) {
           pxy[j][0] = (uint32_t)o.p0.c[0] | ((uint32_t)o.p0.c[1] << 16);
           pz[j] = o.p0.c[2];
@@ -640,7 +673,227 @@ __global__ __launch_bounds__(kGenThreads) __attribute__((amdgpu_waves_per_eu(8, 
     if (f.out_patch) copy_out(stage_idx, (unsigned char*)f.out_patch, lo, n_out, 2u);
     gen_sync_lds();                                                        // (the stage is the next unit's)
   }
-  gen_sync_lds();                                                          // (wave_sum and prefix_s are the next group's)
+}
+
+// ---------------------------------------------------------- k_general_blocks
+// k_general for the frames every stream has (FrameShape::block_units: block side a power of two in [16, 256], occupancy precision a
+// power of two, strides <= 65536, every patch's three axes distinct): a unit is a 256-pixel chunk of ONE virtual block, so
+//   - the block's record and the ownership test (src/codec.rs:379) are SCALAR loads, and a unit whose block belongs to another
+//     patch costs its lanes nothing (k_general asked for the samples of every pixel of every virtual block: a third of them
+//     lie in blocks that are somebody else's);
+//   - the samples of all the group's owned units are requested in one straight stretch of code (k_general's per-lane branches
+//     made the compiler wait for one unit's samples before it asked for the next unit's record: fifteen dependent round trips
+//     per group of five units);
+//   - addresses are {scalar base, 32-bit lane offset} built with 24-bit multiply-adds (32-bit multiplies and 64-bit address
+//     arithmetic run at a quarter of the rate, and were a third of k_general's vector time);
+//   - a point is kept as (normal coordinate of each layer, canvas pixel): the tangent and bitangent coordinates are the same for
+//     both layers and recomputed when the point is staged, where the axis assignment (src/decoder.rs:871-888) is three LDS
+//     addresses instead of nine selects per point; two points of a pixel differ iff their normal coordinates do.
+// Steps 2, 4 and 5 (ranks, look-back, staging) are k_general's.
+#ifndef VPCC_GENB_WAVES
+#define VPCC_GENB_WAVES 8
+#endif
+__global__ __launch_bounds__(kGenThreads) __attribute__((amdgpu_waves_per_eu(VPCC_GENB_WAVES, 8))) void k_general_blocks(const DevFrame* __restrict__ frames, uint32_t first, uint32_t count, uint32_t groups_per_frame, uint32_t interleave, uint32_t gen) {
+  const GenWork work = gen_work(first, count, groups_per_frame, interleave);
+  if (!work.any) return;
+  const VPCC_CONST DevFrame& f = *(const VPCC_CONST DevFrame*)(frames + work.frame);   // (host-written: scalar loads)
+  constexpr uint32_t kU = kGenBlockUnits;
+  const uint32_t log2R = 31u - (uint32_t)__builtin_clz(f.R), log2C = 2u * log2R - 8u;      // R * R / 256 chunks per virtual block
+  const uint32_t n_units = f.n_vblocks << log2C, n_groups = (n_units + kU - 1u) / kU;
+  __shared__ uint32_t wave_sum[kU][4];
+  __shared__ uint32_t prefix_s;
+  constexpr uint32_t kS = kGenBlockStage;                                   // units staged together
+  __shared__ __attribute__((aligned(16))) unsigned char stage_xyz[kS * 2 * kGenThreads * 6 + 32];
+  __shared__ __attribute__((aligned(16))) unsigned char stage_rgb[kS * 2 * kGenThreads * 3 + 32];
+  __shared__ __attribute__((aligned(16))) unsigned char stage_idx[kS * 2 * kGenThreads * 2 + 32];
+  const uint32_t tid = threadIdx.x, wave = tid >> 6, lane = tid & 63u;
+  const uint32_t ps = f.prec_shift;
+  // the thread's pixel of a block's chunk c: (pu0, pv0 + c * (256 / R)) — R <= 256: a chunk is whole rows
+  const uint32_t pu0 = tid & (f.R - 1u), pv0 = tid >> log2R;
+  const ColourKeys keys = vpcc_colour_keys();
+  const bool two = f.map_count > 1u, absolute = f.absolute_d1 != 0u, has_attr = f.has_attr != 0u;
+  uint64_t* const state = reinterpret_cast<uint64_t*>(f.vb_count);          // one {generation | status | value} word per group
+  // One group per workgroup, no loop: around a loop the compiler must assume that a register it is about to write may still be the
+  // target of a load of the previous trip, and waits for ALL outstanding loads — in the middle of step 1b.
+  const uint32_t group = work.group;
+  if (group >= n_groups) return;
+  // 1a. the units' blocks, and which of them own their canvas block (uniform; no branch: all records, then all owners, are
+  // requested together — a unit past the frame's last reads block 0 and is nobody's)
+  VBlock b[kU];
+  bool own[kU];
+#pragma unroll
+  for (uint32_t j = 0; j < kU; ++j) {
+    const uint32_t unit = group * kU + j;
+    own[j] = unit < n_units;
+    b[j] = cload(f.vblocks + (own[j] ? unit >> log2C : 0u));
+  }
+#pragma unroll
+  for (uint32_t j = 0; j < kU; ++j) own[j] = own[j] & (cload(f.block_to_patch + b[j].canvas_block) == (uint32_t)b[j].patch + 1u);
+  // 1b. the thread's pixel of every owned unit: occupancy and both depths (the pixel lies inside the canvas and the planes
+  // cover it: validate_frame; one map: geo[1] is the descriptor's alias of geo[0])
+  uint32_t cxy[kU], s_occ[kU], s_d0[kU], s_d1[kU];
+#pragma unroll
+  for (uint32_t j = 0; j < kU; ++j) {
+    cxy[j] = s_occ[j] = s_d0[j] = s_d1[j] = 0;
+    if (own[j]) {
+      const int32_t pu = (int32_t)pu0, pv = (int32_t)(pv0 + ((((group * kU + j) & ((1u << log2C) - 1u)) << 8) >> log2R));
+      const int32_t cux = (int32_t)(b[j].coef & 3u) - 1, cvx = (int32_t)((b[j].coef >> 2) & 3u) - 1;   // patch_to_canvas, src/decoder.rs:841-867
+      const int32_t cuy = (int32_t)((b[j].coef >> 4) & 3u) - 1, cvy = (int32_t)(b[j].coef >> 6) - 1;
+      const uint32_t x = (uint32_t)((int32_t)b[j].x0 + __mul24(cux, pu) + __mul24(cvx, pv));
+      const uint32_t y = (uint32_t)((int32_t)b[j].y0 + __mul24(cuy, pu) + __mul24(cvy, pv));
+      cxy[j] = x | (y << 16);                                                                   // (canvas sides <= 32768)
+      s_occ[j] = ld32(f.occ, __umul24(y >> ps, f.occ_stride) + (x >> ps));                     // src/codec.rs:288-301, 393
+      s_d0[j] = ld32(f.geo[0], (__umul24(y, f.geo_stride[0]) + x) * 2u);
+      s_d1[j] = ld32(f.geo[1], (__umul24(y, f.geo_stride[1]) + x) * 2u);
+    }
+  }
+  // (Opaque to the compiler: it folds the first operation on a sample into the branch that loads it, and with it the wait for
+  // the sample — one round trip per unit instead of one per group.)
+#pragma unroll
+  for (uint32_t j = 0; j < kU; ++j) asm volatile("" : "+v"(s_occ[j]), "+v"(s_d0[j]), "+v"(s_d1[j]));
+  // 1c. the normal coordinate of the pixel's points (Patch::generate_point, src/decoder.rs:871-888; generate_points,
+  // src/codec.rs:517-565) and how many there are (codec.rs:422-427)
+  uint32_t nn[kU], np[kU];
+#pragma unroll
+  for (uint32_t j = 0; j < kU; ++j) {
+    nn[j] = np[j] = 0;
+    if (own[j]) {
+      const bool mode0 = (b[j].axes_mode >> 6) == 0u;
+      const uint32_t pd1 = b[j].d1, d0 = s_d0[j] >> 2, d1 = s_d1[j] >> 2;                       // depth / 4, codec.rs:534
+      const uint32_t n0 = (mode0 ? d0 + pd1 : (pd1 > d0 ? pd1 : d0) - d0) & 0xFFFFu;            // `as u16`
+      uint32_t n1 = n0;
+      if (two) n1 = (absolute ? (mode0 ? d1 + pd1 : (pd1 > d1 ? pd1 : d1) - d1) : (mode0 ? n0 + d1 : n0 - d1)) & 0xFFFFu;
+      nn[j] = n0 | (n1 << 16);
+      np[j] = s_occ[j] ? (n1 != n0 ? 2u : 1u) : 0u;
+    }
+  }
+  // 2. ranks inside the units
+  uint32_t before[kU];
+#pragma unroll
+  for (uint32_t j = 0; j < kU; ++j) {
+    before[j] = 0;
+    if (own[j]) {
+      const uint64_t m1 = __ballot(np[j] >= 1u), m2 = __ballot(np[j] == 2u);
+      before[j] = mbcnt(m1) + mbcnt(m2);
+      if (lane == 0) wave_sum[j][wave] = (uint32_t)__popcll(m1) + (uint32_t)__popcll(m2);
+    }
+  }
+  gen_sync_lds();
+  uint32_t ubase[kU], utot[kU], total = 0;                                   // a unit's first rank in the group, its points
+#pragma unroll
+  for (uint32_t j = 0; j < kU; ++j) {
+    uint32_t wb = 0, t = 0;
+    if (own[j]) {
+#pragma unroll
+      for (uint32_t w = 0; w < 4; ++w) {
+        const uint32_t x = wave_sum[j][w];
+        if (w < wave) wb += x;
+        t += x;
+      }
+    }
+    ubase[j] = total;
+    utot[j] = t;
+    before[j] = (before[j] + wb) | (np[j] << 16);                          // rank in the unit (<= 512) | points
+    total += t;
+  }
+  if (tid == 0)
+    __hip_atomic_store(glw(state) + group, ((uint64_t)gen << kGenGenShift) | (group ? kGenAggregate : kGenPrefix) | total, __ATOMIC_RELAXED,
+                       __HIP_MEMORY_SCOPE_AGENT);
+  // 3. colours of the thread's points (color_point_cloud, src/codec.rs:626-644: layer l of the attribute video for point l),
+  // r | g << 8 | b << 16: a layer's samples of all units are requested together
+  uint32_t col[kU][2];
+#pragma unroll
+  for (uint32_t l = 0; l < 2; ++l) {
+    const uint16_t* const ay = f.attr_y[l]; const uint16_t* const au = f.attr_u[l]; const uint16_t* const av = f.attr_v[l];
+    const uint32_t as = f.attr_stride[l], ac = f.attr_cstride[l];
+    uint32_t sy[kU], su[kU], sv[kU];
+#pragma unroll
+    for (uint32_t j = 0; j < kU; ++j) {
+      sy[j] = su[j] = sv[j] = 0;
+      if (has_attr && (before[j] >> 16) > l) {
+        const uint32_t x = cxy[j] & 0xFFFFu, y = cxy[j] >> 16;
+        const uint32_t cidx = (__umul24(y >> 1, ac) + (x >> 1)) * 2u;                           // chroma nearest neighbour
+        sy[j] = ld32(ay, (__umul24(y, as) + x) * 2u);
+        su[j] = ld32(au, cidx);
+        sv[j] = ld32(av, cidx);
+      }
+    }
+#pragma unroll
+    for (uint32_t j = 0; j < kU; ++j) asm volatile("" : "+v"(sy[j]), "+v"(su[j]), "+v"(sv[j]));
+#pragma unroll
+    for (uint32_t j = 0; j < kU; ++j) {
+      col[j][l] = 0;
+      if (has_attr && (before[j] >> 16) > l) {
+        col[j][l] = yuv10_to_rgb8_packed(sy[j], su[j], sv[j], keys);
+      }
+    }
+  }
+  // 4. look-back
+  if (wave == 0 && group) {
+    uint32_t excl = 0, spins = 0;
+    for (int32_t hi = (int32_t)group - 1; hi >= 0;) {                       // predecessors hi, hi - 1, ..., 64 at a time
+      const int32_t u = hi - (int32_t)lane;
+      const uint64_t s = u >= 0 ? __hip_atomic_load(gl(state) + u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : (((uint64_t)gen << kGenGenShift) | kGenPrefix);
+      const uint32_t st = gen_status(s, gen);
+      const uint64_t pending = __ballot(st == 0u), prefix = __ballot(st == 2u);
+      const uint32_t first_prefix = prefix ? (uint32_t)__builtin_ctzll(prefix) : 64u;
+      const uint64_t needed = first_prefix >= 63u ? ~0ull : ((2ull << first_prefix) - 1ull);   // everything in front of the nearest PREFIX
+      if (pending & needed) {
+        if (++spins > kGenSpinLimit) { if (lane == 0) atomicOr(f.error_flag, kErrorSpinLimit); break; }      // never in a healthy run
+        __builtin_amdgcn_s_sleep(1);
+        continue;
+      }
+      uint32_t v = lane <= first_prefix ? (uint32_t)s : 0u;
+      for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+      excl += v;
+      if (prefix) break;
+      hi -= 64;
+    }
+    if (lane == 0) {
+      prefix_s = excl;
+      __hip_atomic_store(glw(state) + group, ((uint64_t)gen << kGenGenShift) | kGenPrefix | (uint64_t)(excl + total), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+  } else if (tid == 0 && group == 0) {
+    prefix_s = 0;
+  }
+  gen_sync_lds();
+  const uint32_t base = prefix_s;
+  if (group == n_groups - 1u && tid == 0) *glw(f.n_points) = base + total;
+  // 5. kS units at a time: their points [first, first + pts) — one stretch of the output, the units follow each other —, clipped
+  // to the caller's capacity, laid out in LDS as they will lie in memory (a unit at a time: two barriers per unit, eight per group)
+#pragma unroll
+  for (uint32_t j0 = 0; j0 < kU; j0 += kS) {
+    uint32_t pts = 0;
+#pragma unroll
+    for (uint32_t j = j0; j < j0 + kS && j < kU; ++j) pts += utot[j];
+    if (!pts) continue;                                                     // (uniform: nothing to stage, no barrier)
+    const uint32_t p_first = base + ubase[j0];
+    const uint32_t lo = min(p_first, f.capacity), n_out = min(p_first + pts, f.capacity) - lo;
+    const uint32_t sx = (uint32_t)((uintptr_t)((const unsigned char*)f.out_xyz + (size_t)lo * 6u) & 15u);
+    const uint32_t sc = (uint32_t)((uintptr_t)((const unsigned char*)f.out_rgb + (size_t)lo * 3u) & 15u);
+    const uint32_t si = (uint32_t)((uintptr_t)((const unsigned char*)f.out_patch + (size_t)lo * 2u) & 15u);
+#pragma unroll
+    for (uint32_t j = j0; j < j0 + kS && j < kU; ++j) {
+      if (!utot[j]) continue;
+      const uint32_t k0 = ubase[j] - ubase[j0] + (before[j] & 0xFFFFu), npj = before[j] >> 16;      // rank among the staged points
+      // tangent and bitangent coordinate of the pixel (src/decoder.rs:875-876), and where the three coordinates go
+      const uint32_t pv = pv0 + ((((group * kU + j) & ((1u << log2C) - 1u)) << 8) >> log2R);
+      const uint32_t t = __umul24(pu0, b[j].lod_x) + b[j].t0, bt = __umul24(pv, b[j].lod_y) + b[j].b0;
+      const uint32_t at_n = sx + 2u * (b[j].axes_mode & 3u), at_t = sx + 2u * ((b[j].axes_mode >> 2) & 3u), at_b = sx + 2u * ((b[j].axes_mode >> 4) & 3u);
+      auto put = [&](uint32_t k, uint32_t n, uint32_t c) {
+        unsigned char* q = stage_xyz + 6u * k;                              // (2-byte aligned: arrays are 256-byte aligned, elements 6 bytes)
+        *(uint16_t*)(q + at_n) = (uint16_t)n; *(uint16_t*)(q + at_t) = (uint16_t)t; *(uint16_t*)(q + at_b) = (uint16_t)bt;
+        if (has_attr) { unsigned char* o = stage_rgb + sc + 3u * k; o[0] = (unsigned char)c; o[1] = (unsigned char)(c >> 8); o[2] = (unsigned char)(c >> 16); }
+        if (f.out_patch) *(uint16_t*)(stage_idx + si + 2u * k) = b[j].patch;                   // partition, codec.rs:452
+      };
+      if (npj >= 1u && k0 < n_out) put(k0, nn[j], col[j][0]);              // (n_out: the caller's capacity)
+      if (npj == 2u && k0 + 1u < n_out) put(k0 + 1u, nn[j] >> 16, col[j][1]);
+    }
+    gen_sync_lds();
+    copy_out(stage_xyz, (unsigned char*)f.out_xyz, lo, n_out, 6u);
+    if (has_attr) copy_out(stage_rgb, (unsigned char*)f.out_rgb, lo, n_out, 3u);
+    if (f.out_patch) copy_out(stage_idx, (unsigned char*)f.out_patch, lo, n_out, 2u);
+    if (j0 + kS < kU) gen_sync_lds();                                      // (the stage is the next units')
   }
 }
 
@@ -661,13 +914,15 @@ void launch_block_owner(const DevFrame* d_frames, uint32_t first, uint32_t count
   else
     hipLaunchKernelGGL(k_block_owner<64>, dim3((max_vb + 3) / 4, count), dim3(256), 0, (hipStream_t)stream, d_frames, first);
 }
-void launch_general(const DevFrame* d_frames, uint32_t first, uint32_t count, uint32_t max_units, uint32_t gen, uint32_t resident_wgs, void* stream) {
+void launch_general(const DevFrame* d_frames, uint32_t first, uint32_t count, uint32_t max_units, uint32_t gen, bool block_units, void* stream) {
   if (!count || !max_units) return;
-  // as many workgroups per frame as stay resident together over all frames of the launch (at least one, at most a group each)
+  if (block_units) {
+    const uint32_t groups = (max_units + kGenBlockUnits - 1u) / kGenBlockUnits;
+    hipLaunchKernelGGL(k_general_blocks, dim3(gen_grid(count, groups, kGenInterleave)), dim3(kGenThreads), 0, (hipStream_t)stream, d_frames, first, count, groups, kGenInterleave, gen);
+    return;
+  }
   const uint32_t groups = (max_units + kGenUnitsPerGroup - 1u) / kGenUnitsPerGroup;
-  static const bool persistent = getenv("VPCC_GENERAL_PERSISTENT") != nullptr;      // (measured: 2.02 ms against 1.89 with a workgroup per group)
-  const uint32_t per_frame = persistent ? std::max(1u, std::min(groups, resident_wgs / count)) : groups;
-  hipLaunchKernelGGL(k_general, dim3(per_frame, count), dim3(kGenThreads), 0, (hipStream_t)stream, d_frames, first, gen);
+  hipLaunchKernelGGL(k_general, dim3(gen_grid(count, groups, kGenInterleave)), dim3(kGenThreads), 0, (hipStream_t)stream, d_frames, first, count, groups, kGenInterleave, gen);
 }
 // Plane ingest by the GPU itself: every workgroup pulls 64-KB pieces of page-locked HOST memory over PCIe (zero-copy
 // reads, 16 B per lane, coalesced) and stores them in HBM.  One launch moves all planes of a gof: 57 GB/s with 64
