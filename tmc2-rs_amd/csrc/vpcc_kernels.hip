@@ -690,6 +690,14 @@ __global__ __launch_bounds__(kGenThreads) __attribute__((amdgpu_waves_per_eu(VPC
 //     both layers and recomputed when the point is staged, where the axis assignment (src/decoder.rs:871-888) is three LDS
 //     addresses instead of nine selects per point; two points of a pixel differ iff their normal coordinates do.
 // Steps 2, 4 and 5 (ranks, look-back, staging) are k_general's.
+#ifdef VPCC_GEN_STAMPS                                    // tools/exp_general_stamps.py: where a group's time goes (never in the product)
+constexpr uint32_t kGenStampEvery = 397, kGenStampSlots = 512;
+__device__ unsigned long long g_gen_stamps[kGenStampSlots][16];
+#define VPCC_GSTAMP(k) do { __builtin_amdgcn_sched_barrier(0); if (blockIdx.x % kGenStampEvery == 0 && blockIdx.x / kGenStampEvery < kGenStampSlots && threadIdx.x == 0) \
+    g_gen_stamps[blockIdx.x / kGenStampEvery][(k)] = __builtin_amdgcn_s_memrealtime(); __builtin_amdgcn_sched_barrier(0); } while (0)
+#else
+#define VPCC_GSTAMP(k) do { } while (0)
+#endif
 #ifndef VPCC_GENB_WAVES
 #define VPCC_GENB_WAVES 8
 #endif
@@ -717,6 +725,7 @@ __global__ __launch_bounds__(kGenThreads) __attribute__((amdgpu_waves_per_eu(VPC
   // target of a load of the previous trip, and waits for ALL outstanding loads — in the middle of step 1b.
   const uint32_t group = work.group;
   if (group >= n_groups) return;
+  VPCC_GSTAMP(0);
   // 1a. the units' blocks, and which of them own their canvas block (uniform; no branch: all records, then all owners, are
   // requested together — a unit past the frame's last reads block 0 and is nobody's)
   VBlock b[kU];
@@ -729,6 +738,7 @@ __global__ __launch_bounds__(kGenThreads) __attribute__((amdgpu_waves_per_eu(VPC
   }
 #pragma unroll
   for (uint32_t j = 0; j < kU; ++j) own[j] = own[j] & (cload(f.block_to_patch + b[j].canvas_block) == (uint32_t)b[j].patch + 1u);
+  VPCC_GSTAMP(1);
   // 1b. the thread's pixel of every owned unit: occupancy and both depths (the pixel lies inside the canvas and the planes
   // cover it: validate_frame; one map: geo[1] is the descriptor's alias of geo[0])
   uint32_t cxy[kU], s_occ[kU], s_d0[kU], s_d1[kU];
@@ -747,10 +757,12 @@ __global__ __launch_bounds__(kGenThreads) __attribute__((amdgpu_waves_per_eu(VPC
       s_d1[j] = ld32(f.geo[1], (__umul24(y, f.geo_stride[1]) + x) * 2u);
     }
   }
+  VPCC_GSTAMP(2);
   // (Opaque to the compiler: it folds the first operation on a sample into the branch that loads it, and with it the wait for
   // the sample — one round trip per unit instead of one per group.)
 #pragma unroll
   for (uint32_t j = 0; j < kU; ++j) asm volatile("" : "+v"(s_occ[j]), "+v"(s_d0[j]), "+v"(s_d1[j]));
+  VPCC_GSTAMP(3);
   // 1c. the normal coordinate of the pixel's points (Patch::generate_point, src/decoder.rs:871-888; generate_points,
   // src/codec.rs:517-565) and how many there are (codec.rs:422-427)
   uint32_t nn[kU], np[kU];
@@ -779,6 +791,7 @@ __global__ __launch_bounds__(kGenThreads) __attribute__((amdgpu_waves_per_eu(VPC
     }
   }
   gen_sync_lds();
+  VPCC_GSTAMP(4);
   uint32_t ubase[kU], utot[kU], total = 0;                                   // a unit's first rank in the group, its points
 #pragma unroll
   for (uint32_t j = 0; j < kU; ++j) {
@@ -827,6 +840,7 @@ __global__ __launch_bounds__(kGenThreads) __attribute__((amdgpu_waves_per_eu(VPC
         col[j][l] = yuv10_to_rgb8_packed(sy[j], su[j], sv[j], keys);
       }
     }
+    VPCC_GSTAMP(5 + l);
   }
   // 4. look-back
   if (wave == 0 && group) {
@@ -856,7 +870,9 @@ __global__ __launch_bounds__(kGenThreads) __attribute__((amdgpu_waves_per_eu(VPC
   } else if (tid == 0 && group == 0) {
     prefix_s = 0;
   }
+  VPCC_GSTAMP(7);
   gen_sync_lds();
+  VPCC_GSTAMP(8);
   const uint32_t base = prefix_s;
   if (group == n_groups - 1u && tid == 0) *glw(f.n_points) = base + total;
   // 5. kS units at a time: their points [first, first + pts) — one stretch of the output, the units follow each other —, clipped
@@ -894,8 +910,15 @@ __global__ __launch_bounds__(kGenThreads) __attribute__((amdgpu_waves_per_eu(VPC
     if (has_attr) copy_out(stage_rgb, (unsigned char*)f.out_rgb, lo, n_out, 3u);
     if (f.out_patch) copy_out(stage_idx, (unsigned char*)f.out_patch, lo, n_out, 2u);
     if (j0 + kS < kU) gen_sync_lds();                                      // (the stage is the next units')
+    VPCC_GSTAMP(9 + j0 / kS);
   }
+  VPCC_GSTAMP(15);
 }
+#ifdef VPCC_GEN_STAMPS
+extern "C" int vpcc_debug_general_stamps(unsigned long long* out) {
+  return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_gen_stamps), sizeof(unsigned long long) * kGenStampSlots * 16) == hipSuccess ? 0 : 1;
+}
+#endif
 
 // ---------------------------------------------------- k_upsample_occupancy
 // tile.occupancy_map, src/codec.rs:288-301 (kept for API completeness; the main path never builds it).

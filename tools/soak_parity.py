@@ -39,16 +39,17 @@ def frame(i, R):
 ctx = recon.Context(0)
 done = bad = 0
 t0 = time.time()
-paths = {"tiles": 0, "general": 0}
+paths = {"tiles": 0, "general": 0, "general, block units": 0}
 modes = [0, 0, 0]
 while done < n_total:
     k = int(rng.integers(1, 41))
-    R = int(rng.choice([16] * 7 + [8, 32, 4]))                  # one block size per gof: gofs of 16s take the tile kernel
+    R = int(rng.choice([16] * 7 + [8, 32, 4, 64]))                  # one block size per gof: gofs of 16s take the tile kernel
     frames = [frame(done + j, R) for j in range(k)]
     refs = [ob.reconstruct(f) for f in frames]
     mode = int(rng.choice([0, 0, 1, 2]))                          # planes: the host's / the caller's device planes, borrowed / ... copied
+    force = _abi.VPCC_GOF_FORCE_GENERAL if rng.random() < 0.25 else 0   # a quarter of the gofs of 16s through the general sequence too
     if mode == 0:
-        g = ctx.gof(frames, flags=_abi.VPCC_GOF_WANT_PATCH_INDEX | _abi.VPCC_GOF_PROFILE)
+        g = ctx.gof(frames, flags=_abi.VPCC_GOF_WANT_PATCH_INDEX | _abi.VPCC_GOF_PROFILE | force)
     else:
         keep, descs = [], []
         def up(a):
@@ -70,14 +71,14 @@ while done < n_total:
             descs.append(d)
         torch.cuda.synchronize()
         g = ctx.gof(None, memory=_abi.VPCC_MEM_DEVICE, descs=descs,
-                    flags=_abi.VPCC_GOF_WANT_PATCH_INDEX | _abi.VPCC_GOF_PROFILE | (_abi.VPCC_GOF_COPY_PLANES if mode == 2 else 0))
+                    flags=_abi.VPCC_GOF_WANT_PATCH_INDEX | _abi.VPCC_GOF_PROFILE | force | (_abi.VPCC_GOF_COPY_PLANES if mode == 2 else 0))
         if mode == 2:
             del keep[:]                                          # copied: the caller's planes may go
             torch.cuda.synchronize()
     modes[mode] += k
     g.reconstruct()
     names = [n for n, _ in g.kernel_times()]
-    paths["tiles" if any("k_recon_tiles" in n for n in names) else "general"] += k
+    paths["tiles" if any("k_recon_tiles" in n for n in names) else "general, block units" if "k_general_blocks" in names else "general"] += k
     for j, (st, ref) in enumerate(refs):
         got = g.download(j, want_patch_index=True)
         colours = frames[j]["attribute_count"] > 0               # (a frame without attribute: with_colors == false, nothing is written)
