@@ -6,6 +6,8 @@
 //                    (src/codec.rs:517-565, src/decoder.rs:871-888), counted, ranked by a decoupled look-back over units of up to
 //                    256 pixels, and emitted — fused with the attribute gather (src/codec.rs:569-658) and YUV->RGB
 //                    (src/codec.rs:661-687) — through LDS as whole 16-byte pieces of the output arrays
+//   k_general_blocks : the same pass for frames whose units are chunks of ONE virtual block (block side 16 ... 256): what a block
+//                    decides is scalar work, and a block that belongs to another patch costs nothing
 // The W x H occupancy map of src/codec.rs:288-301, point_to_pixel and colors16bit are never
 // materialised: occupancy is read through the low-resolution plane, and colour is fetched by the
 // thread that emits the point.
