@@ -18,6 +18,25 @@ int main(int argc, char** argv) {
   static uint8_t dummy8[16];
   static uint16_t dummy16[16];
   long accepted = 0, rejected = 0, items = 0, rotated = 0;
+  // The general sequence's (frame, group) of a workgroup (gen_work_of): every pair of the launch exactly once, a frame on ONE XCD
+  // (workgroup L runs on XCD L % 8), and inside a frame the workgroup number grows with the group — what the look-back relies on.
+  for (long it = 0; it < std::min(iterations, 200L); ++it) {
+    const uint32_t count = 1 + below(140), groups = 1 + below(60), il = 1 + below(16);
+    const uint32_t grid = vpcc::gen_grid_size(count, groups, il);
+    std::vector<int64_t> last((size_t)count, -1), at((size_t)count * groups, -1);
+    for (uint32_t L = 0; L < grid; ++L) {
+      const vpcc::GenWork w = vpcc::gen_work_of(L, count, groups, il);
+      if (!w.any) continue;
+      if (w.frame >= count || w.group >= groups) { std::fprintf(stderr, "gen_work_of: out of range\n"); return 1; }
+      if (w.frame % 8u != L % 8u) { std::fprintf(stderr, "gen_work_of: frame %u on XCD %u\n", w.frame, L % 8u); return 1; }
+      if (at[(size_t)w.frame * groups + w.group] >= 0) { std::fprintf(stderr, "gen_work_of: (%u, %u) twice\n", w.frame, w.group); return 1; }
+      at[(size_t)w.frame * groups + w.group] = L;
+      if ((int64_t)w.group != last[w.frame] + 1) { std::fprintf(stderr, "gen_work_of: groups of frame %u out of order\n", w.frame); return 1; }
+      last[w.frame] = w.group;
+    }
+    for (uint32_t i = 0; i < count; ++i)
+      if (last[i] != (int64_t)groups - 1) { std::fprintf(stderr, "gen_work_of: frame %u misses groups (count %u, groups %u, interleave %u)\n", i, count, groups, il); return 1; }
+  }
   for (long it = 0; it < iterations; ++it) {
     vpcc_frame_desc f{};
     const uint32_t R = 1u << (3 + below(3)), prec = 1u << below(3);
@@ -227,7 +246,8 @@ int main(int argc, char** argv) {
       if (rq.general_records) {
         arena.push_back({o.patches, o.patches + 64 * std::max<size_t>(P, 1), "patches"});
         if (o.patches + 64 * P > L.host_end) { std::fprintf(stderr, "layout: patches behind host_end\n"); return 1; }
-        arena.push_back({o.vblocks, o.vblocks + 16 * vbn, "vblocks"});
+        arena.push_back({o.vblocks, o.vblocks + sizeof(vpcc::VBlock) * vbn, "vblocks"});
+        if (o.vblocks & 15) { std::fprintf(stderr, "layout: virtual blocks not aligned for 16-byte scalar loads\n"); return 1; }
         const size_t units = vpcc::general_units(fr[i].occupancy_resolution, sh[i].n_vblocks);      // status words: inside the control region
         if (o.vb_count < L.scan || o.vb_count + 8 * units > L.ctrl_begin + L.ctrl_bytes || (o.vb_count & 7)) { std::fprintf(stderr, "layout: unit status words\n"); return 1; }
         if (i + 1 < n && L.f[i + 1].vb_count != o.vb_count + 8 * units) { std::fprintf(stderr, "layout: unit status words overlap\n"); return 1; }

@@ -282,6 +282,23 @@ VPCC_HD inline uint32_t general_units(uint32_t R, uint32_t n_vblocks) {
   const uint32_t per = (uint32_t)(256u / RR);
   return (n_vblocks + per - 1u) / per;
 }
+// Which (frame of the launch, group) workgroup L of the pass takes, and how many workgroups a launch has: XCD L % 8 takes frames
+// L % 8, L % 8 + 8, ..., `interleave` of them at a time with their groups in turn (why: vpcc_kernels.hip).  What the look-back relies
+// on: every (frame, group) is taken exactly once, and L grows with the group inside a frame.
+struct GenWork { uint32_t frame, group; bool any; };
+VPCC_HD inline GenWork gen_work_of(uint32_t L, uint32_t count, uint32_t groups_per_frame, uint32_t interleave) {
+  const uint32_t xcd = L & 7u, slot = L >> 3, per_round = interleave * groups_per_frame;
+  const uint32_t round = slot / per_round, r = slot - round * per_round, group = r / interleave, fi = r - group * interleave;
+  GenWork w;
+  w.group = group;
+  w.frame = (round * interleave + fi) * 8u + xcd;
+  w.any = w.frame < count;
+  return w;
+}
+inline uint32_t gen_grid_size(uint32_t count, uint32_t groups_per_frame, uint32_t interleave) {
+  const uint32_t per_xcd = (count + 7u) / 8u;
+  return 8u * ((per_xcd + interleave - 1u) / interleave) * interleave * groups_per_frame;
+}
 // block_units: every frame of the launch has FrameShape::block_units (vpcc_host.hpp) — k_general_blocks, whose units are chunks
 // of ONE virtual block each, so that everything a block decides is scalar work; else k_general, which takes any frame.
 void launch_general(const DevFrame* d_frames, uint32_t first, uint32_t count, uint32_t max_units, uint32_t gen, bool block_units, void* stream);

@@ -493,19 +493,10 @@ __device__ __forceinline__ void copy_out(const unsigned char* lds, unsigned char
 #define VPCC_GEN_INTERLEAVE 8
 #endif
 constexpr uint32_t kGenInterleave = VPCC_GEN_INTERLEAVE;
-struct GenWork { uint32_t frame, group; bool any; };
 __device__ __forceinline__ GenWork gen_work(uint32_t first, uint32_t count, uint32_t groups_per_frame, uint32_t interleave) {
-  const uint32_t xcd = blockIdx.x & 7u, slot = blockIdx.x >> 3, per_round = interleave * groups_per_frame;
-  const uint32_t round = slot / per_round, r = slot - round * per_round, group = r / interleave, fi = r - group * interleave;
-  GenWork w;
-  w.group = group;
-  w.frame = first + (round * interleave + fi) * 8u + xcd;
-  w.any = (round * interleave + fi) * 8u + xcd < count;
+  GenWork w = gen_work_of(blockIdx.x, count, groups_per_frame, interleave);      // vpcc_device.hpp (tests/fuzz_plan.cpp checks it on the CPU)
+  w.frame += first;
   return w;
-}
-inline uint32_t gen_grid(uint32_t count, uint32_t groups_per_frame, uint32_t interleave) {
-  const uint32_t per_xcd = (count + 7u) / 8u;
-  return 8u * ((per_xcd + interleave - 1u) / interleave) * interleave * groups_per_frame;
 }
 
 #ifndef VPCC_GEN_WAVES
@@ -943,11 +934,11 @@ void launch_general(const DevFrame* d_frames, uint32_t first, uint32_t count, ui
   if (!count || !max_units) return;
   if (block_units) {
     const uint32_t groups = (max_units + kGenBlockUnits - 1u) / kGenBlockUnits;
-    hipLaunchKernelGGL(k_general_blocks, dim3(gen_grid(count, groups, kGenInterleave)), dim3(kGenThreads), 0, (hipStream_t)stream, d_frames, first, count, groups, kGenInterleave, gen);
+    hipLaunchKernelGGL(k_general_blocks, dim3(gen_grid_size(count, groups, kGenInterleave)), dim3(kGenThreads), 0, (hipStream_t)stream, d_frames, first, count, groups, kGenInterleave, gen);
     return;
   }
   const uint32_t groups = (max_units + kGenUnitsPerGroup - 1u) / kGenUnitsPerGroup;
-  hipLaunchKernelGGL(k_general, dim3(gen_grid(count, groups, kGenInterleave)), dim3(kGenThreads), 0, (hipStream_t)stream, d_frames, first, count, groups, kGenInterleave, gen);
+  hipLaunchKernelGGL(k_general, dim3(gen_grid_size(count, groups, kGenInterleave)), dim3(kGenThreads), 0, (hipStream_t)stream, d_frames, first, count, groups, kGenInterleave, gen);
 }
 // Plane ingest by the GPU itself: every workgroup pulls 64-KB pieces of page-locked HOST memory over PCIe (zero-copy
 // reads, 16 B per lane, coalesced) and stores them in HBM.  One launch moves all planes of a gof: 57 GB/s with 64
