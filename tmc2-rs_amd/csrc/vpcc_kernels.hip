@@ -440,8 +440,8 @@ void launch_plan_vblocks(DevFrame* d_frames, uint32_t first, uint32_t count, uin
 //   5. the unit's points are laid out in LDS exactly as they will lie in memory — at the output address modulo 16 — and leave
 //      as whole aligned 16-byte pieces (non-temporal), the ragged first and last piece byte by byte: ~190 + 95 store
 //      instructions per unit of ~450 points where k_emit issued six 2-byte / 1-byte stores per point.
-// Units are dispatched in emission order (blockIdx.x fastest), so a unit only ever waits for units that were dispatched before
-// it.  Status words carry the launch generation: nothing is cleared between launches.
+// A frame's groups are dispatched in ascending order (gen_work_of, vpcc_device.hpp), so a group only ever waits for groups that
+// were dispatched before it.  Status words carry the launch generation: nothing is cleared between launches.
 namespace {
 constexpr uint32_t kGenThreads = 256;
 constexpr uint64_t kGenStatusShift = 32, kGenGenShift = 34;

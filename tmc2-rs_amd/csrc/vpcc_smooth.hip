@@ -110,16 +110,17 @@ __device__ __forceinline__ uint32_t qperm(uint32_t v) {
 // multiple of four cells apart in every axis); the table holds cells of one patch at a time and lives as long as it can:
 //   1. a lane adds up, in registers, those of its four points that share a cell — pairwise (1 into 0, 3 into 2), then
 //      2 into 0: A A A A becomes one LEADER, A A B B two, the rest stay on their own (a cell may have several leaders);
-//   2. every leader swaps its cell into its slot if the slot is free (LDS compare-and-swap), and all look at what the slot
-//      holds now: a leader whose cell it is has the slot, the others stay PENDING;
-//   3. the leaders that have their slot add their sums to it with LDS atomics (six words: x, y, z, count + R << 16, G, B);
+//   2. every leader swaps its cell into its slot if the slot is free (LDS compare-and-swap); what the swap returns — free, or the
+//      leader's own cell — says whether the slot is the leader's: the others stay PENDING;
+//   3. the leaders that have their slot add their sums to it with LDS atomics (three 64-bit words: x | y, z | G, count | R | B);
 //   4. while leaders are pending, the table is flushed — which frees every slot — and they try again (at least one per
 //      contended slot succeeds each time); it is flushed for good after the wave's last chunk, and before points of
 //      another patch (a chunk that holds several patches is worked on patch by patch);
 //   flush: lane s owns slot s: the occupied slots are lined up, appended to the wave's cell list, and lane 4 j + t
 //      carries 64-bit word t of the j-th cell: the four words of a cell leave as ONE 32-byte atomic request
 //      ({count, s0}, {s1, s2}, sum of squared patch indices, {sum of patch indices, 0}: no carry crosses a pair's halves;
-//      the table holds ONE patch, so the patch sums follow from the count).  Every field of a cell is a sum, so it does
+//      the table holds ONE patch, so the patch sums follow from the count), and lanes 4 j and 4 j + 1 the two words of its
+//      colour cell.  Every field of a cell is a sum, so it does
 //      not matter in how many parts a wave delivers a cell.
 // The grids are all-zero between launches: k_smooth_clear zeroes exactly the listed cells afterwards — no dense memset
 // (50 MB per frame at w = 128) per launch.
@@ -130,9 +131,14 @@ __device__ __forceinline__ uint32_t qperm(uint32_t v) {
 // wave-wide reductions for waves with a collision, 0.15-0.17 (it is the number of atomic REQUESTS that counts: the
 // elected lanes issuing four 8-byte atomics each was 3 x slower).
 struct StatTable {
-  uint32_t key[128];           // [0, 64): cell index of the slot's cell, all-ones: free; [64, 128): a DUMP slot per lane —
-  uint32_t acc[5][128];        //   what a lane without a leader reads and "adds" to, so that nothing here needs a branch
-  uint64_t cnt_r[128];         // x, y, z, G, B | count + (R << 16): the red sum grows into the upper half
+  uint32_t key[64];            // cell index of the slot's cell, all-ones: free
+  // The sums of a slot in THREE 64-bit words: it was six LDS adds per leader (x, y, z, count + R << 16, G, B) and a look at the slot
+  // behind the compare-and-swap, on the CU's one LDS — INSTS_LDS 22.4 M -> 11.8 M per launch, the kernel 0.439 -> 0.379 ms (round 5).
+  // No field reaches its neighbour: a table lives for kSmoothListSpan <= 1 024 points, so count < 2^11, a colour sum < 2^18, a
+  // coordinate sum < 2^26.
+  uint64_t xy[64];             // x | y << 32
+  uint64_t zg[64];             // z | G << 32
+  uint64_t crb[64];            // count | R << 16 | B << 40
   uint32_t order[64];          // the occupied slots, lined up
 };
 constexpr uint32_t kFreeSlot = 0xFFFFFFFFu;                  // (cells < 2^32 - 1: vpcc_gof_smooth)
@@ -166,34 +172,28 @@ __device__ __forceinline__ void stats_flush(StatTable& T, const StatDst& dst, ui
     if (j < ncell) {
       const uint32_t sl = T.order[j];
       const uint32_t k = T.key[sl];
-      const uint64_t cr = T.cnt_r[sl];
+      const uint64_t cr = T.crb[sl], zg = T.zg[sl], xy = kMode == 1u ? 0ull : T.xy[sl];
       const uint32_t cnt = (uint32_t)cr & 0xFFFFu;
-      const uint32_t s0 = kMode == 1u ? (uint32_t)(cr >> 16) : T.acc[0][sl];
-      const uint32_t s1 = T.acc[kMode == 1u ? 3 : 1][sl], s2 = T.acc[kMode == 1u ? 4 : 2][sl];
+      const uint32_t s0 = kMode == 1u ? (uint32_t)(cr >> 16) & 0xFFFFFFu : (uint32_t)xy;                      // (mode 1: R, G, B)
+      const uint32_t s1 = kMode == 1u ? (uint32_t)(zg >> 32) : (uint32_t)(xy >> 32), s2 = kMode == 1u ? (uint32_t)(cr >> 40) : (uint32_t)zg;
       const uint32_t sp = cnt * pl;
       const uint64_t val = t == 0 ? (uint64_t)cnt | ((uint64_t)s0 << 32)
                          : t == 1 ? (uint64_t)s1 | ((uint64_t)s2 << 32)
                          : t == 2 ? (uint64_t)sp * pl : (uint64_t)sp;
       atomicAdd(reinterpret_cast<unsigned long long*>(dst.grid + k) + t, (unsigned long long)val);
-    }
-  }
-  if (kMode == 2u)                                           // the colour cells: lane 2 j + t carries word t of the j-th
-    for (uint32_t base = 0; base < ncell; base += 32u) {
-      const uint32_t j = base + (lane >> 1), t = lane & 1u;
-      if (j < ncell) {
-        const uint32_t sl = T.order[j];
-        const uint64_t cr = T.cnt_r[sl];
-        const uint64_t val = t == 0 ? (cr & 0xFFFFull) | ((cr >> 16) << 32)                          // {count, R}
-                                    : (uint64_t)T.acc[3][sl] | ((uint64_t)T.acc[4][sl] << 32);       // {G, B}
-        atomicAdd(reinterpret_cast<unsigned long long*>(dst.cgrid + T.key[sl]) + t, (unsigned long long)val);
+      if (kMode == 2u && t < 2u) {                           // the colour cell, from the same words of the table: lanes 0 and 1 of the four
+        const uint64_t cval = t == 0 ? (cr & 0xFFFFull) | (((cr >> 16) & 0xFFFFFFull) << 32)         // {count, R}
+                                     : (zg >> 32) | ((cr >> 40) << 32);                              // {G, B}
+        atomicAdd(reinterpret_cast<unsigned long long*>(dst.cgrid + k) + t, (unsigned long long)cval);
       }
     }
+  }
   __builtin_amdgcn_wave_barrier();
   if (occupied) {
     T.key[lane] = kFreeSlot;
-    T.cnt_r[lane] = 0ull;
-#pragma unroll
-    for (int q = 0; q < 5; ++q) if ((kWords >> q) & 1u) T.acc[q][lane] = 0u;
+    T.crb[lane] = 0ull;
+    T.zg[lane] = 0ull;
+    if (kWords & 3u) T.xy[lane] = 0ull;
   }
   __builtin_amdgcn_wave_barrier();
   m += ncell;
@@ -278,34 +278,24 @@ __device__ __forceinline__ void stats_chunk(const QuadIn& in, uint32_t nvalid, c
       if (same2 && (lane & 2u)) pend0 = false;
     }
     for (;;) {
-      // 2. a slot each: compare-and-swap "free -> my cell" (a lane without a leader does it to its dump slot), in the
-      // order of the points; then everybody looks at what the slot holds now
-      uint32_t at[4];
-#pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        at[j] = pend(j) ? slot[j] : 64u + lane;
-        if (j == 0) atomicCAS(&T.key[at[j]], kFreeSlot, key[j]);
-        else if (pend(j)) atomicCAS(&T.key[at[j]], kFreeSlot, key[j]);
-      }
-      __builtin_amdgcn_wave_barrier();
-      // 3. add (a leader that did not get its slot: to the dump)
+      // 2. a slot each, leader by leader: compare-and-swap "free -> my cell".  What the swap RETURNS says whose the slot is — it was
+      // free (now mine) or held my cell already —: no second look at the slot;
+      // 3. the leaders that have their slot add their sums to it, three 64-bit LDS adds; the others stay pending
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
         auto add = [&](uint32_t to) {
-          if (kWords & 1u) atomicAdd(&T.acc[0][to], W[j][0]);
-          if (kWords & 2u) atomicAdd(&T.acc[1][to], W[j][1]);
-          if (kWords & 4u) atomicAdd(&T.acc[2][to], W[j][2]);
-          atomicAdd(reinterpret_cast<unsigned long long*>(&T.cnt_r[to]), (unsigned long long)W[j][3]);
-          if (kWords & 8u) atomicAdd(&T.acc[3][to], W[j][4] & 0xFFFFu);
-          if (kWords & 16u) atomicAdd(&T.acc[4][to], W[j][4] >> 16);
+          typedef unsigned long long u64;
+          if (kWords & 3u) atomicAdd(reinterpret_cast<u64*>(&T.xy[to]), (u64)W[j][0] | ((u64)W[j][1] << 32));
+          if (kMode == 2u) atomicAdd(reinterpret_cast<u64*>(&T.zg[to]), (u64)W[j][2] | ((u64)(W[j][4] & 0xFFFFu) << 32));
+          else if (kMode == 0u) atomicAdd(reinterpret_cast<uint32_t*>(&T.zg[to]), W[j][2]);                   // (the low half: z)
+          else atomicAdd(reinterpret_cast<uint32_t*>(&T.zg[to]) + 1, W[j][4] & 0xFFFFu);                     // (the high half: G)
+          if (kMode == 0u) atomicAdd(reinterpret_cast<uint32_t*>(&T.crb[to]), W[j][3]);                      // (no colours: the count)
+          else atomicAdd(reinterpret_cast<u64*>(&T.crb[to]), (u64)W[j][3] | ((u64)(W[j][4] >> 16) << 40));
         };
-        if (j == 0) {                                         // every lane that kept its first leader: no branch
-          const bool hit = pend(j) && T.key[at[j]] == key[j];
-          add(hit ? at[j] : 64u + lane);
-          pend(j) = pend(j) && !hit;
-        } else if (pend(j)) {                                 // few lanes have one here
-          if (T.key[at[j]] == key[j]) {
-            add(at[j]);
+        if (pend(j)) {                                        // (leaders only: the LDS's time goes with the lanes that take part)
+          const uint32_t was = atomicCAS(&T.key[slot[j]], kFreeSlot, key[j]);
+          if (was == kFreeSlot || was == key[j]) {
+            add(slot[j]);
             pend(j) = false;
           }
         }
@@ -343,10 +333,8 @@ __global__ __launch_bounds__(256) void k_smooth_stats(const DevFrame* __restrict
   const uint32_t span = blockIdx.x * 4u + wave;                          // the wave's kSmoothListSpan points
   if (span * kSmoothListSpan >= n) return;
   StatTable& T = s_tab[wave];
-  T.key[lane] = kFreeSlot; T.key[64u + lane] = 0u;
-  T.cnt_r[lane] = 0ull;
-#pragma unroll
-  for (int q = 0; q < 5; ++q) T.acc[q][lane] = 0u;
+  T.key[lane] = kFreeSlot;
+  T.xy[lane] = T.zg[lane] = T.crb[lane] = 0ull;
   StatDst dst;
   dst.grid = sg.cells(blockIdx.y);
   dst.cgrid = sg.color_cells(blockIdx.y);
