@@ -21,14 +21,18 @@ int main(int argc, char** argv) {
   // The general sequence's (frame, group) of a workgroup (gen_work_of): every pair of the launch exactly once, a frame on ONE XCD
   // (workgroup L runs on XCD L % 8), and inside a frame the workgroup number grows with the group — what the look-back relies on.
   for (long it = 0; it < std::min(iterations, 200L); ++it) {
-    const uint32_t count = 1 + below(140), groups = 1 + below(60), il = 1 + below(16);
-    const uint32_t grid = vpcc::gen_grid_size(count, groups, il);
+    const uint32_t count = 1 + below(it % 3 ? 140 : 12), groups = 1 + below(60);
+    const vpcc::GenShape shape = vpcc::gen_shape(count, groups, 1 + below(16));
+    const uint32_t grid = shape.grid, il = shape.interleave;
+    if (shape.lanes != std::min(count, 8u) || (uint64_t)grid > (uint64_t)8 * il * groups * ((count + 8 * il - 1) / (8 * il)) ||
+        (count <= 8 * il && grid != shape.lanes * ((count + shape.lanes - 1) / shape.lanes) * groups)) {
+      std::fprintf(stderr, "gen_shape: %u frames, %u groups: lanes %u interleave %u grid %u\n", count, groups, shape.lanes, il, grid); return 1; }
     std::vector<int64_t> last((size_t)count, -1), at((size_t)count * groups, -1);
     for (uint32_t L = 0; L < grid; ++L) {
-      const vpcc::GenWork w = vpcc::gen_work_of(L, count, groups, il);
+      const vpcc::GenWork w = vpcc::gen_work_of(L, count, groups, il, shape.lanes);
       if (!w.any) continue;
       if (w.frame >= count || w.group >= groups) { std::fprintf(stderr, "gen_work_of: out of range\n"); return 1; }
-      if (w.frame % 8u != L % 8u) { std::fprintf(stderr, "gen_work_of: frame %u on XCD %u\n", w.frame, L % 8u); return 1; }
+      if (shape.lanes == 8u && w.frame % 8u != L % 8u) { std::fprintf(stderr, "gen_work_of: frame %u on XCD %u\n", w.frame, L % 8u); return 1; }
       if (at[(size_t)w.frame * groups + w.group] >= 0) { std::fprintf(stderr, "gen_work_of: (%u, %u) twice\n", w.frame, w.group); return 1; }
       at[(size_t)w.frame * groups + w.group] = L;
       if ((int64_t)w.group != last[w.frame] + 1) { std::fprintf(stderr, "gen_work_of: groups of frame %u out of order\n", w.frame); return 1; }

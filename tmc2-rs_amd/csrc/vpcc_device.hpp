@@ -282,22 +282,29 @@ VPCC_HD inline uint32_t general_units(uint32_t R, uint32_t n_vblocks) {
   const uint32_t per = (uint32_t)(256u / RR);
   return (n_vblocks + per - 1u) / per;
 }
-// Which (frame of the launch, group) workgroup L of the pass takes, and how many workgroups a launch has: XCD L % 8 takes frames
-// L % 8, L % 8 + 8, ..., `interleave` of them at a time with their groups in turn (why: vpcc_kernels.hip).  What the look-back relies
-// on: every (frame, group) is taken exactly once, and L grows with the group inside a frame.
+// Which (frame of the launch, group) workgroup L of the pass takes, and how many workgroups a launch has: of `lanes` lanes — the eight
+// XCDs (workgroup L runs on XCD L % 8) for launches of eight frames or more, else one per frame — lane x takes frames x, x + lanes, ...,
+// `interleave` of them at a time with their groups in turn (why: vpcc_kernels.hip).  What the look-back relies on: every (frame,
+// group) is taken exactly once, and L grows with the group inside a frame.  gen_shape picks lanes and interleave so that a small
+// launch has no idle workgroups (a one-frame launch over 8 x 8 slots would dispatch 64 workgroups for every one that works).
 struct GenWork { uint32_t frame, group; bool any; };
-VPCC_HD inline GenWork gen_work_of(uint32_t L, uint32_t count, uint32_t groups_per_frame, uint32_t interleave) {
-  const uint32_t xcd = L & 7u, slot = L >> 3, per_round = interleave * groups_per_frame;
+struct GenShape { uint32_t lanes, interleave, grid; };
+VPCC_HD inline GenWork gen_work_of(uint32_t L, uint32_t count, uint32_t groups_per_frame, uint32_t interleave, uint32_t lanes) {
+  const uint32_t lane = L % lanes, slot = L / lanes, per_round = interleave * groups_per_frame;
   const uint32_t round = slot / per_round, r = slot - round * per_round, group = r / interleave, fi = r - group * interleave;
   GenWork w;
   w.group = group;
-  w.frame = (round * interleave + fi) * 8u + xcd;
+  w.frame = (round * interleave + fi) * lanes + lane;
   w.any = w.frame < count;
   return w;
 }
-inline uint32_t gen_grid_size(uint32_t count, uint32_t groups_per_frame, uint32_t interleave) {
-  const uint32_t per_xcd = (count + 7u) / 8u;
-  return 8u * ((per_xcd + interleave - 1u) / interleave) * interleave * groups_per_frame;
+inline GenShape gen_shape(uint32_t count, uint32_t groups_per_frame, uint32_t max_interleave) {
+  GenShape s;
+  s.lanes = count >= 8u ? 8u : (count ? count : 1u);
+  const uint32_t per_lane = (count + s.lanes - 1u) / s.lanes;
+  s.interleave = per_lane < max_interleave ? (per_lane ? per_lane : 1u) : max_interleave;
+  s.grid = s.lanes * ((per_lane + s.interleave - 1u) / s.interleave) * s.interleave * groups_per_frame;
+  return s;
 }
 // block_units: every frame of the launch has FrameShape::block_units (vpcc_host.hpp) — k_general_blocks, whose units are chunks
 // of ONE virtual block each, so that everything a block decides is scalar work; else k_general, which takes any frame.

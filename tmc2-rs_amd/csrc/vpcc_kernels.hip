@@ -493,8 +493,8 @@ __device__ __forceinline__ void copy_out(const unsigned char* lds, unsigned char
 #define VPCC_GEN_INTERLEAVE 8
 #endif
 constexpr uint32_t kGenInterleave = VPCC_GEN_INTERLEAVE;
-__device__ __forceinline__ GenWork gen_work(uint32_t first, uint32_t count, uint32_t groups_per_frame, uint32_t interleave) {
-  GenWork w = gen_work_of(blockIdx.x, count, groups_per_frame, interleave);      // vpcc_device.hpp (tests/fuzz_plan.cpp checks it on the CPU)
+__device__ __forceinline__ GenWork gen_work(uint32_t first, uint32_t count, uint32_t groups_per_frame, uint32_t interleave, uint32_t lanes) {
+  GenWork w = gen_work_of(blockIdx.x, count, groups_per_frame, interleave, lanes);   // vpcc_device.hpp (tests/fuzz_plan.cpp checks it on the CPU)
   w.frame += first;
   return w;
 }
@@ -502,8 +502,8 @@ __device__ __forceinline__ GenWork gen_work(uint32_t first, uint32_t count, uint
 #ifndef VPCC_GEN_WAVES
 #define VPCC_GEN_WAVES 7
 #endif
-__global__ __launch_bounds__(kGenThreads) __attribute__((amdgpu_waves_per_eu(VPCC_GEN_WAVES, 8))) void k_general(const DevFrame* __restrict__ frames, uint32_t first, uint32_t count, uint32_t groups_per_frame, uint32_t interleave, uint32_t gen) {
-  const GenWork work = gen_work(first, count, groups_per_frame, interleave);
+__global__ __launch_bounds__(kGenThreads) __attribute__((amdgpu_waves_per_eu(VPCC_GEN_WAVES, 8))) void k_general(const DevFrame* __restrict__ frames, uint32_t first, uint32_t count, uint32_t groups_per_frame, uint32_t interleave, uint32_t lanes, uint32_t gen) {
+  const GenWork work = gen_work(first, count, groups_per_frame, interleave, lanes);
   if (!work.any) return;
   const DevFrame& f = frames[work.frame];
   const uint32_t R = f.R, RR = R * R, n_vb = f.n_vblocks;
@@ -694,8 +694,8 @@ __device__ unsigned long long g_gen_stamps[kGenStampSlots][16];
 #ifndef VPCC_GENB_WAVES
 #define VPCC_GENB_WAVES 8
 #endif
-__global__ __launch_bounds__(kGenThreads) __attribute__((amdgpu_waves_per_eu(VPCC_GENB_WAVES, 8))) void k_general_blocks(const DevFrame* __restrict__ frames, uint32_t first, uint32_t count, uint32_t groups_per_frame, uint32_t interleave, uint32_t gen) {
-  const GenWork work = gen_work(first, count, groups_per_frame, interleave);
+__global__ __launch_bounds__(kGenThreads) __attribute__((amdgpu_waves_per_eu(VPCC_GENB_WAVES, 8))) void k_general_blocks(const DevFrame* __restrict__ frames, uint32_t first, uint32_t count, uint32_t groups_per_frame, uint32_t interleave, uint32_t lanes, uint32_t gen) {
+  const GenWork work = gen_work(first, count, groups_per_frame, interleave, lanes);
   if (!work.any) return;
   const VPCC_CONST DevFrame& f = *(const VPCC_CONST DevFrame*)(frames + work.frame);   // (host-written: scalar loads)
   constexpr uint32_t kU = kGenBlockUnits;
@@ -934,11 +934,13 @@ void launch_general(const DevFrame* d_frames, uint32_t first, uint32_t count, ui
   if (!count || !max_units) return;
   if (block_units) {
     const uint32_t groups = (max_units + kGenBlockUnits - 1u) / kGenBlockUnits;
-    hipLaunchKernelGGL(k_general_blocks, dim3(gen_grid_size(count, groups, kGenInterleave)), dim3(kGenThreads), 0, (hipStream_t)stream, d_frames, first, count, groups, kGenInterleave, gen);
+    const GenShape shape = gen_shape(count, groups, kGenInterleave);
+    hipLaunchKernelGGL(k_general_blocks, dim3(shape.grid), dim3(kGenThreads), 0, (hipStream_t)stream, d_frames, first, count, groups, shape.interleave, shape.lanes, gen);
     return;
   }
   const uint32_t groups = (max_units + kGenUnitsPerGroup - 1u) / kGenUnitsPerGroup;
-  hipLaunchKernelGGL(k_general, dim3(gen_grid_size(count, groups, kGenInterleave)), dim3(kGenThreads), 0, (hipStream_t)stream, d_frames, first, count, groups, kGenInterleave, gen);
+  const GenShape shape = gen_shape(count, groups, kGenInterleave);
+  hipLaunchKernelGGL(k_general, dim3(shape.grid), dim3(kGenThreads), 0, (hipStream_t)stream, d_frames, first, count, groups, shape.interleave, shape.lanes, gen);
 }
 // Plane ingest by the GPU itself: every workgroup pulls 64-KB pieces of page-locked HOST memory over PCIe (zero-copy
 // reads, 16 B per lane, coalesced) and stores them in HBM.  One launch moves all planes of a gof: 57 GB/s with 64

@@ -65,10 +65,11 @@ try:
             geo, col = [(True, False), (False, True), (True, True)][int(rng.integers(0, 3))]
             G = int(rng.choice([4, 8, 8, 16]))
             sm = (geo, col, G, int(rng.choice([0, 2, 4])), G if rng.random() < 0.6 else int(rng.choice([4, 8, 16])), int(rng.choice([0, 5, 10])), int(rng.choice([50, 100, 765])))
-        gofs, expect = [], []
-        for g in range(int(rng.integers(1, 15))):
-            idx = [int(k) for k in rng.integers(0, len(pool), size=int(rng.integers(1, 41)))]
-            gofs.append([pool[k][0] for k in idx]); expect += [expected(k, sm) for k in idx]
+        gofs, expect, picked = [], [], []
+        short = os.environ.get("VPCC_SOAK_SHORT_STREAMS") is not None     # many short streams: the start of a stream, over and over
+        for g in range(int(rng.integers(1, 4 if short else 15))):
+            idx = [int(k) for k in rng.integers(0, len(pool), size=int(rng.integers(1, 9 if short else 41)))]
+            gofs.append([pool[k][0] for k in idx]); expect += [expected(k, sm) for k in idx]; picked += idx
         lanes = int(rng.choice([1, 1, 2, 3, 4]))
         stop_at = int(rng.integers(0, len(expect))) if rng.random() < 0.15 else None
         container.write_container(path, gofs)
@@ -77,9 +78,17 @@ try:
             dec.set_smoothing(geometry=sm[0], color=sm[1], bitdepth=10, grid_size=sm[2], threshold=sm[3], color_grid_size=sm[4],
                               color_threshold_smoothing=sm[5], color_threshold_difference=sm[6])
         dec.start()
-        got = []
+        got, detail = [], []
         for fr in dec:
             got.append((fr["n"], crc(fr["xyz"], fr["rgb"])))
+            if sm is None and got[-1] != expect[len(got) - 1]:     # what differs, while the frame is at hand
+                ex, ec, _ = pool[picked[len(got) - 1]][2]
+                gx, gc = np.asarray(fr["xyz"]), np.asarray(fr["rgb"])
+                m = min(len(ex), len(gx))
+                dx = np.nonzero((gx[:m] != ex[:m]).any(axis=1))[0]; dc = np.nonzero((gc[:m] != ec[:m]).any(axis=1))[0]
+                detail.append(f"frame {len(got) - 1}: points {len(gx)} vs {len(ex)}; positions differ at {len(dx)} points (first {dx[:6].tolist()}, last {dx[-3:].tolist()}), "
+                              f"colours at {len(dc)} (first {dc[:6].tolist()}, last {dc[-3:].tolist()}); "
+                              f"got xyz {gx[dx[:2]].tolist() if len(dx) else []} want {ex[dx[:2]].tolist() if len(dx) else []}; got rgb {gc[dc[:2]].tolist() if len(dc) else []} want {ec[dc[:2]].tolist() if len(dc) else []}")
             if stop_at is not None and len(got) > stop_at:
                 break
         err = dec.error()
@@ -89,9 +98,25 @@ try:
         if not ok:
             bad += 1
             first = next((i for i, (a, b) in enumerate(zip(got, expect)) if a != b), None)
+            differ = [i for i, (a, b) in enumerate(zip(got, expect)) if a != b]
             print(f"MISMATCH stream {si}: {len(gofs)} GOFs of {[len(g) for g in gofs]} frames, {lanes} lanes, {on}, "
                   f"{ {k: os.environ[k] for k in ('VPCC_DECODER_PIN_CHUNK_MB', 'VPCC_DECODER_POOL_GIB') if k in os.environ} }, smoothing {sm}, stop_at {stop_at}: "
                   f"error {err!r}, {len(got)} of {len(expect)} frames, first difference at {first}", flush=True)
+            for line in detail[:8]:
+                print("  " + line, flush=True)
+            # which frames, what they are, and whether the same stream decoded again differs again
+            print("  frames that differ:", [(i, picked[i], pool[picked[i]][0]["width"], pool[picked[i]][0]["height"], pool[picked[i]][0]["occupancy_precision"],
+                                            "points %d vs %d" % (got[i][0], expect[i][0])) for i in differ[:12]], flush=True)
+            print("  the stream's frames (pool index, width, height, precision):", [(k, pool[k][0]["width"], pool[k][0]["height"], pool[k][0]["occupancy_precision"]) for k in picked[:48]], flush=True)
+            for again in range(3):
+                dec2 = recon.Decoder(path, devices=(0,) * lanes)
+                if sm is not None:
+                    dec2.set_smoothing(geometry=sm[0], color=sm[1], bitdepth=10, grid_size=sm[2], threshold=sm[3], color_grid_size=sm[4],
+                                       color_threshold_smoothing=sm[5], color_threshold_difference=sm[6])
+                dec2.start()
+                got2 = [(fr["n"], crc(fr["xyz"], fr["rgb"])) for fr in dec2]
+                dec2.close()
+                print(f"  decoded again ({again}): differs at {[i for i, (a, b) in enumerate(zip(got2, expect)) if a != b][:12]}", flush=True)
         if si % 10 == 9:
             print(f"{si + 1} streams, {frames} frames, {bad} bad, {time.time() - t0:.0f} s", flush=True)
 finally:
