@@ -54,6 +54,7 @@ try:
         for s in switches + ["VPCC_DECODER_PIN_CHUNK_MB", "VPCC_DECODER_POOL_GIB"]:
             os.environ.pop(s, None)
         on = [s for s in switches if rng.random() < 0.2]
+        on += [s for s in os.environ.get("VPCC_SOAK_FORCE_SWITCHES", "").split(",") if s and s not in on]     # (a hunt in one configuration)
         for s in on:
             os.environ[s] = "1"
         if rng.random() < 0.25:
