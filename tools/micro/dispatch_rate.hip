@@ -31,8 +31,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))) voi
   }
 }
 int main() {
-  unsigned* d; hipMalloc(&d, 4);
-  hipEvent_t a, b; hipEventCreate(&a); hipEventCreate(&b);
+  unsigned* d; (void)hipMalloc(&d, 4);
+  hipEvent_t a, b; (void)hipEventCreate(&a); (void)hipEventCreate(&b);
   const dim3 grid(790, 128);
   const unsigned groups = grid.x * grid.y;
   for (unsigned us : {0u, 2u, 4u, 6u, 8u}) {
@@ -40,11 +40,11 @@ int main() {
     for (int lds : {1024, 11428}) {
       auto run = [&](bool loop) {
         for (int r = 0; r < 4; ++r) {
-          if (r == 1) hipEventRecord(a);
+          if (r == 1) (void)hipEventRecord(a);
           if (!loop) { if (lds == 1024) hipLaunchKernelGGL(k_wg<1024>, grid, dim3(256), 0, 0, us * 100, d); else hipLaunchKernelGGL(k_wg<11428>, grid, dim3(256), 0, 0, us * 100, d); }
           else { if (lds == 1024) hipLaunchKernelGGL(k_loop<1024>, dim3(2048), dim3(256), 0, 0, us * 100, groups, d); else hipLaunchKernelGGL(k_loop<11428>, dim3(2048), dim3(256), 0, 0, us * 100, groups, d); }
         }
-        hipEventRecord(b); hipEventSynchronize(b); hipEventElapsedTime(&ms, a, b);
+        (void)hipEventRecord(b); (void)hipEventSynchronize(b); (void)hipEventElapsedTime(&ms, a, b);
         return ms / 3;
       };
       const float one = run(false), loop = run(true);
