@@ -85,6 +85,13 @@ int main(int argc, char** argv) {
     if (vpcc::validate_frame(&f, &shape) != VPCC_OK) { ++rejected; continue; }
     ++accepted;
     for (const vpcc_patch& p : patches) rotated += p.orientation >= 2 && p.orientation != 8;
+    {   // which frames k_general_blocks may take (FrameShape::block_units): said again here, independently
+      bool distinct = true;
+      for (const vpcc_patch& p : patches)
+        distinct = distinct && p.normal_axis != p.tangent_axis && p.normal_axis != p.bitangent_axis && p.tangent_axis != p.bitangent_axis;
+      const bool want = R >= 16 && R <= 256 && (R & (R - 1)) == 0 && (prec & (prec - 1)) == 0 && f.width <= 65536 && distinct;   // (tight rows: pitch = width)
+      if (shape.block_units != want) { std::fprintf(stderr, "block_units %d, expected %d (R %u, precision %u)\n", (int)shape.block_units, (int)want, R, prec); return 1; }
+    }
     // The host writes O(patches): vb_base, one item template per patch, the affine patches.  The virtual blocks are DERIVED
     // from them on the device (patch_of_vblock + vblock_of in k_plan_vblocks; the templates' origin and size_u0 in
     // k_plan_tiles): both derivations, run here on the CPU, must give the reference's loop nest — patches ascending, v0
