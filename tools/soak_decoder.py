@@ -2,7 +2,10 @@
 """Soak of the streaming Decoder: random streams — 1 .. 14 GOFs of 1 .. 40 frames drawn from a pool of random frames of several canvas
 sizes —, 1 .. 4 lanes (on one GPU), random ingest switches (stretches / kernel / copy engine, staged descriptors or not, the input
 page-locked in chunks, with or without the tail split, with or without a pool), now and then a consumer that stops early, three streams in ten with the smoothing filters switched on (random parameters); every
-frame that arrives is compared with the oracle's (and the smoothing specification's), in presentation order.  Usage: tools/soak_decoder.py [streams = 150] [first seed = 0]"""
+frame that arrives is compared with the oracle's (and the smoothing specification's), in presentation order; of a stream that differs the
+tool prints which frames, points and values, and decodes the same file three more times.  Usage: tools/soak_decoder.py [streams = 150] [first seed = 0]
+Environment: VPCC_SOAK_SHORT_STREAMS=1 — 1-3 GOFs of 1-8 frames (the start of a stream, over and over: seven streams a second);
+VPCC_SOAK_FORCE_SWITCHES=A,B — these switches on in every stream (a hunt in one configuration)."""
 import os, sys, tempfile, time, zlib
 REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(REPO, "tmc2-rs_amd")); sys.path.insert(0, os.path.join(REPO, "tests"))
